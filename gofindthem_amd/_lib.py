@@ -1,0 +1,62 @@
+"""ctypes binding of libgft.so (include/gft.h).  Fails loudly when the library is missing: there is no
+Python/CPU implementation of the hot path in this package."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libgft.so")
+
+GFT_OK, GFT_E_INVALID, GFT_E_NOT_BUILT, GFT_E_HIP, GFT_E_UNSUPPORTED, GFT_E_PARSE, GFT_E_ENGINE = 0, -1, -2, -3, -4, -5, -6
+GFT_POS_START, GFT_POS_END = 0, 1
+GFT_FOLD_ASCII = 1
+OP_UNIT, OP_AND, OP_OR, OP_NOT, OP_INORD = 1, 2, 3, 4, 5
+INORD_FLAG = 1 << 27
+
+
+class GftMatches(C.Structure):
+    _fields_ = [("n_docs", C.c_uint64), ("n_matches", C.c_uint64), ("match_off", C.c_void_p),
+                ("term_id", C.c_void_p), ("pos", C.c_void_p)]
+
+
+class GftExtra(C.Structure):
+    _fields_ = [("off", C.c_void_p), ("slot", C.c_void_p), ("pos", C.c_void_p)]
+
+
+# every symbol include/gft.h declares: (restype, argtypes)
+_vp, _u32, _u64, _i = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+SYMBOLS = {
+    "gft_engine_create": (_i, [C.POINTER(_vp), _i]),
+    "gft_engine_destroy": (None, [_vp]),
+    "gft_last_error": (C.c_char_p, [_vp]),
+    "gft_set_stream": (_i, [_vp, _vp]),
+    "gft_build": (_i, [_vp, _vp, _vp, _u32, _u32]),
+    "gft_n_terms": (_u32, [_vp]),
+    "gft_n_states": (_u32, [_vp]),
+    "gft_term": (_i, [_vp, _u32, C.POINTER(_vp), C.POINTER(_u32)]),
+    "gft_term_id": (C.c_int64, [_vp, _vp, _u32]),
+    "gft_scan": (_i, [_vp, _vp, _vp, _u64, _u32, C.POINTER(GftMatches)]),
+    "gft_scan_device": (_i, [_vp, _vp, _vp, _u64, _u32, C.POINTER(GftMatches)]),
+    "gft_set_programs": (_i, [_vp, _vp, _vp, _u32, _u32]),
+    "gft_n_exprs": (_u32, [_vp]),
+    "gft_process": (_i, [_vp, _vp, _vp, _u64, _u32, C.POINTER(GftExtra), _vp]),
+    "gft_process_device": (_i, [_vp, _vp, _vp, _u64, _u32, C.POINTER(GftExtra), _vp]),
+    "gft_profile_enable": (_i, [_vp, _i]),
+    "gft_profile_read": (_i, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_u64)]),
+    "gft_profile_reset": (_i, [_vp]),
+}
+
+_LIB = None
+
+
+def load():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libgft.so is not built (run `python -m gofindthem_amd.build`); "
+                               "gofindthem_amd has no CPU fallback for the hot path")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            f = getattr(L, name)            # AttributeError if a declared symbol is not exported
+            f.restype, f.argtypes = res, args
+        _LIB = L
+    return _LIB

@@ -1,0 +1,60 @@
+"""In-tree build of the HIP/C++ pieces for gfx950 (no cmake needed: a handful of hipcc/g++ invocations).
+
+    python -m gofindthem_amd.build          # builds libgft.so (product) and libgfworkload.so (bench utility)
+
+hipcc cross-compiles gfx950 code objects without a GPU, so this runs in the CPU-only container; the built
+.so files are git-ignored but travel to the GPU box with the repository snapshot.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libgft.so")
+ARCH = "gfx950"
+
+HIP_SOURCES = ["gft_kernels.hip"]
+CXX_SOURCES = ["gft_api.cpp", "ac_tables.cpp", "dsl_compile.cpp", "finder_host.cpp"]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_lib(force=False, verbose=False):
+    srcs = [os.path.join(CSRC, f) for f in HIP_SOURCES + CXX_SOURCES if os.path.exists(os.path.join(CSRC, f))]
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))]
+    hdrs.append(os.path.join(os.path.dirname(HERE), "include", "gft.h"))
+    if not force and not _newer(LIB, srcs + hdrs):
+        return LIB
+    objs = []
+    for s in srcs:
+        o = os.path.join(CSRC, os.path.basename(s) + ".o")
+        if force or _newer(o, [s] + hdrs):
+            cmd = ["hipcc", "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-c", s, "-o", o]
+            if s.endswith(".cpp"):
+                cmd[1:1] = ["-x", "hip"]   # host code that includes hip_runtime.h; no kernels inside
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        objs.append(o)
+    cmd = ["hipcc", "-shared", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+def build_all(force=False, verbose=False):
+    lib = build_lib(force, verbose)
+    from . import workload
+    wl = workload.build(force)
+    return lib, wl
+
+
+if __name__ == "__main__":
+    print(build_all(force="--force" in sys.argv, verbose=True))

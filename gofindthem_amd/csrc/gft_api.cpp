@@ -1,0 +1,584 @@
+// gft_api.cpp -- the C ABI of include/gft.h: engine handle, table upload, workspace management and the
+// kernel pipelines behind gft_scan* / gft_process*.  Host orchestration only; all per-byte and per-match work
+// happens in gft_kernels.hip.  There is no CPU fallback: every compute entry point needs a HIP device.
+#include "../../include/gft.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "ac_tables.hpp"
+#include "gft_kernels.hpp"
+
+using namespace gft;
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct ProfCat {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+};
+
+}  // namespace
+
+struct gft_engine {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    unsigned n_cus = 256;
+    size_t lds_max = 65536;
+    mutable std::string err;
+
+    // automaton
+    AcTables tab;
+    bool built = false;
+    uint32_t build_flags = 0;
+    uint32_t n_lds_states = 0;
+    DevBuf d_byte_class, d_delta, d_out_term, d_out_link, d_term_len;
+
+    // programs
+    bool have_programs = false;
+    uint32_t n_exprs = 0, n_extra = 0;
+    DevBuf d_prog, d_prog_off;
+
+    // workspace
+    DevBuf d_unit_cnt, d_unit_base, d_units, d_partial, d_cursor, d_pool_term, d_pool_pos, d_unit_start,
+        d_unit_count, d_unit_out, d_term, d_pos, d_match_off;
+    uint64_t pool_cap = 0;
+    // staging for the host-buffer entry points
+    DevBuf d_text, d_doc_off, d_bitmap, d_xoff, d_xslot, d_xpos;
+    std::vector<uint64_t> h_match_off;
+    std::vector<uint32_t> h_term, h_pos;
+
+    // profiling
+    bool profiling = false;
+    std::map<std::string, ProfCat> prof;
+};
+
+namespace {
+
+int fail(const gft_engine* e, int code, const std::string& msg) {
+    e->err = msg;
+    return code;
+}
+int fail_hip(const gft_engine* e, hipError_t h, const char* what) {
+    e->err = std::string(what) + ": " + hipGetErrorString(h);
+    return GFT_E_HIP;
+}
+
+#define HIP_TRY(expr, what)                                   \
+    do {                                                      \
+        hipError_t _h = (expr);                               \
+        if (_h != hipSuccess) return fail_hip(e, _h, what);   \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+struct ProfScope {
+    gft_engine* e;
+    hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(gft_engine* e_, const char* cat) : e(e_) {
+        if (!e->profiling) return;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+        (void)hipEventRecord(a, e->stream);
+        e->prof[cat].ev.emplace_back(a, b);
+    }
+    ~ProfScope() { if (b) (void)hipEventRecord(b, e->stream); }
+};
+
+template <class T>
+int upload(gft_engine* e, DevBuf& buf, const std::vector<T>& v, const char* what) {
+    HIP_TRY(buf.ensure(std::max<size_t>(v.size() * sizeof(T), 16)), what);
+    if (!v.empty()) HIP_TRY(hipMemcpyAsync(buf.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, e->stream), what);
+    return GFT_OK;
+}
+
+// validates one postfix program and measures its stack needs
+int check_program(const gft_engine* e, const uint32_t* w, uint64_t len, uint32_t n_slots, uint32_t idx) {
+    uint32_t sp = 0, psp = 0;
+    std::vector<uint32_t> pcnt;   // pair counts of the INORD operand stack
+    bool in_group = false;
+    auto bad = [&](const char* m) {
+        return fail(e, GFT_E_INVALID, "program " + std::to_string(idx) + ": " + m);
+    };
+    for (uint64_t pc = 0; pc < len; pc++) {
+        const uint32_t op = w[pc] >> 28;
+        const bool fl = (w[pc] & GFT_INORD_FLAG) != 0;
+        switch (op) {
+        case GFT_OP_UNIT:
+            if ((w[pc] & GFT_SLOT_MASK) >= n_slots) return bad("slot out of range");
+            sp++;
+            if (fl) { pcnt.push_back(1); in_group = true; }
+            break;
+        case GFT_OP_AND:
+        case GFT_OP_OR:
+            if (sp < 2) return bad("operand stack underflow");
+            sp--;
+            if (fl) {
+                if (pcnt.size() < 2) return bad("INORD operand stack underflow");
+                uint32_t r = pcnt.back(); pcnt.pop_back();
+                if (op == GFT_OP_AND) pcnt.back() = r; else pcnt.back() += r;
+            }
+            break;
+        case GFT_OP_NOT:
+            if (sp < 1) return bad("operand stack underflow");
+            if (in_group) return bad("NOT inside INORD");
+            break;
+        case GFT_OP_INORD:
+            if (sp < 1 || pcnt.size() != 1) return bad("malformed INORD group");
+            pcnt.clear(); in_group = false;
+            break;
+        default:
+            return bad("unknown opcode");
+        }
+        if (sp > kMaxBoolDepth)
+            return fail(e, GFT_E_UNSUPPORTED, "program " + std::to_string(idx) + ": operand stack deeper than " +
+                                                   std::to_string(kMaxBoolDepth));
+        uint32_t tot = 0;
+        for (uint32_t c : pcnt) tot += c;
+        psp = (uint32_t)pcnt.size();
+        if (tot > kMaxPairs || psp > kMaxPairDepth)
+            return fail(e, GFT_E_UNSUPPORTED, "program " + std::to_string(idx) + ": INORD group too wide for the device solver");
+    }
+    if (sp != 1 || !pcnt.empty()) return bad("program does not reduce to one value");
+    return GFT_OK;
+}
+
+int ensure_pool(gft_engine* e, uint64_t entries) {
+    if (entries <= e->pool_cap) return GFT_OK;
+    HIP_TRY(e->d_pool_term.ensure(entries * 4), "pool alloc");
+    HIP_TRY(e->d_pool_pos.ensure(entries * 4), "pool alloc");
+    e->pool_cap = std::min(e->d_pool_term.cap, e->d_pool_pos.cap) / 4;
+    return GFT_OK;
+}
+
+// The device pipeline shared by scan and process.  On success the canonical CSR sits in e->d_match_off /
+// d_term / d_pos and *n_matches is set.
+int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_off, uint64_t n_docs, uint32_t flags,
+                  uint64_t* n_matches) {
+    hipStream_t st = e->stream;
+    *n_matches = 0;
+    HIP_TRY(e->d_match_off.ensure((n_docs + 1) * 8), "match_off alloc");
+    if (n_docs == 0) {
+        HIP_TRY(hipMemsetAsync(e->d_match_off.p, 0, 8, st), "memset");
+        HIP_TRY(hipStreamSynchronize(st), "sync");
+        return GFT_OK;
+    }
+    const uint32_t warm = e->tab.max_term_len ? e->tab.max_term_len - 1 : 0;
+    const uint32_t unit_max = kTextBuf - warm;
+
+    // 1. work units
+    HIP_TRY(e->d_unit_cnt.ensure(n_docs * 4), "unit alloc");
+    HIP_TRY(e->d_unit_base.ensure((n_docs + 1) * 8), "unit alloc");
+    HIP_TRY(e->d_partial.ensure(scan_partials_needed(n_docs) * 8), "unit alloc");
+    uint64_t n_units = 0, text_lo = 0, text_hi = 0;
+    {
+        ProfScope ps(e, "aux");
+        HIP_TRY(launch_unit_count(d_doc_off, n_docs, unit_max, e->d_unit_cnt.as<uint32_t>(), st), "unit_count");
+        HIP_TRY(launch_exclusive_scan(e->d_unit_cnt.as<uint32_t>(), n_docs, e->d_unit_base.as<uint64_t>(),
+                                      e->d_partial.as<uint64_t>(), st), "unit scan");
+    }
+    HIP_TRY(hipMemcpyAsync(&n_units, e->d_unit_base.as<uint64_t>() + n_docs, 8, hipMemcpyDeviceToHost, st), "readback");
+    HIP_TRY(hipMemcpyAsync(&text_lo, d_doc_off, 8, hipMemcpyDeviceToHost, st), "readback");
+    HIP_TRY(hipMemcpyAsync(&text_hi, d_doc_off + n_docs, 8, hipMemcpyDeviceToHost, st), "readback");
+    HIP_TRY(hipStreamSynchronize(st), "sync");
+    if (text_hi < text_lo) return fail(e, GFT_E_INVALID, "doc_off is not ascending");
+
+    HIP_TRY(e->d_units.ensure(n_units * sizeof(Unit)), "unit alloc");
+    HIP_TRY(e->d_unit_start.ensure(n_units * 8), "unit alloc");
+    HIP_TRY(e->d_unit_count.ensure(n_units * 4), "unit alloc");
+    HIP_TRY(e->d_unit_out.ensure((n_units + 1) * 8), "unit alloc");
+    HIP_TRY(e->d_partial.ensure(scan_partials_needed(std::max(n_units, n_docs)) * 8), "unit alloc");
+    HIP_TRY(e->d_cursor.ensure(8), "cursor alloc");
+    {
+        ProfScope ps(e, "aux");
+        HIP_TRY(launch_unit_fill(d_doc_off, n_docs, e->d_unit_base.as<uint64_t>(), e->d_units.as<Unit>(), st), "unit_fill");
+    }
+
+    // 2. automaton walk into the slab pool; grow the pool and re-run if it overflowed (never truncate)
+    int rc = ensure_pool(e, std::max<uint64_t>(1u << 20, (text_hi - text_lo) / 16));
+    if (rc) return rc;
+    uint64_t total = 0;
+    for (int attempt = 0; attempt < 3; attempt++) {
+        HIP_TRY(hipMemsetAsync(e->d_cursor.p, 0, 8, st), "memset");
+        ScanParams P;
+        P.text = d_text; P.doc_off = d_doc_off; P.units = e->d_units.as<Unit>(); P.n_units = n_units;
+        P.byte_class = e->d_byte_class.as<uint8_t>(); P.delta = e->d_delta.as<uint32_t>();
+        P.out_term = e->d_out_term.as<uint32_t>(); P.out_link = e->d_out_link.as<uint32_t>();
+        P.term_len = e->d_term_len.as<uint32_t>();
+        P.n_classes = e->tab.n_classes; P.n_states = e->tab.n_states; P.n_lds_states = e->n_lds_states;
+        P.max_term_len = e->tab.max_term_len;
+        P.pos_end = (e->build_flags & GFT_POS_END) ? 1 : 0;
+        P.fold = (flags & GFT_FOLD_ASCII) ? 1 : 0;
+        P.cursor = e->d_cursor.as<uint64_t>(); P.pool_cap = e->pool_cap;
+        P.pool_term = e->d_pool_term.as<uint32_t>(); P.pool_pos = e->d_pool_pos.as<uint32_t>();
+        P.unit_start = e->d_unit_start.as<uint64_t>(); P.unit_count = e->d_unit_count.as<uint32_t>();
+        {
+            ProfScope ps(e, "scan");
+            HIP_TRY(launch_scan_units(P, e->n_cus, st), "scan kernel launch");
+        }
+        HIP_TRY(hipMemcpyAsync(&total, e->d_cursor.p, 8, hipMemcpyDeviceToHost, st), "readback");
+        HIP_TRY(hipStreamSynchronize(st), "scan kernel");
+        if (total <= e->pool_cap) break;
+        if (attempt == 2) return fail(e, GFT_E_HIP, "match pool overflow persisted");
+        rc = ensure_pool(e, total + total / 16);
+        if (rc) return rc;
+    }
+
+    // 3. slabs -> canonical CSR
+    HIP_TRY(e->d_term.ensure(std::max<uint64_t>(total, 1) * 4), "result alloc");
+    HIP_TRY(e->d_pos.ensure(std::max<uint64_t>(total, 1) * 4), "result alloc");
+    {
+        ProfScope ps(e, "aux");
+        HIP_TRY(launch_exclusive_scan(e->d_unit_count.as<uint32_t>(), n_units, e->d_unit_out.as<uint64_t>(),
+                                      e->d_partial.as<uint64_t>(), st), "unit_out scan");
+        HIP_TRY(launch_gather(e->d_unit_start.as<uint64_t>(), e->d_unit_count.as<uint32_t>(),
+                              e->d_unit_out.as<uint64_t>(), n_units, e->d_pool_term.as<uint32_t>(),
+                              e->d_pool_pos.as<uint32_t>(), e->d_term.as<uint32_t>(), e->d_pos.as<uint32_t>(),
+                              e->d_unit_base.as<uint64_t>(), n_docs, e->d_match_off.as<uint64_t>(), e->n_cus, st),
+                "gather");
+    }
+    *n_matches = total;
+    return GFT_OK;
+}
+
+int solve_pipeline(gft_engine* e, uint64_t n_docs, const gft_extra_matches* d_extra, uint32_t* d_bitmap) {
+    if (!n_docs || !e->n_exprs) return GFT_OK;
+    SolveParams S;
+    S.match_off = e->d_match_off.as<uint64_t>(); S.term_id = e->d_term.as<uint32_t>(); S.pos = e->d_pos.as<uint32_t>();
+    S.x_off = d_extra ? d_extra->off : nullptr;
+    S.x_slot = d_extra ? d_extra->slot : nullptr;
+    S.x_pos = d_extra ? d_extra->pos : nullptr;
+    S.n_docs = n_docs;
+    S.prog = e->d_prog.as<uint32_t>(); S.prog_off = e->d_prog_off.as<uint64_t>();
+    S.n_exprs = e->n_exprs; S.n_terms = (uint32_t)e->tab.terms.size();
+    S.present_words = (S.n_terms + e->n_extra + 31) / 32 + 1;
+    S.bitmap = d_bitmap;
+    if (solve_lds_bytes(S.present_words) > e->lds_max)
+        return fail(e, GFT_E_UNSUPPORTED, "dictionary too large for the LDS presence bitset");
+    ProfScope ps(e, "solve");
+    HIP_TRY(launch_solve(S, e->n_cus, e->stream), "solve kernel launch");
+    return GFT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gft_engine_create(gft_engine** out, int device) {
+    if (!out) return GFT_E_INVALID;
+    *out = nullptr;
+    gft_engine* e = new gft_engine();
+    int count = 0;
+    hipError_t h = hipGetDeviceCount(&count);
+    if (h != hipSuccess || count == 0) {
+        // keep the handle so the caller can read the message, but every compute call will fail loudly
+        e->device = -1;
+        e->err = std::string("no HIP device available: ") + (h != hipSuccess ? hipGetErrorString(h) : "device count is 0");
+        *out = e;
+        return GFT_E_HIP;
+    }
+    if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
+    e->device = device;
+    DeviceGuard g(device);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        e->n_cus = prop.multiProcessorCount > 0 ? (unsigned)prop.multiProcessorCount : 256;
+        int optin = 0;
+        if (hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, device) != hipSuccess) optin = 0;
+        e->lds_max = std::max<size_t>(prop.sharedMemPerBlock, (size_t)std::max(optin, 0));
+        if (std::string(prop.gcnArchName).find("gfx950") != std::string::npos) e->lds_max = std::max<size_t>(e->lds_max, 160 * 1024);
+    }
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) == hipSuccess) e->own_stream = true;
+    else e->stream = nullptr;
+    *out = e;
+    return GFT_OK;
+}
+
+void gft_engine_destroy(gft_engine* e) {
+    if (!e) return;
+    if (e->device >= 0) {
+        DeviceGuard g(e->device);
+        if (e->stream) (void)hipStreamSynchronize(e->stream);
+        for (auto& kv : e->prof)
+            for (auto& p : kv.second.ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+        DevBuf* all[] = {&e->d_byte_class, &e->d_delta, &e->d_out_term, &e->d_out_link, &e->d_term_len, &e->d_prog,
+                         &e->d_prog_off, &e->d_unit_cnt, &e->d_unit_base, &e->d_units, &e->d_partial, &e->d_cursor,
+                         &e->d_pool_term, &e->d_pool_pos, &e->d_unit_start, &e->d_unit_count, &e->d_unit_out,
+                         &e->d_term, &e->d_pos, &e->d_match_off, &e->d_text, &e->d_doc_off, &e->d_bitmap, &e->d_xoff,
+                         &e->d_xslot, &e->d_xpos};
+        for (DevBuf* b : all) b->release();
+        if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+    }
+    delete e;
+}
+
+const char* gft_last_error(const gft_engine* e) { return e ? e->err.c_str() : "null engine"; }
+
+int gft_set_stream(gft_engine* e, void* hip_stream) {
+    if (!e) return GFT_E_INVALID;
+    if (e->device < 0) return fail(e, GFT_E_HIP, "no HIP device available");
+    DeviceGuard g(e->device);
+    if (e->own_stream && e->stream) { (void)hipStreamSynchronize(e->stream); (void)hipStreamDestroy(e->stream); }
+    e->own_stream = false;
+    e->stream = (hipStream_t)hip_stream;
+    if (!hip_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking), "stream create");
+        e->own_stream = true;
+    }
+    return GFT_OK;
+}
+
+int gft_build(gft_engine* e, const uint8_t* terms_blob, const uint64_t* term_off, uint32_t n_terms, uint32_t flags) {
+    if (!e || (n_terms && (!terms_blob || !term_off))) return e ? fail(e, GFT_E_INVALID, "null argument") : GFT_E_INVALID;
+    if (e->device < 0) return fail(e, GFT_E_HIP, "no HIP device available");
+    std::vector<std::string> terms;
+    terms.reserve(n_terms);
+    for (uint32_t i = 0; i < n_terms; i++) {
+        if (term_off[i + 1] < term_off[i]) return fail(e, GFT_E_INVALID, "term_off is not ascending");
+        terms.emplace_back((const char*)terms_blob + term_off[i], (size_t)(term_off[i + 1] - term_off[i]));
+    }
+    e->built = false;
+    build_ac_tables(std::move(terms), e->tab);
+    if (e->tab.max_term_len + 1024 > kTextBuf)
+        return fail(e, GFT_E_UNSUPPORTED, "keyword longer than " + std::to_string(kTextBuf - 1024) + " bytes");
+    if (e->tab.n_states >= 0x7FFFFFFFu) return fail(e, GFT_E_UNSUPPORTED, "automaton too large");
+    e->build_flags = flags;
+
+    DeviceGuard g(e->device);
+    const size_t fixed = 256 + (size_t)(kScanBlockThreads / 64) * kTextBuf + 1024;
+    if (e->lds_max < fixed + (size_t)e->tab.n_classes * 4)
+        return fail(e, GFT_E_UNSUPPORTED, "device LDS too small for the scan kernel");
+    size_t rows = (e->lds_max - fixed) / ((size_t)e->tab.n_classes * 4);
+    e->n_lds_states = (uint32_t)std::min<size_t>(rows, e->tab.n_states);
+
+    std::vector<uint8_t> bc(e->tab.byte_class, e->tab.byte_class + 256);
+    int rc;
+    if ((rc = upload(e, e->d_byte_class, bc, "table upload"))) return rc;
+    if ((rc = upload(e, e->d_delta, e->tab.delta, "table upload"))) return rc;
+    if ((rc = upload(e, e->d_out_term, e->tab.out_term, "table upload"))) return rc;
+    if ((rc = upload(e, e->d_out_link, e->tab.out_link, "table upload"))) return rc;
+    if ((rc = upload(e, e->d_term_len, e->tab.term_len, "table upload"))) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream), "table upload");
+    e->built = true;
+    e->have_programs = false;   // slots refer to the dictionary: programs must be set again
+    e->n_exprs = 0;
+    return GFT_OK;
+}
+
+uint32_t gft_n_terms(const gft_engine* e) { return e ? (uint32_t)e->tab.terms.size() : 0; }
+uint32_t gft_n_states(const gft_engine* e) { return e ? e->tab.n_states : 0; }
+uint32_t gft_n_exprs(const gft_engine* e) { return e ? e->n_exprs : 0; }
+
+int gft_term(const gft_engine* e, uint32_t term_id, const uint8_t** ptr, uint32_t* len) {
+    if (!e || !ptr || !len) return GFT_E_INVALID;
+    if (term_id >= e->tab.terms.size()) return fail(e, GFT_E_INVALID, "term id out of range");
+    *ptr = (const uint8_t*)e->tab.terms[term_id].data();
+    *len = (uint32_t)e->tab.terms[term_id].size();
+    return GFT_OK;
+}
+
+int64_t gft_term_id(const gft_engine* e, const uint8_t* term, uint32_t len) {
+    if (!e) return -1;
+    std::string s((const char*)term, len);
+    auto it = std::lower_bound(e->tab.terms.begin(), e->tab.terms.end(), s);
+    if (it == e->tab.terms.end() || *it != s) return -1;
+    return (int64_t)(it - e->tab.terms.begin());
+}
+
+int gft_scan_device(gft_engine* e, const uint8_t* d_text_blob, const uint64_t* d_doc_off, uint64_t n_docs,
+                    uint32_t flags, gft_matches* out_dev) {
+    if (!e || !out_dev || (n_docs && (!d_text_blob || !d_doc_off))) return e ? fail(e, GFT_E_INVALID, "null argument") : GFT_E_INVALID;
+    if (e->device < 0) return fail(e, GFT_E_HIP, "no HIP device available");
+    if (!e->built) return fail(e, GFT_E_NOT_BUILT, "gft_build has not been called");
+    DeviceGuard g(e->device);
+    uint64_t nm = 0;
+    int rc = scan_pipeline(e, d_text_blob, d_doc_off, n_docs, flags, &nm);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream), "scan pipeline");
+    out_dev->n_docs = n_docs; out_dev->n_matches = nm;
+    out_dev->match_off = e->d_match_off.as<uint64_t>();
+    out_dev->term_id = e->d_term.as<uint32_t>();
+    out_dev->pos = e->d_pos.as<uint32_t>();
+    return GFT_OK;
+}
+
+static int stage_docs(gft_engine* e, const uint8_t* text_blob, const uint64_t* doc_off, uint64_t n_docs) {
+    const uint64_t bytes = n_docs ? doc_off[n_docs] : 0;
+    HIP_TRY(e->d_text.ensure(bytes + 64), "text alloc");
+    HIP_TRY(e->d_doc_off.ensure((n_docs + 1) * 8), "doc_off alloc");
+    if (bytes) HIP_TRY(hipMemcpyAsync(e->d_text.p, text_blob, bytes, hipMemcpyHostToDevice, e->stream), "text upload");
+    if (n_docs) HIP_TRY(hipMemcpyAsync(e->d_doc_off.p, doc_off, (n_docs + 1) * 8, hipMemcpyHostToDevice, e->stream), "doc_off upload");
+    return GFT_OK;
+}
+
+int gft_scan(gft_engine* e, const uint8_t* text_blob, const uint64_t* doc_off, uint64_t n_docs, uint32_t flags,
+             gft_matches* out) {
+    if (!e || !out || (n_docs && (!doc_off))) return e ? fail(e, GFT_E_INVALID, "null argument") : GFT_E_INVALID;
+    if (e->device < 0) return fail(e, GFT_E_HIP, "no HIP device available");
+    if (!e->built) return fail(e, GFT_E_NOT_BUILT, "gft_build has not been called");
+    DeviceGuard g(e->device);
+    int rc = stage_docs(e, text_blob, doc_off, n_docs);
+    if (rc) return rc;
+    uint64_t nm = 0;
+    rc = scan_pipeline(e, e->d_text.as<uint8_t>(), e->d_doc_off.as<uint64_t>(), n_docs, flags, &nm);
+    if (rc) return rc;
+    e->h_match_off.assign(n_docs + 1, 0);
+    e->h_term.assign(nm, 0);
+    e->h_pos.assign(nm, 0);
+    HIP_TRY(hipMemcpyAsync(e->h_match_off.data(), e->d_match_off.p, (n_docs + 1) * 8, hipMemcpyDeviceToHost, e->stream), "download");
+    if (nm) {
+        HIP_TRY(hipMemcpyAsync(e->h_term.data(), e->d_term.p, nm * 4, hipMemcpyDeviceToHost, e->stream), "download");
+        HIP_TRY(hipMemcpyAsync(e->h_pos.data(), e->d_pos.p, nm * 4, hipMemcpyDeviceToHost, e->stream), "download");
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream), "scan pipeline");
+    out->n_docs = n_docs; out->n_matches = nm;
+    out->match_off = e->h_match_off.data(); out->term_id = e->h_term.data(); out->pos = e->h_pos.data();
+    return GFT_OK;
+}
+
+int gft_set_programs(gft_engine* e, const uint32_t* prog_words, const uint64_t* prog_off, uint32_t n_exprs,
+                     uint32_t n_extra) {
+    if (!e || (n_exprs && (!prog_words || !prog_off))) return e ? fail(e, GFT_E_INVALID, "null argument") : GFT_E_INVALID;
+    if (e->device < 0) return fail(e, GFT_E_HIP, "no HIP device available");
+    if (!e->built) return fail(e, GFT_E_NOT_BUILT, "gft_build has not been called");
+    const uint32_t n_slots = (uint32_t)e->tab.terms.size() + n_extra;
+    if (n_slots > GFT_SLOT_MASK) return fail(e, GFT_E_UNSUPPORTED, "too many slots");
+    for (uint32_t i = 0; i < n_exprs; i++) {
+        if (prog_off[i + 1] < prog_off[i]) return fail(e, GFT_E_INVALID, "prog_off is not ascending");
+        int rc = check_program(e, prog_words + prog_off[i], prog_off[i + 1] - prog_off[i], n_slots, i);
+        if (rc) return rc;
+    }
+    DeviceGuard g(e->device);
+    std::vector<uint32_t> w(prog_words, prog_words + (n_exprs ? prog_off[n_exprs] : 0));
+    std::vector<uint64_t> o(prog_off, prog_off + (n_exprs ? n_exprs + 1 : 0));
+    if (o.empty()) o.push_back(0);
+    int rc;
+    if ((rc = upload(e, e->d_prog, w, "program upload"))) return rc;
+    if ((rc = upload(e, e->d_prog_off, o, "program upload"))) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream), "program upload");
+    e->n_exprs = n_exprs; e->n_extra = n_extra; e->have_programs = true;
+    return GFT_OK;
+}
+
+int gft_process_device(gft_engine* e, const uint8_t* d_text_blob, const uint64_t* d_doc_off, uint64_t n_docs,
+                       uint32_t flags, const gft_extra_matches* d_extra, uint32_t* d_hit_bitmap) {
+    if (!e || (n_docs && (!d_text_blob || !d_doc_off))) return e ? fail(e, GFT_E_INVALID, "null argument") : GFT_E_INVALID;
+    if (e->device < 0) return fail(e, GFT_E_HIP, "no HIP device available");
+    if (!e->built) return fail(e, GFT_E_NOT_BUILT, "gft_build has not been called");
+    if (!e->have_programs) return fail(e, GFT_E_NOT_BUILT, "gft_set_programs has not been called");
+    if (n_docs && e->n_exprs && !d_hit_bitmap) return fail(e, GFT_E_INVALID, "null bitmap");
+    DeviceGuard g(e->device);
+    uint64_t nm = 0;
+    int rc = scan_pipeline(e, d_text_blob, d_doc_off, n_docs, flags, &nm);
+    if (rc) return rc;
+    rc = solve_pipeline(e, n_docs, d_extra, d_hit_bitmap);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream), "process pipeline");
+    return GFT_OK;
+}
+
+int gft_process(gft_engine* e, const uint8_t* text_blob, const uint64_t* doc_off, uint64_t n_docs, uint32_t flags,
+                const gft_extra_matches* extra, uint32_t* hit_bitmap) {
+    if (!e || (n_docs && !doc_off)) return e ? fail(e, GFT_E_INVALID, "null argument") : GFT_E_INVALID;
+    if (e->device < 0) return fail(e, GFT_E_HIP, "no HIP device available");
+    if (!e->built) return fail(e, GFT_E_NOT_BUILT, "gft_build has not been called");
+    if (!e->have_programs) return fail(e, GFT_E_NOT_BUILT, "gft_set_programs has not been called");
+    DeviceGuard g(e->device);
+    int rc = stage_docs(e, text_blob, doc_off, n_docs);
+    if (rc) return rc;
+    gft_extra_matches dx;
+    const gft_extra_matches* pdx = nullptr;
+    if (extra && extra->off && n_docs) {
+        const uint64_t nx = extra->off[n_docs];
+        HIP_TRY(e->d_xoff.ensure((n_docs + 1) * 8), "extra alloc");
+        HIP_TRY(e->d_xslot.ensure(std::max<uint64_t>(nx, 1) * 4), "extra alloc");
+        HIP_TRY(e->d_xpos.ensure(std::max<uint64_t>(nx, 1) * 4), "extra alloc");
+        HIP_TRY(hipMemcpyAsync(e->d_xoff.p, extra->off, (n_docs + 1) * 8, hipMemcpyHostToDevice, e->stream), "extra upload");
+        if (nx) {
+            for (uint64_t i = 0; i < nx; i++)
+                if (extra->slot[i] >= e->n_extra) return fail(e, GFT_E_INVALID, "extra slot out of range");
+            HIP_TRY(hipMemcpyAsync(e->d_xslot.p, extra->slot, nx * 4, hipMemcpyHostToDevice, e->stream), "extra upload");
+            HIP_TRY(hipMemcpyAsync(e->d_xpos.p, extra->pos, nx * 4, hipMemcpyHostToDevice, e->stream), "extra upload");
+        }
+        dx.off = e->d_xoff.as<uint64_t>(); dx.slot = e->d_xslot.as<uint32_t>(); dx.pos = e->d_xpos.as<uint32_t>();
+        pdx = &dx;
+    }
+    const uint64_t words = (e->n_exprs + 31) / 32;
+    HIP_TRY(e->d_bitmap.ensure(std::max<uint64_t>(n_docs * words, 1) * 4), "bitmap alloc");
+    uint64_t nm = 0;
+    rc = scan_pipeline(e, e->d_text.as<uint8_t>(), e->d_doc_off.as<uint64_t>(), n_docs, flags, &nm);
+    if (rc) return rc;
+    rc = solve_pipeline(e, n_docs, pdx, e->d_bitmap.as<uint32_t>());
+    if (rc) return rc;
+    if (n_docs * words) {
+        if (!hit_bitmap) return fail(e, GFT_E_INVALID, "null bitmap");
+        HIP_TRY(hipMemcpyAsync(hit_bitmap, e->d_bitmap.p, n_docs * words * 4, hipMemcpyDeviceToHost, e->stream), "download");
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream), "process pipeline");
+    return GFT_OK;
+}
+
+int gft_profile_enable(gft_engine* e, int on) {
+    if (!e) return GFT_E_INVALID;
+    e->profiling = on != 0;
+    return GFT_OK;
+}
+
+int gft_profile_reset(gft_engine* e) {
+    if (!e) return GFT_E_INVALID;
+    if (e->device < 0) return GFT_OK;
+    DeviceGuard g(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (auto& kv : e->prof) {
+        for (auto& p : kv.second.ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+        kv.second.ev.clear();
+    }
+    return GFT_OK;
+}
+
+int gft_profile_read(gft_engine* e, const char* name, double* total_ms, uint64_t* launches) {
+    if (!e || !name || !total_ms || !launches) return GFT_E_INVALID;
+    *total_ms = 0; *launches = 0;
+    if (e->device < 0) return fail(e, GFT_E_HIP, "no HIP device available");
+    DeviceGuard g(e->device);
+    HIP_TRY(hipStreamSynchronize(e->stream), "sync");
+    auto it = e->prof.find(name);
+    if (it == e->prof.end()) return GFT_OK;
+    for (auto& p : it->second.ev) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, p.first, p.second), "event elapsed");
+        *total_ms += ms;
+    }
+    *launches = it->second.ev.size();
+    return GFT_OK;
+}
+
+}  // extern "C"

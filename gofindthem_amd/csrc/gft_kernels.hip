@@ -1,0 +1,508 @@
+// gft_kernels.hip -- HIP kernels (gfx950 / CDNA4, wave64) for the ProcessText hot path.
+//
+//   k_scan_units   Aho-Corasick traversal, one wavefront per work unit (a document, or a slice of a long one).
+//                  Replaces (*Matcher).MatchAll as called from CloudflareForkEngine.FindSubstrings
+//                  (finder/substringEngine.go:110-119).
+//   k_gather       unit slabs -> canonical CSR (document order, reference emission order inside a document).
+//   k_solve        per-document evaluation of every expression program.  Replaces addMatchesToSolverMap +
+//                  solveExpressions (finder/finder.go:181-215) and Expression.solve (dsl/expression.go:66-142).
+//   k_*scan*       exclusive prefix sums used to lay the CSR out.
+//
+// No MFMA anywhere: this is a byte automaton walk plus boolean/integer evaluation (HBM/LDS bound).
+#include <hip/hip_runtime.h>
+
+#include "gft_kernels.hpp"
+
+namespace gft {
+
+namespace {
+
+constexpr uint32_t kLane = 64;
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    const uint32_t l = lane_id();
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        uint32_t o = __shfl_up(v, s, 64);
+        if ((int)l >= s) v += o;
+    }
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// work units
+// ------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_unit_count(const uint64_t* __restrict__ doc_off, uint64_t n_docs,
+                                                    uint32_t unit_max, uint32_t* __restrict__ cnt) {
+    uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n_docs) return;
+    uint64_t n = doc_off[d + 1] - doc_off[d];
+    cnt[d] = n <= unit_max ? 1u : (uint32_t)((n + unit_max - 1) / unit_max);
+}
+
+__global__ void __launch_bounds__(256) k_unit_fill(const uint64_t* __restrict__ doc_off, uint64_t n_docs,
+                                                   const uint64_t* __restrict__ unit_base, Unit* __restrict__ units) {
+    uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n_docs) return;
+    uint64_t n = doc_off[d + 1] - doc_off[d];
+    uint64_t b = unit_base[d];
+    uint32_t k = (uint32_t)(unit_base[d + 1] - b);
+    uint64_t per = (n + k - 1) / k;
+    for (uint32_t i = 0; i < k; i++) {
+        uint64_t lo = (uint64_t)i * per, hi = lo + per < n ? lo + per : n;
+        if (lo > n) lo = n;
+        units[b + i] = Unit{(uint32_t)d, (uint32_t)lo, (uint32_t)hi};
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// exclusive scan u32 -> u64 (out has n+1 entries, out[n] = total).  Three small kernels, 4096 items / block.
+// ------------------------------------------------------------------------------------------------------
+constexpr uint32_t kScanItems = 16, kScanBlock = 256, kScanTile = kScanItems * kScanBlock;
+
+__device__ __forceinline__ uint64_t block_excl_scan_u64(uint64_t v, uint64_t* total) {
+    __shared__ uint64_t wsum[kScanBlock / 64];
+    const uint32_t l = lane_id(), w = threadIdx.x >> 6;
+    uint64_t incl = v;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        uint64_t o = __shfl_up(incl, s, 64);
+        if ((int)l >= s) incl += o;
+    }
+    if (l == 63) wsum[w] = incl;
+    __syncthreads();
+    uint64_t off = 0, tot = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < kScanBlock / 64; i++) {
+        if (i < w) off += wsum[i];
+        tot += wsum[i];
+    }
+    __syncthreads();
+    *total = tot;
+    return off + incl - v;
+}
+
+__global__ void __launch_bounds__(kScanBlock) k_scan_partials(const uint32_t* __restrict__ in, uint64_t n,
+                                                              uint64_t* __restrict__ partial) {
+    uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanItems;
+    uint64_t s = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < kScanItems; i++)
+        if (base + i < n) s += in[base + i];
+    uint64_t tot;
+    block_excl_scan_u64(s, &tot);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(kScanBlock) k_scan_spine(uint64_t* __restrict__ partial, uint64_t n_part) {
+    uint64_t carry = 0;
+    for (uint64_t b = 0; b < n_part; b += kScanBlock) {
+        uint64_t i = b + threadIdx.x;
+        uint64_t v = i < n_part ? partial[i] : 0, tot;
+        uint64_t ex = block_excl_scan_u64(v, &tot);
+        if (i < n_part) partial[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) partial[n_part] = carry;
+}
+
+__global__ void __launch_bounds__(kScanBlock) k_scan_final(const uint32_t* __restrict__ in, uint64_t n,
+                                                           const uint64_t* __restrict__ partial, uint64_t n_part,
+                                                           uint64_t* __restrict__ out) {
+    uint64_t base = (uint64_t)blockIdx.x * kScanTile + (uint64_t)threadIdx.x * kScanItems;
+    uint32_t v[kScanItems];
+    uint64_t s = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < kScanItems; i++) {
+        v[i] = base + i < n ? in[base + i] : 0;
+        s += v[i];
+    }
+    uint64_t tot;
+    uint64_t ex = block_excl_scan_u64(s, &tot) + partial[blockIdx.x];
+#pragma unroll
+    for (uint32_t i = 0; i < kScanItems; i++) {
+        if (base + i < n) out[base + i] = ex;
+        ex += v[i];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = partial[n_part];
+}
+
+// ------------------------------------------------------------------------------------------------------
+// k_scan_units (v1): two-tier class-compressed DFA, hot rows in LDS, the rest read through L2.
+// One wave per unit: the unit's bytes are staged into the wave's LDS buffer with coalesced loads, lane k walks
+// bytes [k*C, (k+1)*C) after a (max_term_len-1)-byte warm-up from the root and reports matches whose END lies in
+// its own range.  Two walks per unit (count, then write after a ballot-free wave prefix sum) keep the unit's
+// matches in text order; a single global cursor hands out the unit's slab.
+// ------------------------------------------------------------------------------------------------------
+template <bool WRITE>
+__device__ __forceinline__ uint32_t walk_chunk(const ScanParams& P, const uint8_t* __restrict__ buf,
+                                               const uint8_t* __restrict__ cls_lds,
+                                               const uint32_t* __restrict__ delta_lds, uint32_t seg_lo,
+                                               uint32_t walk_from, uint32_t my_lo, uint32_t my_hi, uint64_t out_idx) {
+    uint32_t state = 0, cnt = 0;
+    const uint32_t ncls = P.n_classes;
+    for (uint32_t p = walk_from; p < my_hi; p++) {
+        const uint32_t c = cls_lds[buf[p - seg_lo]];
+        const uint32_t e = state < P.n_lds_states ? delta_lds[state * ncls + c] : P.delta[(size_t)state * ncls + c];
+        state = e & 0x7FFFFFFFu;
+        if ((e >> 31) && p >= my_lo) {
+            uint32_t s = state;
+            do {
+                const uint32_t t = P.out_term[s];
+                if (t != 0xFFFFFFFFu) {
+                    if (WRITE) {
+                        P.pool_term[out_idx + cnt] = t;
+                        P.pool_pos[out_idx + cnt] = P.pos_end ? p : p + 1 - P.term_len[t];
+                    }
+                    cnt++;
+                }
+                s = P.out_link[s];
+            } while (s != 0);
+        }
+    }
+    return cnt;
+}
+
+__global__ void __launch_bounds__(kScanBlockThreads) k_scan_units(const ScanParams P) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    uint8_t* cls_lds = smem;
+    uint32_t* delta_lds = reinterpret_cast<uint32_t*>(smem + 256);
+    const uint32_t tier_words = P.n_lds_states * P.n_classes;
+    uint8_t* text_lds = smem + 256 + (((size_t)tier_words * 4 + 15) & ~(size_t)15);
+
+    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) cls_lds[i] = P.byte_class[i];
+    for (uint32_t i = threadIdx.x; i < tier_words; i += blockDim.x) delta_lds[i] = P.delta[i];
+    __syncthreads();
+
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    uint8_t* buf = text_lds + (size_t)wave * kTextBuf;
+    const uint32_t warm = P.max_term_len > 0 ? P.max_term_len - 1 : 0;
+
+    for (uint64_t u = (uint64_t)blockIdx.x * wpb + wave; u < P.n_units; u += (uint64_t)gridDim.x * wpb) {
+        const Unit un = P.units[u];
+        const uint64_t dstart = P.doc_off[un.doc];
+        const uint32_t seg_lo = un.lo > warm ? un.lo - warm : 0;
+        const uint32_t nbytes = un.hi - seg_lo;       // <= kTextBuf by construction (host checks)
+        const uint8_t* src = P.text + dstart + seg_lo;
+        for (uint32_t i = lane; i < nbytes; i += kLane) {
+            uint8_t b = src[i];
+            if (P.fold && b >= 'A' && b <= 'Z') b += 32;
+            buf[i] = b;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+        const uint32_t own = un.hi - un.lo;
+        uint32_t C = ((own + 63) / 64 + 3) & ~3u;      // bytes per lane, multiple of 4
+        if (((C >> 2) & 1u) == 0) C += 4;             // odd dword stride between lanes: conflict-free LDS reads
+        const uint32_t my_lo = un.lo + lane * C;
+        const uint32_t my_hi = my_lo + C < un.hi ? my_lo + C : un.hi;
+        const bool active = my_lo < un.hi;
+        const uint32_t walk_from = my_lo > seg_lo + warm ? my_lo - warm : seg_lo;
+
+        uint32_t cnt = 0;
+        if (active) cnt = walk_chunk<false>(P, buf, cls_lds, delta_lds, seg_lo, walk_from, my_lo, my_hi, 0);
+        const uint32_t incl = wave_incl_scan(cnt);
+        const uint32_t total = __shfl(incl, 63, 64);
+        uint64_t base = 0;
+        if (lane == 0) {
+            base = total ? atomicAdd(reinterpret_cast<unsigned long long*>(P.cursor), (unsigned long long)total) : 0;
+            P.unit_start[u] = base;
+            P.unit_count[u] = total;
+        }
+        base = __shfl(base, 0, 64);
+        if (active && cnt && base + total <= P.pool_cap)
+            walk_chunk<true>(P, buf, cls_lds, delta_lds, seg_lo, walk_from, my_lo, my_hi, base + incl - cnt);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// k_gather: one wave per unit copies its slab to the final CSR position.
+// ------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_gather(const uint64_t* __restrict__ unit_start,
+                                                const uint32_t* __restrict__ unit_count,
+                                                const uint64_t* __restrict__ unit_out, uint64_t n_units,
+                                                const uint32_t* __restrict__ pool_term,
+                                                const uint32_t* __restrict__ pool_pos, uint32_t* __restrict__ term_id,
+                                                uint32_t* __restrict__ pos) {
+    const uint32_t lane = lane_id(), wpb = blockDim.x >> 6;
+    for (uint64_t u = (uint64_t)blockIdx.x * wpb + (threadIdx.x >> 6); u < n_units; u += (uint64_t)gridDim.x * wpb) {
+        const uint64_t s = unit_start[u], d = unit_out[u];
+        const uint32_t n = unit_count[u];
+        for (uint32_t i = lane; i < n; i += kLane) {
+            term_id[d + i] = pool_term[s + i];
+            pos[d + i] = pool_pos[s + i];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_match_off(const uint64_t* __restrict__ unit_base,
+                                                   const uint64_t* __restrict__ unit_out, uint64_t n_docs,
+                                                   uint64_t* __restrict__ match_off) {
+    uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d <= n_docs) match_off[d] = unit_out[unit_base[d]];
+}
+
+// ------------------------------------------------------------------------------------------------------
+// k_solve (v1): one wave per document, one lane per expression (64 at a time).
+//
+// Per document the wave builds the slot-presence bitset in LDS (UNIT truth == key presence in the reference's
+// map, dsl/expression.go:68-72) and every lane interprets its postfix program.  Inside an INORD group a node's
+// position list is kept as a set of (slot, theta) pairs meaning { p in pos(slot) : p > theta }:
+//   UNIT t      -> {(t, -1)}
+//   OR          -> union (duplicates irrelevant: only minimum / emptiness are ever observed)
+//   AND(L, R)   -> m = min over L of succ(t, theta); empty if m = +inf, else {(t, max(theta, m)) : (t, theta) in R}
+//                  (== rpos[getLowestIdxGTVal(rpos, lpos[0]):], dsl/expression.go:87-93,175-189)
+//   INORD       -> rval && exists pair with succ < +inf   (dsl/expression.go:129-137)
+// succ(t, theta) = first position of slot t greater than theta in this document.
+// ------------------------------------------------------------------------------------------------------
+struct DocMatches {
+    const uint32_t* term;
+    const uint32_t* pos;
+    uint32_t n;
+    const uint32_t* xslot;   // extra (regex) matches, slot relative to n_terms
+    const uint32_t* xpos;
+    uint32_t nx;
+    uint32_t n_terms;
+};
+
+// first position of `slot` that is > theta (theta == -1 means "any"), or INT64_MAX
+__device__ __forceinline__ int64_t succ_query(const DocMatches& M, uint32_t slot, int64_t theta) {
+    int64_t best = INT64_MAX;
+    if (slot < M.n_terms) {
+        for (uint32_t i = 0; i < M.n; i++)
+            if (M.term[i] == slot) {
+                int64_t p = M.pos[i];
+                if (p > theta && p < best) best = p;
+            }
+    }
+    // a keyword and a regex with the same literal share one map key (finder.go:181-196): the caller maps
+    // both onto one slot, so both lists are consulted
+    for (uint32_t i = 0; i < M.nx; i++)
+        if (M.xslot[i] + M.n_terms == slot) {
+            int64_t p = M.xpos[i];
+            if (p > theta && p < best) best = p;
+        }
+    return best;
+}
+
+struct Pair { uint32_t slot; int32_t theta; };
+
+__device__ bool eval_program(const uint32_t* __restrict__ prog, uint32_t len, const uint32_t* __restrict__ present,
+                             const DocMatches& M) {
+    // bool stack as bits, pair-range stack only used inside INORD groups
+    uint64_t bits_lo = 0, bits_hi = 0;   // up to 128 deep
+    uint32_t sp = 0;
+    Pair pairs[kMaxPairs];
+    uint16_t rbeg[kMaxPairDepth], rcnt[kMaxPairDepth];
+    uint32_t psp = 0;  // pair-range stack pointer
+
+    auto push = [&](bool v) {
+        if (sp < 64) bits_lo = (bits_lo & ~(1ull << sp)) | ((uint64_t)v << sp);
+        else bits_hi = (bits_hi & ~(1ull << (sp - 64))) | ((uint64_t)v << (sp - 64));
+        sp++;
+    };
+    auto pop = [&]() -> bool {
+        sp--;
+        return sp < 64 ? (bits_lo >> sp) & 1 : (bits_hi >> (sp - 64)) & 1;
+    };
+
+    for (uint32_t pc = 0; pc < len; pc++) {
+        const uint32_t w = prog[pc];
+        const uint32_t op = w >> 28;
+        const bool in_inord = (w & GFT_K_INORD_FLAG) != 0;
+        switch (op) {
+        case 1: {  // UNIT
+            const uint32_t slot = w & GFT_K_SLOT_MASK;
+            push((present[slot >> 5] >> (slot & 31)) & 1);
+            if (in_inord) {
+                const uint32_t b = psp ? rbeg[psp - 1] + rcnt[psp - 1] : 0;
+                pairs[b] = Pair{slot, -1};
+                rbeg[psp] = (uint16_t)b; rcnt[psp] = 1; psp++;
+            }
+            break;
+        }
+        case 2: {  // AND
+            const bool r = pop(), l = pop();
+            push(l && r);
+            if (in_inord) {
+                const uint32_t lb = rbeg[psp - 2], lc = rcnt[psp - 2], rb = rbeg[psp - 1], rc = rcnt[psp - 1];
+                int64_t m = INT64_MAX;
+                for (uint32_t i = 0; i < lc; i++) {
+                    int64_t s = succ_query(M, pairs[lb + i].slot, pairs[lb + i].theta);
+                    if (s < m) m = s;
+                }
+                uint32_t nc = 0;
+                if (m != INT64_MAX)
+                    for (uint32_t i = 0; i < rc; i++) {
+                        Pair q = pairs[rb + i];
+                        if ((int64_t)q.theta < m) q.theta = (int32_t)m;
+                        pairs[lb + nc++] = q;
+                    }
+                psp--;
+                rcnt[psp - 1] = (uint16_t)nc;
+            }
+            break;
+        }
+        case 3: {  // OR
+            const bool r = pop(), l = pop();
+            push(l || r);
+            if (in_inord) {  // ranges are adjacent: union == concatenation
+                psp--;
+                rcnt[psp - 1] = (uint16_t)(rcnt[psp - 1] + rcnt[psp]);
+            }
+            break;
+        }
+        case 4:  // NOT
+            push(!pop());
+            break;
+        case 5: {  // INORD: rval && len(rpos) > 0
+            bool v = pop();
+            bool any = false;
+            const uint32_t b = rbeg[psp - 1], c = rcnt[psp - 1];
+            for (uint32_t i = 0; i < c && !any; i++)
+                any = succ_query(M, pairs[b + i].slot, pairs[b + i].theta) != INT64_MAX;
+            psp--;
+            push(v && any);
+            break;
+        }
+        default:
+            break;
+        }
+    }
+    return sp ? pop() : false;
+}
+
+__global__ void __launch_bounds__(kSolveBlockThreads) k_solve(const SolveParams P) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    uint32_t* present = reinterpret_cast<uint32_t*>(smem) + (size_t)wave * P.present_words;
+    const uint32_t bm_words = (P.n_exprs + 31) / 32;
+
+    for (uint64_t d = (uint64_t)blockIdx.x * wpb + wave; d < P.n_docs; d += (uint64_t)gridDim.x * wpb) {
+        for (uint32_t i = lane; i < P.present_words; i += kLane) present[i] = 0;
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        DocMatches M;
+        const uint64_t mo = P.match_off[d];
+        M.term = P.term_id + mo; M.pos = P.pos + mo; M.n = (uint32_t)(P.match_off[d + 1] - mo);
+        M.n_terms = P.n_terms;
+        M.nx = 0; M.xslot = nullptr; M.xpos = nullptr;
+        if (P.x_off) {
+            const uint64_t xo = P.x_off[d];
+            M.xslot = P.x_slot + xo; M.xpos = P.x_pos + xo; M.nx = (uint32_t)(P.x_off[d + 1] - xo);
+        }
+        for (uint32_t i = lane; i < M.n; i += kLane) {
+            const uint32_t t = M.term[i];
+            atomicOr(&present[t >> 5], 1u << (t & 31));
+        }
+        for (uint32_t i = lane; i < M.nx; i += kLane) {
+            const uint32_t t = M.xslot[i] + P.n_terms;
+            atomicOr(&present[t >> 5], 1u << (t & 31));
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+        uint32_t* row = P.bitmap + d * bm_words;
+        for (uint32_t e0 = 0; e0 < P.n_exprs; e0 += kLane) {
+            const uint32_t e = e0 + lane;
+            bool v = false;
+            if (e < P.n_exprs) {
+                const uint64_t po = P.prog_off[e];
+                v = eval_program(P.prog + po, (uint32_t)(P.prog_off[e + 1] - po), present, M);
+            }
+            const uint64_t b = __ballot(v);
+            if (lane == 0) {
+                row[e0 >> 5] = (uint32_t)b;
+                if ((e0 >> 5) + 1 < bm_words) row[(e0 >> 5) + 1] = (uint32_t)(b >> 32);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+inline unsigned grid_for(uint64_t n, unsigned per_block, unsigned cap) {
+    uint64_t g = (n + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    return (unsigned)(g > cap ? cap : g);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------------
+hipError_t launch_unit_count(const uint64_t* d_doc_off, uint64_t n_docs, uint32_t unit_max, uint32_t* d_cnt,
+                             hipStream_t st) {
+    if (!n_docs) return hipSuccess;
+    k_unit_count<<<dim3((unsigned)((n_docs + 255) / 256)), dim3(256), 0, st>>>(d_doc_off, n_docs, unit_max, d_cnt);
+    return hipGetLastError();
+}
+
+hipError_t launch_unit_fill(const uint64_t* d_doc_off, uint64_t n_docs, const uint64_t* d_unit_base, Unit* d_units,
+                            hipStream_t st) {
+    if (!n_docs) return hipSuccess;
+    k_unit_fill<<<dim3((unsigned)((n_docs + 255) / 256)), dim3(256), 0, st>>>(d_doc_off, n_docs, d_unit_base, d_units);
+    return hipGetLastError();
+}
+
+uint64_t scan_partials_needed(uint64_t n) { return (n + kScanTile - 1) / kScanTile + 1; }
+
+hipError_t launch_exclusive_scan(const uint32_t* d_in, uint64_t n, uint64_t* d_out, uint64_t* d_partial,
+                                 hipStream_t st) {
+    const uint64_t n_part = (n + kScanTile - 1) / kScanTile;
+    if (n_part == 0) {
+        return hipMemsetAsync(d_out, 0, sizeof(uint64_t), st);
+    }
+    k_scan_partials<<<dim3((unsigned)n_part), dim3(kScanBlock), 0, st>>>(d_in, n, d_partial);
+    k_scan_spine<<<dim3(1), dim3(kScanBlock), 0, st>>>(d_partial, n_part);
+    k_scan_final<<<dim3((unsigned)n_part), dim3(kScanBlock), 0, st>>>(d_in, n, d_partial, n_part, d_out);
+    return hipGetLastError();
+}
+
+size_t scan_units_lds_bytes(uint32_t n_lds_states, uint32_t n_classes) {
+    return 256 + (((size_t)n_lds_states * n_classes * 4 + 15) & ~(size_t)15) +
+           (size_t)(kScanBlockThreads / 64) * kTextBuf;
+}
+
+hipError_t launch_scan_units(const ScanParams& P, unsigned n_cus, hipStream_t st) {
+    if (!P.n_units) return hipSuccess;
+    const size_t lds = scan_units_lds_bytes(P.n_lds_states, P.n_classes);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_units),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const unsigned wpb = kScanBlockThreads / 64;
+    const unsigned grid = grid_for(P.n_units, wpb, n_cus * 2);
+    k_scan_units<<<dim3(grid), dim3(kScanBlockThreads), lds, st>>>(P);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather(const uint64_t* d_unit_start, const uint32_t* d_unit_count, const uint64_t* d_unit_out,
+                         uint64_t n_units, const uint32_t* d_pool_term, const uint32_t* d_pool_pos, uint32_t* d_term,
+                         uint32_t* d_pos, const uint64_t* d_unit_base, uint64_t n_docs, uint64_t* d_match_off,
+                         unsigned n_cus, hipStream_t st) {
+    k_match_off<<<dim3((unsigned)((n_docs + 1 + 255) / 256)), dim3(256), 0, st>>>(d_unit_base, d_unit_out, n_docs,
+                                                                                  d_match_off);
+    if (n_units)
+        k_gather<<<dim3(grid_for(n_units, 4, n_cus * 16)), dim3(256), 0, st>>>(
+            d_unit_start, d_unit_count, d_unit_out, n_units, d_pool_term, d_pool_pos, d_term, d_pos);
+    return hipGetLastError();
+}
+
+size_t solve_lds_bytes(uint32_t present_words) { return (size_t)(kSolveBlockThreads / 64) * present_words * 4; }
+
+hipError_t launch_solve(const SolveParams& P, unsigned n_cus, hipStream_t st) {
+    if (!P.n_docs || !P.n_exprs) return hipSuccess;
+    const size_t lds = solve_lds_bytes(P.present_words);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const unsigned wpb = kSolveBlockThreads / 64;
+    k_solve<<<dim3(grid_for(P.n_docs, wpb, n_cus * 8)), dim3(kSolveBlockThreads), lds, st>>>(P);
+    return hipGetLastError();
+}
+
+}  // namespace gft

@@ -1,0 +1,74 @@
+// Kernel parameter blocks + launcher prototypes shared by gft_kernels.hip and gft_api.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gft {
+
+constexpr uint32_t kScanBlockThreads = 512;      // 8 waves: one work unit per wave
+constexpr uint32_t kTextBuf = 8448;              // per-wave LDS text buffer (bytes)
+constexpr uint32_t kSolveBlockThreads = 256;
+constexpr uint32_t kMaxPairs = 64;               // (slot, theta) pairs alive inside one INORD group
+constexpr uint32_t kMaxPairDepth = 32;           // operand-stack depth inside one INORD group
+constexpr uint32_t kMaxBoolDepth = 128;          // operand-stack depth of a whole program
+
+#define GFT_K_INORD_FLAG (1u << 27)
+#define GFT_K_SLOT_MASK ((1u << 27) - 1u)
+
+// a work unit: matches whose END offset lies in [lo, hi) of document `doc`
+struct Unit { uint32_t doc, lo, hi; };
+
+struct ScanParams {
+    const uint8_t* text;
+    const uint64_t* doc_off;
+    const Unit* units;
+    uint64_t n_units;
+    // automaton
+    const uint8_t* byte_class;   // [256]
+    const uint32_t* delta;       // [n_states * n_classes]
+    const uint32_t* out_term;
+    const uint32_t* out_link;
+    const uint32_t* term_len;
+    uint32_t n_classes, n_states, n_lds_states, max_term_len;
+    uint32_t pos_end, fold;
+    // output
+    uint64_t* cursor;            // pool allocation cursor (entries)
+    uint64_t pool_cap;
+    uint32_t* pool_term;
+    uint32_t* pool_pos;
+    uint64_t* unit_start;
+    uint32_t* unit_count;
+};
+
+struct SolveParams {
+    const uint64_t* match_off;
+    const uint32_t* term_id;
+    const uint32_t* pos;
+    const uint64_t* x_off;       // extra (regex) matches, nullable
+    const uint32_t* x_slot;
+    const uint32_t* x_pos;
+    uint64_t n_docs;
+    const uint32_t* prog;
+    const uint64_t* prog_off;
+    uint32_t n_exprs, n_terms, present_words;
+    uint32_t* bitmap;
+};
+
+hipError_t launch_unit_count(const uint64_t* d_doc_off, uint64_t n_docs, uint32_t unit_max, uint32_t* d_cnt,
+                             hipStream_t st);
+hipError_t launch_unit_fill(const uint64_t* d_doc_off, uint64_t n_docs, const uint64_t* d_unit_base, Unit* d_units,
+                            hipStream_t st);
+uint64_t scan_partials_needed(uint64_t n);
+// d_out has n+1 entries; d_partial has scan_partials_needed(n) entries
+hipError_t launch_exclusive_scan(const uint32_t* d_in, uint64_t n, uint64_t* d_out, uint64_t* d_partial,
+                                 hipStream_t st);
+size_t scan_units_lds_bytes(uint32_t n_lds_states, uint32_t n_classes);
+hipError_t launch_scan_units(const ScanParams& P, unsigned n_cus, hipStream_t st);
+hipError_t launch_gather(const uint64_t* d_unit_start, const uint32_t* d_unit_count, const uint64_t* d_unit_out,
+                         uint64_t n_units, const uint32_t* d_pool_term, const uint32_t* d_pool_pos, uint32_t* d_term,
+                         uint32_t* d_pos, const uint64_t* d_unit_base, uint64_t n_docs, uint64_t* d_match_off,
+                         unsigned n_cus, hipStream_t st);
+size_t solve_lds_bytes(uint32_t present_words);
+hipError_t launch_solve(const SolveParams& P, unsigned n_cus, hipStream_t st);
+
+}  // namespace gft

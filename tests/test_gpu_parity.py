@@ -1,0 +1,150 @@
+"""GPU parity: the HIP path (through the C ABI of libgft.so) against the CPU oracle, bit-exact."""
+import numpy as np
+import pytest
+
+from helpers import assert_csr_equal, docs, tree_to_program
+from oracle import dsl_ref
+from oracle.pyoracle import Oracle, POS_END, POS_START
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from gofindthem_amd.engine import Engine
+    e = Engine()
+    yield e
+    e.close()
+
+
+def both(eng, terms, pos_mode=POS_START):
+    eng.build(terms, pos_end=(pos_mode == POS_END))
+    o = Oracle(terms, pos_mode)
+    assert eng.terms() == o.terms()
+    assert eng.n_states == o.n_states
+    return o
+
+
+def test_ushers(eng):
+    o = both(eng, ["he", "she", "his", "hers"])
+    blob, off = docs(["ushers", "", "she", "xxhishers"])
+    got = eng.scan(blob, off)
+    assert_csr_equal(got, o.scan(blob, off))
+    assert list(zip(got[1][:3].tolist(), got[2][:3].tolist())) == [(3, 1), (0, 2), (1, 2)]
+    o = both(eng, ["he", "she", "his", "hers"], POS_END)
+    assert_csr_equal(eng.scan(blob, off), o.scan(blob, off))
+
+
+def test_empty_inputs(eng):
+    o = both(eng, ["a"])
+    blob, off = docs([])
+    mo, ti, po = eng.scan(blob, off)
+    assert mo.tolist() == [0] and ti.size == 0
+    blob, off = docs(["", "", ""])
+    assert_csr_equal(eng.scan(blob, off), o.scan(blob, off))
+    both(eng, [])                       # empty dictionary: nothing matches
+    blob, off = docs(["abc", "a"])
+    mo, ti, po = eng.scan(blob, off)
+    assert mo.tolist() == [0, 0, 0]
+    o = both(eng, ["", "b"])            # the empty keyword never matches
+    assert_csr_equal(eng.scan(blob, off), o.scan(blob, off))
+
+
+@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("pos_mode", [POS_START, POS_END])
+def test_random_dictionaries(eng, seed, pos_mode):
+    rng = np.random.default_rng(seed)
+    alpha = [b"ab", b"abc", b"abcdefgh", bytes(range(256)), b"abcdefghijklmnopqrstuvwxyz "][seed % 5]
+    n_terms = [1, 5, 40, 300, 1000, 17, 3000, 64][seed]
+    maxlen = [3, 9, 9, 6, 5, 40, 12, 200][seed]
+    terms = set()
+    for _ in range(n_terms):
+        L = int(rng.integers(1, maxlen + 1))
+        terms.add(bytes(alpha[i] for i in rng.integers(0, len(alpha), L)))
+    o = both(eng, sorted(terms), pos_mode)
+    lens = [0, 1, 2, 7, 63, 64, 65, 300, 2000, 4095, 4096, 4097, 8191, 8449, 20000, 70000]
+    texts = [bytes(alpha[i] for i in rng.integers(0, len(alpha), n)) for n in lens]
+    # plant whole terms so long keywords occur too
+    tl = sorted(terms)
+    planted = b" ".join(tl[i] for i in rng.integers(0, len(tl), 400))
+    texts.append(planted)
+    blob, off = docs(texts)
+    assert_csr_equal(eng.scan(blob, off), o.scan(blob, off))
+
+
+def test_ascii_fold(eng):
+    o = both(eng, ["lorem", "ipsum dolor", "x"])
+    blob, off = docs(["LoReM IPSUM DOLOR sit amet X", "\xc3\x89LOREM\xff"])
+    assert_csr_equal(eng.scan(blob, off, fold=True), o.scan(blob, off, fold=True))
+    assert eng.scan(blob, off, fold=False)[1].size == 0
+
+
+@pytest.mark.parametrize("n_terms,n_docs", [(50, 300), (1000, 2000), (10000, 1500)])
+def test_workload_positions(eng, n_terms, n_docs):
+    """BASELINE config 2 shape (1 k terms, ~4 KB docs, positions only) at oracle-friendly size."""
+    from gofindthem_amd.workload import Workload
+    w = Workload(n_terms)
+    o = both(eng, w.terms())
+    text, off = w.docs_host(0, n_docs)
+    got = eng.scan(text, off)
+    assert_csr_equal(got, o.scan(text, off))
+    assert got[1].size > n_docs          # planted terms guarantee hits
+
+
+def _programs(o, eng, exprs, cs, regexes=()):
+    trees = [dsl_ref.parse(e, cs)[0] for e in exprs]
+    extra = {}
+
+    def slot_of(lit):
+        t = eng.term_id(lit)
+        if t >= 0:
+            return t
+        return eng.n_terms + extra.setdefault(lit, len(extra))
+    progs = [tree_to_program(t, slot_of) for t in trees]
+    return progs, extra
+
+
+@pytest.mark.parametrize("inord", [0.0, 0.5])
+def test_workload_process(eng, inord):
+    """BASELINE configs 3/4 shape: expressions over the synthetic corpus, hit bitmap bit-exact."""
+    from gofindthem_amd.workload import Workload, make_expressions
+    w = Workload(1000)
+    terms = w.terms()
+    exprs = make_expressions(terms, 200, inord_fraction=inord)
+    o = both(eng, terms)
+    o.set_expressions(exprs, case_sensitive=False)
+    progs, extra = _programs(o, eng, exprs, False)
+    assert not extra
+    eng.set_programs(progs)
+    text, off = w.docs_host(0, 400)
+    got = eng.process(text, off, fold=True)
+    want = o.process(text, off, fold=True)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want)
+    bits = int(np.unpackbits(want.view(np.uint8)).sum())
+    assert 0 < bits < 400 * 200
+
+
+def test_solver_fixtures_on_gpu(eng):
+    """dsl/expression_test.go INORD tables: texts synthesised so that the engine yields the listed positions."""
+    cases = [
+        ('inord("a" and "b" and "c")', "acabXaXcb", True),
+        ('inord("a" and ("b" or "c"))', "cbac", True),
+        ('inord("a" and "b" and "c")', "bacb", False),
+        ('inord("a" and "b" and "c")', "bcab", False),
+        ('inord(("b" or "c") and ("a" or "b"))', "bcab", True),
+        ('inord("b" and "c") and inord("a" and "b")', "bcab", True),
+        ('not "a" or "q"', "", True),
+        ('"a" and not ("b" or "c")', "a", True),
+    ]
+    o = both(eng, ["a", "b", "c", "q"])
+    exprs = [c[0] for c in cases]
+    o.set_expressions(exprs, True)
+    progs, _ = _programs(o, eng, exprs, True)
+    eng.set_programs(progs)
+    blob, off = docs([c[1] for c in cases])
+    got = eng.process(blob, off)
+    want = o.process(blob, off)
+    assert np.array_equal(got, want)
+    for d, c in enumerate(cases):
+        assert bool(got[d, 0] >> d & 1) is c[2], c

@@ -40,10 +40,36 @@ SYMBOLS = {
     "gft_n_exprs": (_u32, [_vp]),
     "gft_process": (_i, [_vp, _vp, _vp, _u64, _u32, C.POINTER(GftExtra), _vp]),
     "gft_process_device": (_i, [_vp, _vp, _vp, _u64, _u32, C.POINTER(GftExtra), _vp]),
+    "gft_finder_create": (_i, [C.POINTER(_vp), _i, _i]),
+    "gft_finder_destroy": (None, [_vp]),
+    "gft_finder_last_error": (C.c_char_p, [_vp]),
+    "gft_finder_engine": (_vp, [_vp]),
+    "gft_finder_set_substring_engine": (_i, [_vp, _vp, _vp, _vp]),
+    "gft_finder_set_regex_engine": (_i, [_vp, _vp, _vp, _vp]),
+    "gft_finder_add_expression": (_i, [_vp, C.c_char_p, _u64, C.c_char_p, _u64]),
+    "gft_finder_n_expressions": (_u32, [_vp]),
+    "gft_finder_n_literals": (_u32, [_vp, _i]),
+    "gft_finder_literal": (_i, [_vp, _i, _u32, C.POINTER(_vp), C.POINTER(_u32)]),
+    "gft_finder_expression": (_i, [_vp, _u32, C.POINTER(_vp), C.POINTER(_u32), C.POINTER(_vp), C.POINTER(_u32),
+                                   C.POINTER(_vp), C.POINTER(_u32)]),
+    "gft_finder_force_build": (_i, [_vp]),
+    "gft_finder_process_text": (_i, [_vp, C.c_char_p, _u64, _vp, _u32, C.POINTER(_u32)]),
+    "gft_finder_process_texts": (_i, [_vp, _vp, _vp, _u64, _vp]),
+    "gft_finder_process_device": (_i, [_vp, _vp, _vp, _u64, _vp]),
+    "gft_finder_debug_add_literal": (_i, [_vp, _i, C.c_char_p, _u32]),
+    "gft_finder_debug_set_updated": (_i, [_vp, _i, _i]),
+    "gft_finder_debug_get_updated": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    "gft_dsl_parse": (_i, [C.c_char_p, _u64, _i, _vp, _u64, C.POINTER(_u64)]),
+    "gft_dsl_tokens": (_i, [C.c_char_p, _u64, _vp, _u64, C.POINTER(_u64)]),
+    "gft_to_lower": (_i, [C.c_char_p, _u64, _vp, _u64, C.POINTER(_u64)]),
     "gft_profile_enable": (_i, [_vp, _i]),
     "gft_profile_read": (_i, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_u64)]),
     "gft_profile_reset": (_i, [_vp]),
 }
+
+EMIT_FN = C.CFUNCTYPE(None, _vp, _vp, _u32, C.c_int64)
+BUILD_FN = C.CFUNCTYPE(_i, _vp, _vp, _vp, _u32, _i, _vp, _u32)
+FIND_FN = C.CFUNCTYPE(_i, _vp, _vp, _u64, EMIT_FN, _vp, _vp, _u32)
 
 _LIB = None
 

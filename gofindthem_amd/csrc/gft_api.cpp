@@ -524,7 +524,7 @@ int gft_process(gft_engine* e, const uint8_t* text_blob, const uint64_t* doc_off
         HIP_TRY(hipMemcpyAsync(e->d_xoff.p, extra->off, (n_docs + 1) * 8, hipMemcpyHostToDevice, e->stream), "extra upload");
         if (nx) {
             for (uint64_t i = 0; i < nx; i++)
-                if (extra->slot[i] >= e->n_extra) return fail(e, GFT_E_INVALID, "extra slot out of range");
+                if (extra->slot[i] >= e->tab.terms.size() + e->n_extra) return fail(e, GFT_E_INVALID, "extra slot out of range");
             HIP_TRY(hipMemcpyAsync(e->d_xslot.p, extra->slot, nx * 4, hipMemcpyHostToDevice, e->stream), "extra upload");
             HIP_TRY(hipMemcpyAsync(e->d_xpos.p, extra->pos, nx * 4, hipMemcpyHostToDevice, e->stream), "extra upload");
         }

@@ -263,7 +263,7 @@ struct DocMatches {
     const uint32_t* term;
     const uint32_t* pos;
     uint32_t n;
-    const uint32_t* xslot;   // extra (regex) matches, slot relative to n_terms
+    const uint32_t* xslot;   // caller-supplied matches, absolute slots
     const uint32_t* xpos;
     uint32_t nx;
     uint32_t n_terms;
@@ -272,17 +272,15 @@ struct DocMatches {
 // first position of `slot` that is > theta (theta == -1 means "any"), or INT64_MAX
 __device__ __forceinline__ int64_t succ_query(const DocMatches& M, uint32_t slot, int64_t theta) {
     int64_t best = INT64_MAX;
-    if (slot < M.n_terms) {
-        for (uint32_t i = 0; i < M.n; i++)
-            if (M.term[i] == slot) {
-                int64_t p = M.pos[i];
-                if (p > theta && p < best) best = p;
-            }
-    }
+    for (uint32_t i = 0; i < M.n; i++)
+        if (M.term[i] == slot) {
+            int64_t p = M.pos[i];
+            if (p > theta && p < best) best = p;
+        }
     // a keyword and a regex with the same literal share one map key (finder.go:181-196): the caller maps
     // both onto one slot, so both lists are consulted
     for (uint32_t i = 0; i < M.nx; i++)
-        if (M.xslot[i] + M.n_terms == slot) {
+        if (M.xslot[i] == slot) {
             int64_t p = M.xpos[i];
             if (p > theta && p < best) best = p;
         }
@@ -400,7 +398,7 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve(const SolveParams 
             atomicOr(&present[t >> 5], 1u << (t & 31));
         }
         for (uint32_t i = lane; i < M.nx; i += kLane) {
-            const uint32_t t = M.xslot[i] + P.n_terms;
+            const uint32_t t = M.xslot[i];
             atomicOr(&present[t >> 5], 1u << (t & 31));
         }
         __builtin_amdgcn_wave_barrier();

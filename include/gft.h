@@ -104,7 +104,10 @@ int gft_set_programs(gft_engine* e, const uint32_t* prog_words, const uint64_t* 
                      uint32_t n_extra);
 uint32_t gft_n_exprs(const gft_engine* e);
 
-/* matches of the extra slots (regex engine output), CSR per document; slot is relative to n_terms */
+/* Caller-supplied matches (regex engine output, or the output of a foreign SubstringEngine), CSR per document.
+ * `slot` is ABSOLUTE: n_terms + j for extra literal j, or a dictionary term id when a regex literal has the same
+ * text as a keyword (both feed one map key in the reference, finder/finder.go:181-196).  Positions of one slot
+ * must be ascending within a document (README.md:155). */
 typedef struct gft_extra_matches {
     const uint64_t* off; /* n_docs + 1 */
     const uint32_t* slot;
@@ -118,6 +121,68 @@ int gft_process(gft_engine* e, const uint8_t* text_blob, const uint64_t* doc_off
 /* Device-resident variant (all pointers are device pointers, bitmap written in HBM). */
 int gft_process_device(gft_engine* e, const uint8_t* d_text_blob, const uint64_t* d_doc_off, uint64_t n_docs,
                        uint32_t flags, const gft_extra_matches* d_extra, uint32_t* d_hit_bitmap);
+
+/* ---- finder.Finder mirror (finder/finder.go:32-240) ---------------------------------------------------------
+ * Host-side orchestration with the reference's semantics: expression registry, keyword / regex sets, lazy engine
+ * build with the same dirty flags (incl. the ForceBuild quirk, finder.go:218-235), error propagation, results in
+ * registration order.  The DSL parser inside is dsl/parser.go + dsl/scanner.go restated (same trees, same error
+ * strings).  All solving happens on the GPU (gft_process); text case folding follows strings.ToLower.
+ * The substring engine defaults to the built-in GPU engine; foreign engines (any SubstringEngine / RegexEngine
+ * implementation, e.g. Go's regexp behind RegexpEngine, or test mocks) are injected as callbacks. */
+typedef struct gft_finder gft_finder;
+
+/* emit one Match{Position, Term} (finder/finder.go:11-14) */
+typedef void (*gft_emit_fn)(void* sink, const uint8_t* term, uint32_t term_len, int64_t position);
+/* BuildEngine(keywords|regexes, caseSensitive): return 0, or non-zero with a NUL-terminated message in err */
+typedef int (*gft_engine_build_fn)(void* user, const uint8_t* blob, const uint64_t* off, uint32_t n,
+                                   int case_sensitive, char* err, uint32_t err_cap);
+/* FindSubstrings / FindRegexes(text): call emit(sink, ...) per match; return 0, or non-zero with message */
+typedef int (*gft_engine_find_fn)(void* user, const uint8_t* text, uint64_t text_len, gft_emit_fn emit, void* sink,
+                                  char* err, uint32_t err_cap);
+
+int gft_finder_create(gft_finder** out, int case_sensitive, int device); /* NewFinder(GpuEngine, EmptyRgxEngine, cs) */
+void gft_finder_destroy(gft_finder* f);
+const char* gft_finder_last_error(const gft_finder* f);
+gft_engine* gft_finder_engine(gft_finder* f); /* the GPU engine handle used for scanning/solving */
+int gft_finder_set_substring_engine(gft_finder* f, gft_engine_build_fn build, gft_engine_find_fn find, void* user);
+int gft_finder_set_regex_engine(gft_finder* f, gft_engine_build_fn build, gft_engine_find_fn find, void* user);
+/* AddExpressionWithTag (finder.go:115-134).  GFT_E_PARSE + the reference's error text on malformed input. */
+int gft_finder_add_expression(gft_finder* f, const uint8_t* expr, uint64_t expr_len, const uint8_t* tag,
+                              uint64_t tag_len);
+uint32_t gft_finder_n_expressions(const gft_finder* f);
+/* which: 0 = keywords, 1 = regexes.  Returns the set size; item i via gft_finder_literal. */
+uint32_t gft_finder_n_literals(const gft_finder* f, int which);
+int gft_finder_literal(const gft_finder* f, int which, uint32_t i, const uint8_t** ptr, uint32_t* len);
+/* expression i: its source string, tag and parsed tree as JSON ({"Type":..,"LExpr":..}); pointers valid until
+ * the next call on f */
+int gft_finder_expression(const gft_finder* f, uint32_t i, const uint8_t** str, uint32_t* str_len,
+                          const uint8_t** tag, uint32_t* tag_len, const uint8_t** tree_json, uint32_t* json_len);
+int gft_finder_force_build(gft_finder* f);                       /* ForceBuild (finder.go:218-235) */
+/* ProcessText (finder.go:139-179): indices of the expressions that are true, in registration order. */
+int gft_finder_process_text(gft_finder* f, const uint8_t* text, uint64_t text_len, uint32_t* out_idx, uint32_t cap,
+                            uint32_t* n_true);
+/* Batch extension: one bitmap row per document (layout as gft_process). */
+int gft_finder_process_texts(gft_finder* f, const uint8_t* text_blob, const uint64_t* doc_off, uint64_t n_docs,
+                             uint32_t* hit_bitmap);
+/* Same with the corpus resident in HBM (GPU substring engine, no regex terms). */
+int gft_finder_process_device(gft_finder* f, const uint8_t* d_text_blob, const uint64_t* d_doc_off, uint64_t n_docs,
+                              uint32_t* d_hit_bitmap);
+/* test hooks mirroring what finder_test.go does by poking struct fields (finder/finder_test.go:205-217) */
+int gft_finder_debug_add_literal(gft_finder* f, int which, const uint8_t* lit, uint32_t len);
+int gft_finder_debug_set_updated(gft_finder* f, int updated_sub, int updated_rgx);
+int gft_finder_debug_get_updated(const gft_finder* f, int* updated_sub, int* updated_rgx);
+
+/* ---- DSL front-end alone (host only, no device needed) ------------------------------------------------------
+ * Each writes a NUL-terminated JSON document into out (cap bytes) and the size it needs into *needed; returns
+ * GFT_OK, or GFT_E_INVALID when cap is too small (call again with *needed bytes).
+ *   gft_dsl_parse : {"tree":{...},"keywords":[..],"regexes":[..],"program":[..]} or {"error":"<reference text>"};
+ *                   "program" uses slots = index into keywords ++ regexes (first-seen order).
+ *   gft_dsl_tokens: [{"Tok":"AND","Lit":"and","Err":null}, ...] up to and including EOF or the first error
+ *                   (dsl/scanner.go:79-106).
+ *   gft_to_lower  : strings.ToLower of the input (raw bytes out, not JSON). */
+int gft_dsl_parse(const uint8_t* expr, uint64_t len, int case_sensitive, char* out, uint64_t cap, uint64_t* needed);
+int gft_dsl_tokens(const uint8_t* expr, uint64_t len, char* out, uint64_t cap, uint64_t* needed);
+int gft_to_lower(const uint8_t* in, uint64_t len, uint8_t* out, uint64_t cap, uint64_t* needed);
 
 /* ---- measurement hooks (bench.py) ---------------------------------------------------------------------- */
 /* When enabled, every kernel launch is bracketed by HIP events on the engine's stream. */

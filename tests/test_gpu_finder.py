@@ -1,0 +1,189 @@
+"""finder.Finder mirror on the GPU, written after the reference's own tests (finder/finder_test.go,
+group/finder/finder_test.go) and the examples/finder program; every solve runs in the HIP solver kernel."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from gofindthem_amd import _lib
+from gofindthem_amd.finder import (EmptyEngine, EmptyRgxEngine, Finder, FinderError, GpuEngine, Match, PyRegexpEngine)
+from oracle.pyoracle import Oracle, pack_strings
+from test_host_logic import make_mocked_finder
+
+pytestmark = pytest.mark.gpu
+
+
+# ---- finder/finder_test.go: TestProcessText (mocked engines) ---------------------------------------------------
+@pytest.mark.parametrize("case", load_golden("process_text.json")["cases"], ids=lambda c: c["message"])
+def test_process_text(case):
+    f, sub, rgx = make_mocked_finder(case, allow_no_device=False)
+    text = load_golden("process_text.json")["text"]
+    if case["expectedErr"]:
+        with pytest.raises(FinderError) as ei:
+            f.ProcessText(text)
+        assert str(ei.value) == case["expectedErr"]
+        return
+    res = f.ProcessText(text)
+    assert [r.to_obj() for r in res] == case["expected"]
+    # lazy build exactly when the dirty flag says so (finder.go:147-153,163-169)
+    assert ("BuildEngine", case["keywords"]) in sub.calls or case["updatedSub"]
+    assert sum(1 for c in sub.calls if c[0] == "BuildEngine") == (0 if case["updatedSub"] else 1)
+    assert sum(1 for c in rgx.calls if c[0] == "BuildEngine") == (0 if case["updatedRgx"] else 1)
+    assert ("FindSubstrings", text) in sub.calls and ("FindRegexes", text) in rgx.calls
+
+
+# ---- finder/finder_test.go: TestAddMatchesToSolverMap + TestSolveExpressions, through ProcessText ----------------
+class Fixed:
+    def __init__(self, matches):
+        self.matches = matches
+
+    def BuildEngine(self, kws, cs):
+        return None
+
+    def FindSubstrings(self, text):
+        return self.matches
+
+    def FindRegexes(self, text):      # as a RegexEngine: report only the terms the finder registered as regexes
+        return [m for m in self.matches if m.Term in self.regexes]
+
+
+@pytest.mark.parametrize("case", load_golden("add_matches.json")["cases"], ids=lambda c: c["message"])
+def test_add_matches_case_folding(case):
+    """Term is lower-cased into the map key when case-insensitive (finder.go:186-188): "Showman" then feeds
+    the same key as "showman"."""
+    ms = [Match(m["Position"], m["Term"]) for m in case["matches"]]
+    f = Finder(Fixed(ms), EmptyRgxEngine(), case["caseSensitive"])
+    keys = sorted(case["expected"])
+    for k in keys:
+        f.AddExpression('"%s"' % k)
+    f.AddExpression('"Showman"')
+    f.AddExpression('inord("sharpest" and "words" and "showman")')
+    got = [r.ExpresionIndex for r in f.ProcessText("irrelevant")]
+    want = list(range(len(keys)))                 # every key of the expected map is present
+    if case["caseSensitive"]:
+        want.append(len(keys))                    # "Showman" stays its own key
+    else:
+        want.append(len(keys))                    # '"Showman"' was lower-cased by the parser -> key "showman"
+    want.append(len(keys) + 1)                    # positions 1 < 7 < 9|10 are in order
+    assert got == want
+
+
+def test_solve_expressions():
+    g = load_golden("solve_expressions.json")
+    for c in g["cases"]:
+        ms = [Match(0, k) for k in c["map"]]
+        f = Finder(Fixed(ms), EmptyRgxEngine(), True)
+        for e in g["expressions"]:
+            f.AddExpressionWithTag(e["exprString"], e["tag"])
+        assert [r.to_obj() for r in f.ProcessText("x")] == c["expected"], c["message"]
+
+
+# ---- dsl/expression_test.go: all 31 Solve cases, map supplied through a fixed engine ----------------------------
+@pytest.mark.parametrize("case", load_golden("solver.json")["cases"], ids=lambda c: c["message"])
+def test_solver_table(case):
+    """Keys with nil/empty position lists (expression_test.go:29-33) cannot come out of an engine -- an engine
+    reports a key by reporting a match -- so each listed key gets its listed positions, or one position when the
+    table says nil (truth of non-INORD expressions depends on key presence only, expression.go:68-72)."""
+    ms = []
+    for k, v in case["map"].items():
+        for p in (v or [0]):
+            ms.append(Match(p, k))
+    ms.sort(key=lambda m: m.Position)
+    sub, rgx = Fixed(ms), Fixed(ms)
+    f = Finder(sub, rgx, True)
+    f.AddExpression(case["expStr"])
+    rgx.regexes = f.GetRegexes()
+    sub.matches = [m for m in ms if m.Term not in rgx.regexes]
+    res = f.ProcessText("x")
+    assert bool(res) is case["expected"]
+
+
+# ---- group/finder/finder_test.go: the real-engine cases -------------------------------------------------------
+def test_engine_truth():
+    for c in load_golden("engine_truth.json")["cases"]:
+        f = Finder(GpuEngine(), EmptyRgxEngine(), c["caseSensitive"])
+        f.AddExpression(c["expression"])
+        assert bool(f.ProcessText(c["text"])) is c["expected_true"], c["text"]
+        assert bool(f.ProcessText(c["text"].upper())) is c["expected_true"]      # case-insensitive finder
+
+
+# ---- examples/finder/main.go -------------------------------------------------------------------------------
+@pytest.mark.parametrize("which", ["case_sensitive", "case_insensitive"])
+def test_examples_finder(which):
+    g = load_golden("examples.json")
+    sec = g[which]
+    cs = which == "case_sensitive"
+    f = Finder(GpuEngine(), PyRegexpEngine(), cs)
+    for e, tag in sec["expressions"]:
+        f.AddExpressionWithTag(e, tag)
+    for text, want in zip(g["texts"], sec["expected_true"]):
+        res = f.ProcessText(text)
+        assert [r.ExpresionIndex for r in res] == want
+        assert [r.Tag for r in res] == [sec["expressions"][i][1] for i in want]
+        assert [r.ExpresionStr for r in res] == [sec["expressions"][i][0] for i in want]
+    # batch extension agrees with the per-document calls
+    bm = f.ProcessTexts(g["texts"])
+    for d, want in enumerate(sec["expected_true"]):
+        assert [i for i in range(len(sec["expressions"])) if bm[d, i >> 5] >> (i & 31) & 1] == want
+
+
+def test_gpu_engine_find_substrings():
+    e = GpuEngine()
+    e.BuildEngine({"he", "she", "his", "hers"}, True)
+    assert e.FindSubstrings("ushers") == [Match(1, "she"), Match(2, "he"), Match(2, "hers")]
+    assert e.FindSubstrings("") == []
+
+
+def test_solve_error_is_returned_like_the_reference():
+    """`"a" "b" and "c"` parses (parser.go:220-233) but Solve fails on its UNSET node for every document
+    (expression.go:139-141); ProcessText returns that error after the engine calls."""
+    f = Finder(GpuEngine(), EmptyRgxEngine(), True)
+    f.AddExpression('"x"')
+    f.AddExpression('"a" "b" and "c"')
+    with pytest.raises(FinderError) as ei:
+        f.ProcessText("abc")
+    assert str(ei.value) == "unable to process expression type 0"
+    o = Oracle(["a", "b", "c", "x"])
+    o.set_expressions(['"x"', '"a" "b" and "c"'], True)
+    blob, off = pack_strings(["abc"])
+    with pytest.raises(RuntimeError, match="unable to process expression type 0"):
+        o.process(blob, off)
+
+
+def test_unicode_case_folding_end_to_end():
+    f = Finder(GpuEngine(), EmptyRgxEngine(), False)
+    f.AddExpression('"STRAßE" and inord("ÉCOLE" and "Ünïcode")')
+    f.AddExpression('"ecole"')
+    res = f.ProcessText("École de la Straße, ÜNÏCODE")
+    assert [r.ExpresionIndex for r in res] == [0]
+    bm = f.ProcessTexts(["École de la Straße, ÜNÏCODE", "ecole", "ÉCOLE ÜNÏCODE"])
+    assert bm[:, 0].tolist() == [1, 2, 0]
+
+
+def test_process_texts_matches_oracle_with_regex_terms():
+    from gofindthem_amd.workload import Workload, make_expressions
+    from oracle import dsl_ref
+    w = Workload(300)
+    terms = w.terms()
+    rx = ["en.*nr", "po[a-z]+ud", "q+"]
+    exprs = make_expressions(terms, 120, inord_fraction=0.4, regexes=rx)
+    f = Finder(GpuEngine(), PyRegexpEngine(), False)
+    f.AddExpressions(exprs)
+    text, off = w.docs_host(0, 60)
+    bm = f.ProcessTexts(blob=text, doc_off=off)
+    # oracle side: same keyword set, regex hits computed by the same host regex stand-in
+    kws = sorted(f.GetKeywords())
+    o = Oracle(kws)
+    o.set_expressions(exprs, False)
+    eng = PyRegexpEngine()
+    eng.BuildEngine(sorted(f.GetRegexes()), False)
+    offs, lits, poss = [0], [], []
+    for d in range(60):
+        t = bytes(text[int(off[d]):int(off[d + 1])])
+        for m in eng.FindRegexes(t):
+            lits.append(o.literals.index(m.Term))
+            poss.append(m.Position)
+        offs.append(len(lits))
+    extra = (np.asarray(offs, np.uint64), np.asarray(lits or [0], np.int32), np.asarray(poss or [0], np.int64))
+    want = o.process(text, off, fold=True, extra=extra)
+    assert np.array_equal(bm, want)
+    assert any(len(x) for x in (lits,))

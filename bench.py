@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py -- ProcessText hot path on MI355X: documents/s and input GB/s, 10 k-term dictionary + 1 k expressions
+over 1 M synthetic ~4 KB documents per GPU (BASELINE.json configs[2]; SURVEY.md 8(d) workload).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over the rank's batch, inputs already resident in HBM:
+Finder.ProcessDevice = work-unit setup + Aho-Corasick scan kernel + CSR gather + solver kernel -> hit bitmap,
+plus (N > 1) one RCCL gather of every rank's bitmap to rank 0.  Documents are independent, so ranks own
+disjoint document ranges of the same size ("weak" scaling) and nothing else is exchanged.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (scan kernel, live HIP-event
+timing) and `cpu_baseline` (the CPU oracle timed on this host, rank 0 / N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--docs", type=int, default=1_000_000, help="documents per GPU")
+    ap.add_argument("--terms", type=int, default=10_000)
+    ap.add_argument("--exprs", type=int, default=1_000)
+    ap.add_argument("--inord", type=float, default=0.0, help="fraction of INORD(...) expressions (config 4: 0.5)")
+    ap.add_argument("--cpu-docs", type=int, default=-1, help="documents in the CPU baseline sample (-1 auto, 0 off)")
+    ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--parity-docs", type=int, default=2048)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a HIP device (there is no CPU fallback for the hot path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
+
+    from gofindthem_amd.engine import Engine  # noqa: F401  (fails loudly if libgft.so is missing)
+    from gofindthem_amd.finder import EmptyRgxEngine, Finder, GpuEngine
+    from gofindthem_amd.workload import Workload, make_expressions
+    from gofindthem_amd import _lib
+    import ctypes as C
+
+    # ---- workload ---------------------------------------------------------------------------------------
+    t_setup = time.time()
+    wl = Workload(args.terms)
+    terms = wl.terms()
+    exprs = make_expressions(terms, args.exprs, inord_fraction=args.inord, cover=True)
+    finder = Finder(GpuEngine.__new__(GpuEngine), EmptyRgxEngine(), caseSensitive=False, device=local_rank)
+    # (NewFinder(GpuEngine, EmptyRgxEngine, caseSensitive=false) as in BMDslSearch, benchmark_test.go:417; the
+    # finder owns the gft_engine behind its GPU substring engine)
+    finder.AddExpressions(exprs)
+    assert len(finder.GetKeywords()) == args.terms, "the expressions must reference the whole dictionary"
+    finder.ForceBuild()
+    L = _lib.load()
+    eh = finder.engine_handle()
+    stream = torch.cuda.current_stream().cuda_stream
+    assert L.gft_set_stream(eh, stream) == 0
+    first = rank * args.docs
+    text, doc_off = wl.docs_device(first, args.docs, device=dev)
+    words = (args.exprs + 31) // 32
+    bitmap = torch.zeros((args.docs, words), dtype=torch.int32, device=dev)
+    gather_list = None
+    if world > 1 and rank == 0:
+        gather_list = [torch.empty_like(bitmap) for _ in range(world)]
+    text_bytes = int(text.numel())
+
+    def step():
+        finder.ProcessDevice(text.data_ptr(), doc_off.data_ptr(), args.docs, bitmap.data_ptr())
+        if world > 1:
+            dist.gather(bitmap, gather_list, dst=0)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # match volume H (drives the algorithmic bytes of the scan kernel)
+    m = _lib.GftMatches()
+    rc = L.gft_scan_device(eh, text.data_ptr(), doc_off.data_ptr(), args.docs, _lib.GFT_FOLD_ASCII, C.byref(m))
+    assert rc == 0, L.gft_last_error(eh)
+    n_matches = int(m.n_matches)
+    setup_s = time.time() - t_setup
+
+    # ---- timed region -------------------------------------------------------------------------------------
+    for _ in range(args.warmup):
+        step()
+    L.gft_profile_enable(eh, 1)
+    L.gft_profile_reset(eh)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    L.gft_profile_enable(eh, 0)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    def prof(name):
+        ms, n = C.c_double(), C.c_uint64()
+        L.gft_profile_read(eh, name.encode(), C.byref(ms), C.byref(n))
+        return ms.value, int(n.value)
+    scan_ms, scan_n = prof("scan")
+    solve_ms, solve_n = prof("solve")
+    aux_ms, aux_n = prof("aux")
+
+    # ---- parity in the same run: sampled documents against the CPU oracle, bit-exact ------------------------------
+    from oracle.pyoracle import Oracle
+    S = min(args.parity_docs, args.docs)
+    h_text, h_off = wl.docs_host(first, S)
+    d_off = doc_off[:S + 1].cpu().numpy().astype(np.uint64)
+    gen_ok = bool(np.array_equal(d_off, h_off)) and bool(
+        np.array_equal(text[:int(h_off[-1])].cpu().numpy(), h_text))
+    orc = Oracle(terms)
+    orc.set_expressions(exprs, case_sensitive=False)
+    want = orc.process(h_text, h_off, fold=True, n_threads=min(8, os.cpu_count() or 1))
+    got = bitmap[:S].cpu().numpy().view(np.uint32)
+    parity_ok = gen_ok and bool(np.array_equal(got, want))
+    if world > 1:
+        flag = torch.tensor([1 if parity_ok else 0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        parity_ok = bool(flag.item())
+        if rank == 0:   # the gathered copy of the last rank equals what that rank computed (checked via its sample)
+            parity_ok = parity_ok and bool(torch.equal(gather_list[0], bitmap))
+
+    # ---- CPU baseline (rank 0, N == 1): the oracle = our restatement of the reference path, on this host ---------------
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_docs != 0:
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        cores = min(cores, args.cpu_threads)      # a 1-GPU box's CPU share is 16 cores
+        n_cpu = args.cpu_docs if args.cpu_docs > 0 else min(args.docs, 4000 * cores)
+        n_cpu = min(n_cpu, args.docs)
+        c_off = doc_off[:n_cpu + 1].cpu().numpy().astype(np.uint64)
+        c_text = text[:int(c_off[-1])].cpu().numpy()
+        tc = time.perf_counter()
+        ref = orc.process(c_text, c_off, fold=True, n_threads=cores)
+        tc = time.perf_counter() - tc
+        same = bool(np.array_equal(ref, bitmap[:n_cpu].cpu().numpy().view(np.uint32)))
+        parity_ok = parity_ok and same
+        cpu = {"value": n_cpu / tc, "unit": "docs/s", "cores": cores, "kind": "port",
+               "input_GBps": float(c_off[-1]) / tc / 1e9,
+               "sample": "first %d documents of the same corpus (%.1f MB), oracle/ac_oracle.cpp ProcessText "
+                         "restatement, %d std::thread workers, %.1f s; bitmap equal to the GPU's: %s"
+                         % (n_cpu, float(c_off[-1]) / 1e6, cores, tc, same)}
+
+    if rank == 0:
+        docs_total = args.docs * world * args.steps
+        ms_per_step = elapsed / args.steps * 1e3
+        # algorithmic bytes of the dominant (scan) kernel per launch: text once + one offset entry per document +
+        # 8 bytes per match written
+        alg_bytes = text_bytes + 8 * args.docs + 8 * n_matches
+        scan_avg_ms = scan_ms / max(scan_n, 1)
+        achieved = alg_bytes / (scan_avg_ms * 1e-3) / 1e9 if scan_n else 0.0
+        out = {
+            "metric": "ProcessText throughput: documents/s (and input GB/s), %d-term dictionary + %d expressions, "
+                      "%d docs of ~4 KB per GPU" % (args.terms, args.exprs, args.docs),
+            "value": docs_total / elapsed,
+            "unit": "docs/s",
+            "input_GBps": text_bytes * world * args.steps / elapsed / 1e9,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[2]: %d terms + %d %s expressions, %d docs x ~4 KB per GPU "
+                                   "(SURVEY.md 8(d) generator), case-insensitive finder, inputs resident in HBM"
+                                   % (args.terms, args.exprs, "AND/OR/NOT" if args.inord == 0 else
+                                      "AND/OR/NOT + %.0f%% INORD" % (args.inord * 100), args.docs),
+                       "docs_per_gpu": args.docs, "text_bytes_per_gpu": text_bytes, "matches_per_gpu": n_matches,
+                       "matches_per_doc": n_matches / args.docs, "parallelism": "docs sharded x%d" % world},
+            "roofline": {"bound": "hbm", "kernel": "k_scan_units", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": None,
+                         "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": scan_avg_ms, "launches": scan_n},
+            "kernels_ms_per_step": {"scan": scan_ms / args.steps, "solve": solve_ms / args.steps,
+                                    "aux(units+prefix sums+gather)": aux_ms / args.steps},
+            "cpu_baseline": cpu,
+            "parity": "bit-exact vs CPU oracle on sampled documents" if parity_ok else "PARITY FAILED",
+            "setup_s": setup_s,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not parity_ok:
+        sys.exit(3)
+
+
+if __name__ == "__main__":
+    main()

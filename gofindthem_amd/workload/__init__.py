@@ -128,11 +128,17 @@ class Workload:
         return text[:total], off
 
 
-def make_expressions(terms, n_exprs, inord_fraction=0.0, seed=BASE_SEED + 3, regexes=()):
-    """Expression strings over `terms` (list of bytes), SURVEY.md 8(d):
-    each has 1 + r%10 leaves (benchmarks/benchmark_test.go:467); a fraction is INORD(t1 AND ... AND tk) exactly
-    like createRandExpressionAndSolverMap (:449-460); the rest combine leaves with random and/or/not and optional
-    parentheses.  `regexes` (source strings) are mixed in as r"..." leaves when given."""
+def make_expressions(terms, n_exprs, inord_fraction=0.0, seed=BASE_SEED + 3, regexes=(), cover=False):
+    """Expression strings over `terms` (list of bytes), SURVEY.md 8(d).
+
+    cover=False: each expression has 1 + r%10 leaves drawn uniformly from `terms` (benchmarks/benchmark_test.go:467).
+    cover=True : the finder's dictionary is exactly the keyword set of its expressions (finder/finder.go:123-126), so
+                 for the automaton to hold ALL `terms` ("10 k-term dictionary + 1 k expressions") the leaves walk a
+                 shuffled cycle of `terms` and leaf counts are 1 + r%(2*len(terms)/n_exprs - 1), topped up until every
+                 term is referenced at least once.
+    A fraction `inord_fraction` is INORD(t1 AND ... AND tk) exactly like createRandExpressionAndSolverMap (:449-460);
+    the rest combine leaves with random and/or/not and optional parentheses.  `regexes` (source strings) are mixed in
+    as r"..." leaves when given."""
     key = mix(seed)
     ctr = [0]
 
@@ -144,16 +150,36 @@ def make_expressions(terms, n_exprs, inord_fraction=0.0, seed=BASE_SEED + 3, reg
         s = t.decode("ascii").replace("\\", "\\\\").replace('"', '\\"')
         return '"%s"' % s
 
+    if cover:
+        span = max(2 * len(terms) // max(n_exprs, 1) - 1, 1)
+        counts = [1 + rnd(span) for _ in range(n_exprs)]
+        while sum(counts) < len(terms):
+            counts[rnd(n_exprs)] += 1
+        perm = list(range(len(terms)))
+        for i in range(len(perm) - 1, 0, -1):
+            j = rnd(i + 1)
+            perm[i], perm[j] = perm[j], perm[i]
+        cur = [0]
+
+        def next_term():
+            t = terms[perm[cur[0] % len(perm)]]
+            cur[0] += 1
+            return t
+    else:
+        counts = [1 + rnd(10) for _ in range(n_exprs)]
+
+        def next_term():
+            return terms[rnd(len(terms))]
+
     def leaf():
         if regexes and rnd(8) == 0:
             return 'r"%s"' % regexes[rnd(len(regexes))]
-        return lit(terms[rnd(len(terms))])
+        return lit(next_term())
 
     out = []
-    for _ in range(n_exprs):
-        k = 1 + rnd(10)
+    for k in counts:
         if inord_fraction > 0 and rnd(1000) < int(inord_fraction * 1000):
-            out.append("INORD(" + " AND ".join(lit(terms[rnd(len(terms))]) for _ in range(k)) + ")")
+            out.append("INORD(" + " AND ".join(lit(next_term()) for _ in range(k)) + ")")
             continue
         parts, depth = [], 0
         for i in range(k):

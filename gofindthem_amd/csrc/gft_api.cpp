@@ -58,7 +58,9 @@ struct gft_engine {
     // programs
     bool have_programs = false;
     uint32_t n_exprs = 0, n_extra = 0;
-    DevBuf d_prog, d_prog_off;
+    DevBuf d_prog, d_prog_off;            // public postfix words (INORD group subtrees are read from these)
+    DevBuf d_fprog, d_fprog_off, d_groups; // fused internal form + INORD group table
+    DevBuf d_pscratch;                    // HBM presence matrices when n_slots * 8 B does not fit LDS
 
     // workspace
     DevBuf d_unit_cnt, d_unit_base, d_units, d_partial, d_cursor, d_pool_term, d_pool_pos, d_unit_start,
@@ -171,6 +173,57 @@ int check_program(const gft_engine* e, const uint32_t* w, uint64_t len, uint32_t
     return GFT_OK;
 }
 
+// public postfix words -> fused internal form (gft_kernels.hpp FusedOp) + INORD group table.
+// `gbase` = offset of this program inside the uploaded public word array.
+void fuse_program(const uint32_t* w, uint64_t len, uint64_t gbase, std::vector<uint32_t>& out,
+                  std::vector<uint32_t>& groups) {
+    std::vector<uint64_t> starts;   // start index (in w) of every operand on the stack
+    auto is_bin = [&](uint64_t i) { return i < len && ((w[i] >> 28) == GFT_OP_AND || (w[i] >> 28) == GFT_OP_OR); };
+    for (uint64_t i = 0; i < len; i++) {
+        const uint32_t op = w[i] >> 28;
+        switch (op) {
+        case GFT_OP_UNIT: {
+            const uint32_t slot = w[i] & GFT_SLOT_MASK;
+            // a UNIT directly followed by a binary operator is that operator's right operand
+            if (!starts.empty() && is_bin(i + 1)) {
+                out.push_back(((w[i + 1] >> 28) == GFT_OP_AND ? kFopAndS : kFopOrS) << 28 | slot);
+                i += 1;   // the operator is consumed: left operand stays on the stack, merged
+                break;
+            }
+            if (!starts.empty() && i + 1 < len && (w[i + 1] >> 28) == GFT_OP_NOT && is_bin(i + 2)) {
+                out.push_back(((w[i + 2] >> 28) == GFT_OP_AND ? kFopAndNS : kFopOrNS) << 28 | slot);
+                i += 2;
+                break;
+            }
+            out.push_back(kFopLoad << 28 | slot);
+            starts.push_back(i);
+            break;
+        }
+        case GFT_OP_AND:
+        case GFT_OP_OR:
+            out.push_back((op == GFT_OP_AND ? kFopAndPop : kFopOrPop) << 28);
+            starts.pop_back();
+            break;
+        case GFT_OP_NOT:
+            out.push_back(kFopNot << 28);
+            break;
+        case GFT_OP_INORD: {
+            const uint64_t s = starts.back();
+            // a group with a single leaf has a non-empty position list exactly when the leaf is present
+            // (every reported key carries >= 1 position), so no position check is needed
+            if (i - s > 1) {
+                out.push_back(kFopInord << 28 | (uint32_t)(groups.size() / 2));
+                groups.push_back((uint32_t)(gbase + s));
+                groups.push_back((uint32_t)(i - s));
+            }
+            break;
+        }
+        default:
+            break;
+        }
+    }
+}
+
 int ensure_pool(gft_engine* e, uint64_t entries) {
     if (entries <= e->pool_cap) return GFT_OK;
     HIP_TRY(e->d_pool_term.ensure(entries * 4), "pool alloc");
@@ -182,7 +235,7 @@ int ensure_pool(gft_engine* e, uint64_t entries) {
 // The device pipeline shared by scan and process.  On success the canonical CSR sits in e->d_match_off /
 // d_term / d_pos and *n_matches is set.
 int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_off, uint64_t n_docs, uint32_t flags,
-                  uint64_t* n_matches) {
+                  bool need_csr, uint64_t* n_matches) {
     hipStream_t st = e->stream;
     *n_matches = 0;
     HIP_TRY(e->d_match_off.ensure((n_docs + 1) * 8), "match_off alloc");
@@ -252,6 +305,9 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         if (rc) return rc;
     }
 
+    *n_matches = total;
+    if (!need_csr) return GFT_OK;   // the solver reads the slabs in place (doc -> units -> pool)
+
     // 3. slabs -> canonical CSR
     HIP_TRY(e->d_term.ensure(std::max<uint64_t>(total, 1) * 4), "result alloc");
     HIP_TRY(e->d_pos.ensure(std::max<uint64_t>(total, 1) * 4), "result alloc");
@@ -272,19 +328,32 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
 int solve_pipeline(gft_engine* e, uint64_t n_docs, const gft_extra_matches* d_extra, uint32_t* d_bitmap) {
     if (!n_docs || !e->n_exprs) return GFT_OK;
     SolveParams S;
-    S.match_off = e->d_match_off.as<uint64_t>(); S.term_id = e->d_term.as<uint32_t>(); S.pos = e->d_pos.as<uint32_t>();
+    S.doc_unit_base = e->d_unit_base.as<uint64_t>();
+    S.unit_start = e->d_unit_start.as<uint64_t>(); S.unit_count = e->d_unit_count.as<uint32_t>();
+    S.term = e->d_pool_term.as<uint32_t>(); S.pos = e->d_pool_pos.as<uint32_t>();
     S.x_off = d_extra ? d_extra->off : nullptr;
     S.x_slot = d_extra ? d_extra->slot : nullptr;
     S.x_pos = d_extra ? d_extra->pos : nullptr;
     S.n_docs = n_docs;
-    S.prog = e->d_prog.as<uint32_t>(); S.prog_off = e->d_prog_off.as<uint64_t>();
-    S.n_exprs = e->n_exprs; S.n_terms = (uint32_t)e->tab.terms.size();
-    S.present_words = (S.n_terms + e->n_extra + 31) / 32 + 1;
+    S.fprog = e->d_fprog.as<uint32_t>(); S.fprog_off = e->d_fprog_off.as<uint64_t>();
+    S.gprog = e->d_prog.as<uint32_t>(); S.groups = e->d_groups.as<uint32_t>();
+    S.n_exprs = e->n_exprs;
+    S.n_slots = (uint32_t)e->tab.terms.size() + e->n_extra + 1;
+    S.tile_words = std::min<uint32_t>(kSolveTileWords, (e->n_exprs + 31) / 32);
     S.bitmap = d_bitmap;
-    if (solve_lds_bytes(S.present_words) > e->lds_max)
-        return fail(e, GFT_E_UNSUPPORTED, "dictionary too large for the LDS presence bitset");
+    S.p_scratch = nullptr;
+    // presence matrix (8 B per slot) in LDS when it fits next to the output tile, else in HBM (served by L2)
+    const bool p_in_lds = solve_lds_bytes(S.n_slots, S.tile_words, true) + 1024 <= e->lds_max;
+    const uint64_t n_groups = (n_docs + 63) / 64;
+    const size_t lds_need = solve_lds_bytes(S.n_slots, S.tile_words, p_in_lds) + 512;
+    const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, e->lds_max / lds_need));
+    unsigned grid = (unsigned)std::min<uint64_t>(n_groups, (uint64_t)e->n_cus * per_cu);
+    if (!p_in_lds) {
+        HIP_TRY(e->d_pscratch.ensure((size_t)grid * S.n_slots * 8), "presence scratch alloc");
+        S.p_scratch = e->d_pscratch.as<uint64_t>();
+    }
     ProfScope ps(e, "solve");
-    HIP_TRY(launch_solve(S, e->n_cus, e->stream), "solve kernel launch");
+    HIP_TRY(launch_solve(S, p_in_lds, grid, e->stream), "solve kernel launch");
     return GFT_OK;
 }
 
@@ -330,7 +399,8 @@ void gft_engine_destroy(gft_engine* e) {
         for (auto& kv : e->prof)
             for (auto& p : kv.second.ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
         DevBuf* all[] = {&e->d_byte_class, &e->d_delta, &e->d_out_term, &e->d_out_link, &e->d_term_len, &e->d_prog,
-                         &e->d_prog_off, &e->d_unit_cnt, &e->d_unit_base, &e->d_units, &e->d_partial, &e->d_cursor,
+                         &e->d_prog_off, &e->d_fprog, &e->d_fprog_off, &e->d_groups, &e->d_pscratch,
+&e->d_unit_cnt, &e->d_unit_base, &e->d_units, &e->d_partial, &e->d_cursor,
                          &e->d_pool_term, &e->d_pool_pos, &e->d_unit_start, &e->d_unit_count, &e->d_unit_out,
                          &e->d_term, &e->d_pos, &e->d_match_off, &e->d_text, &e->d_doc_off, &e->d_bitmap, &e->d_xoff,
                          &e->d_xslot, &e->d_xpos};
@@ -420,7 +490,7 @@ int gft_scan_device(gft_engine* e, const uint8_t* d_text_blob, const uint64_t* d
     if (!e->built) return fail(e, GFT_E_NOT_BUILT, "gft_build has not been called");
     DeviceGuard g(e->device);
     uint64_t nm = 0;
-    int rc = scan_pipeline(e, d_text_blob, d_doc_off, n_docs, flags, &nm);
+    int rc = scan_pipeline(e, d_text_blob, d_doc_off, n_docs, flags, true, &nm);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream), "scan pipeline");
     out_dev->n_docs = n_docs; out_dev->n_matches = nm;
@@ -448,7 +518,7 @@ int gft_scan(gft_engine* e, const uint8_t* text_blob, const uint64_t* doc_off, u
     int rc = stage_docs(e, text_blob, doc_off, n_docs);
     if (rc) return rc;
     uint64_t nm = 0;
-    rc = scan_pipeline(e, e->d_text.as<uint8_t>(), e->d_doc_off.as<uint64_t>(), n_docs, flags, &nm);
+    rc = scan_pipeline(e, e->d_text.as<uint8_t>(), e->d_doc_off.as<uint64_t>(), n_docs, flags, true, &nm);
     if (rc) return rc;
     e->h_match_off.assign(n_docs + 1, 0);
     e->h_term.assign(nm, 0);
@@ -483,6 +553,17 @@ int gft_set_programs(gft_engine* e, const uint32_t* prog_words, const uint64_t* 
     int rc;
     if ((rc = upload(e, e->d_prog, w, "program upload"))) return rc;
     if ((rc = upload(e, e->d_prog_off, o, "program upload"))) return rc;
+    std::vector<uint32_t> fw, groups;
+    std::vector<uint64_t> fo(1, 0);
+    for (uint32_t i = 0; i < n_exprs; i++) {
+        fuse_program(prog_words + prog_off[i], prog_off[i + 1] - prog_off[i], prog_off[i], fw, groups);
+        fo.push_back(fw.size());
+    }
+    if (fw.empty()) fw.push_back(0);
+    if (groups.empty()) groups.assign(2, 0);
+    if ((rc = upload(e, e->d_fprog, fw, "program upload"))) return rc;
+    if ((rc = upload(e, e->d_fprog_off, fo, "program upload"))) return rc;
+    if ((rc = upload(e, e->d_groups, groups, "program upload"))) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream), "program upload");
     e->n_exprs = n_exprs; e->n_extra = n_extra; e->have_programs = true;
     return GFT_OK;
@@ -497,7 +578,7 @@ int gft_process_device(gft_engine* e, const uint8_t* d_text_blob, const uint64_t
     if (n_docs && e->n_exprs && !d_hit_bitmap) return fail(e, GFT_E_INVALID, "null bitmap");
     DeviceGuard g(e->device);
     uint64_t nm = 0;
-    int rc = scan_pipeline(e, d_text_blob, d_doc_off, n_docs, flags, &nm);
+    int rc = scan_pipeline(e, d_text_blob, d_doc_off, n_docs, flags, false, &nm);
     if (rc) return rc;
     rc = solve_pipeline(e, n_docs, d_extra, d_hit_bitmap);
     if (rc) return rc;
@@ -534,7 +615,7 @@ int gft_process(gft_engine* e, const uint8_t* text_blob, const uint64_t* doc_off
     const uint64_t words = (e->n_exprs + 31) / 32;
     HIP_TRY(e->d_bitmap.ensure(std::max<uint64_t>(n_docs * words, 1) * 4), "bitmap alloc");
     uint64_t nm = 0;
-    rc = scan_pipeline(e, e->d_text.as<uint8_t>(), e->d_doc_off.as<uint64_t>(), n_docs, flags, &nm);
+    rc = scan_pipeline(e, e->d_text.as<uint8_t>(), e->d_doc_off.as<uint64_t>(), n_docs, flags, false, &nm);
     if (rc) return rc;
     rc = solve_pipeline(e, n_docs, pdx, e->d_bitmap.as<uint32_t>());
     if (rc) return rc;

@@ -4,8 +4,7 @@
 //                  Replaces (*Matcher).MatchAll as called from CloudflareForkEngine.FindSubstrings
 //                  (finder/substringEngine.go:110-119).
 //   k_gather       unit slabs -> canonical CSR (document order, reference emission order inside a document).
-//   k_solve        per-document evaluation of every expression program.  Replaces addMatchesToSolverMap +
-//                  solveExpressions (finder/finder.go:181-215) and Expression.solve (dsl/expression.go:66-142).
+//   (the solver kernel lives in gft_solve.hip)
 //   k_*scan*       exclusive prefix sums used to lay the CSR out.
 //
 // No MFMA anywhere: this is a byte automaton walk plus boolean/integer evaluation (HBM/LDS bound).
@@ -246,182 +245,6 @@ __global__ void __launch_bounds__(256) k_match_off(const uint64_t* __restrict__ 
     if (d <= n_docs) match_off[d] = unit_out[unit_base[d]];
 }
 
-// ------------------------------------------------------------------------------------------------------
-// k_solve (v1): one wave per document, one lane per expression (64 at a time).
-//
-// Per document the wave builds the slot-presence bitset in LDS (UNIT truth == key presence in the reference's
-// map, dsl/expression.go:68-72) and every lane interprets its postfix program.  Inside an INORD group a node's
-// position list is kept as a set of (slot, theta) pairs meaning { p in pos(slot) : p > theta }:
-//   UNIT t      -> {(t, -1)}
-//   OR          -> union (duplicates irrelevant: only minimum / emptiness are ever observed)
-//   AND(L, R)   -> m = min over L of succ(t, theta); empty if m = +inf, else {(t, max(theta, m)) : (t, theta) in R}
-//                  (== rpos[getLowestIdxGTVal(rpos, lpos[0]):], dsl/expression.go:87-93,175-189)
-//   INORD       -> rval && exists pair with succ < +inf   (dsl/expression.go:129-137)
-// succ(t, theta) = first position of slot t greater than theta in this document.
-// ------------------------------------------------------------------------------------------------------
-struct DocMatches {
-    const uint32_t* term;
-    const uint32_t* pos;
-    uint32_t n;
-    const uint32_t* xslot;   // caller-supplied matches, absolute slots
-    const uint32_t* xpos;
-    uint32_t nx;
-    uint32_t n_terms;
-};
-
-// first position of `slot` that is > theta (theta == -1 means "any"), or INT64_MAX
-__device__ __forceinline__ int64_t succ_query(const DocMatches& M, uint32_t slot, int64_t theta) {
-    int64_t best = INT64_MAX;
-    for (uint32_t i = 0; i < M.n; i++)
-        if (M.term[i] == slot) {
-            int64_t p = M.pos[i];
-            if (p > theta && p < best) best = p;
-        }
-    // a keyword and a regex with the same literal share one map key (finder.go:181-196): the caller maps
-    // both onto one slot, so both lists are consulted
-    for (uint32_t i = 0; i < M.nx; i++)
-        if (M.xslot[i] == slot) {
-            int64_t p = M.xpos[i];
-            if (p > theta && p < best) best = p;
-        }
-    return best;
-}
-
-struct Pair { uint32_t slot; int32_t theta; };
-
-__device__ bool eval_program(const uint32_t* __restrict__ prog, uint32_t len, const uint32_t* __restrict__ present,
-                             const DocMatches& M) {
-    // bool stack as bits, pair-range stack only used inside INORD groups
-    uint64_t bits_lo = 0, bits_hi = 0;   // up to 128 deep
-    uint32_t sp = 0;
-    Pair pairs[kMaxPairs];
-    uint16_t rbeg[kMaxPairDepth], rcnt[kMaxPairDepth];
-    uint32_t psp = 0;  // pair-range stack pointer
-
-    auto push = [&](bool v) {
-        if (sp < 64) bits_lo = (bits_lo & ~(1ull << sp)) | ((uint64_t)v << sp);
-        else bits_hi = (bits_hi & ~(1ull << (sp - 64))) | ((uint64_t)v << (sp - 64));
-        sp++;
-    };
-    auto pop = [&]() -> bool {
-        sp--;
-        return sp < 64 ? (bits_lo >> sp) & 1 : (bits_hi >> (sp - 64)) & 1;
-    };
-
-    for (uint32_t pc = 0; pc < len; pc++) {
-        const uint32_t w = prog[pc];
-        const uint32_t op = w >> 28;
-        const bool in_inord = (w & GFT_K_INORD_FLAG) != 0;
-        switch (op) {
-        case 1: {  // UNIT
-            const uint32_t slot = w & GFT_K_SLOT_MASK;
-            push((present[slot >> 5] >> (slot & 31)) & 1);
-            if (in_inord) {
-                const uint32_t b = psp ? rbeg[psp - 1] + rcnt[psp - 1] : 0;
-                pairs[b] = Pair{slot, -1};
-                rbeg[psp] = (uint16_t)b; rcnt[psp] = 1; psp++;
-            }
-            break;
-        }
-        case 2: {  // AND
-            const bool r = pop(), l = pop();
-            push(l && r);
-            if (in_inord) {
-                const uint32_t lb = rbeg[psp - 2], lc = rcnt[psp - 2], rb = rbeg[psp - 1], rc = rcnt[psp - 1];
-                int64_t m = INT64_MAX;
-                for (uint32_t i = 0; i < lc; i++) {
-                    int64_t s = succ_query(M, pairs[lb + i].slot, pairs[lb + i].theta);
-                    if (s < m) m = s;
-                }
-                uint32_t nc = 0;
-                if (m != INT64_MAX)
-                    for (uint32_t i = 0; i < rc; i++) {
-                        Pair q = pairs[rb + i];
-                        if ((int64_t)q.theta < m) q.theta = (int32_t)m;
-                        pairs[lb + nc++] = q;
-                    }
-                psp--;
-                rcnt[psp - 1] = (uint16_t)nc;
-            }
-            break;
-        }
-        case 3: {  // OR
-            const bool r = pop(), l = pop();
-            push(l || r);
-            if (in_inord) {  // ranges are adjacent: union == concatenation
-                psp--;
-                rcnt[psp - 1] = (uint16_t)(rcnt[psp - 1] + rcnt[psp]);
-            }
-            break;
-        }
-        case 4:  // NOT
-            push(!pop());
-            break;
-        case 5: {  // INORD: rval && len(rpos) > 0
-            bool v = pop();
-            bool any = false;
-            const uint32_t b = rbeg[psp - 1], c = rcnt[psp - 1];
-            for (uint32_t i = 0; i < c && !any; i++)
-                any = succ_query(M, pairs[b + i].slot, pairs[b + i].theta) != INT64_MAX;
-            psp--;
-            push(v && any);
-            break;
-        }
-        default:
-            break;
-        }
-    }
-    return sp ? pop() : false;
-}
-
-__global__ void __launch_bounds__(kSolveBlockThreads) k_solve(const SolveParams P) {
-    extern __shared__ __align__(16) uint8_t smem[];
-    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
-    uint32_t* present = reinterpret_cast<uint32_t*>(smem) + (size_t)wave * P.present_words;
-    const uint32_t bm_words = (P.n_exprs + 31) / 32;
-
-    for (uint64_t d = (uint64_t)blockIdx.x * wpb + wave; d < P.n_docs; d += (uint64_t)gridDim.x * wpb) {
-        for (uint32_t i = lane; i < P.present_words; i += kLane) present[i] = 0;
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        DocMatches M;
-        const uint64_t mo = P.match_off[d];
-        M.term = P.term_id + mo; M.pos = P.pos + mo; M.n = (uint32_t)(P.match_off[d + 1] - mo);
-        M.n_terms = P.n_terms;
-        M.nx = 0; M.xslot = nullptr; M.xpos = nullptr;
-        if (P.x_off) {
-            const uint64_t xo = P.x_off[d];
-            M.xslot = P.x_slot + xo; M.xpos = P.x_pos + xo; M.nx = (uint32_t)(P.x_off[d + 1] - xo);
-        }
-        for (uint32_t i = lane; i < M.n; i += kLane) {
-            const uint32_t t = M.term[i];
-            atomicOr(&present[t >> 5], 1u << (t & 31));
-        }
-        for (uint32_t i = lane; i < M.nx; i += kLane) {
-            const uint32_t t = M.xslot[i];
-            atomicOr(&present[t >> 5], 1u << (t & 31));
-        }
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-
-        uint32_t* row = P.bitmap + d * bm_words;
-        for (uint32_t e0 = 0; e0 < P.n_exprs; e0 += kLane) {
-            const uint32_t e = e0 + lane;
-            bool v = false;
-            if (e < P.n_exprs) {
-                const uint64_t po = P.prog_off[e];
-                v = eval_program(P.prog + po, (uint32_t)(P.prog_off[e + 1] - po), present, M);
-            }
-            const uint64_t b = __ballot(v);
-            if (lane == 0) {
-                row[e0 >> 5] = (uint32_t)b;
-                if ((e0 >> 5) + 1 < bm_words) row[(e0 >> 5) + 1] = (uint32_t)(b >> 32);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
 inline unsigned grid_for(uint64_t n, unsigned per_block, unsigned cap) {
     uint64_t g = (n + per_block - 1) / per_block;
     if (g < 1) g = 1;
@@ -487,19 +310,6 @@ hipError_t launch_gather(const uint64_t* d_unit_start, const uint32_t* d_unit_co
     if (n_units)
         k_gather<<<dim3(grid_for(n_units, 4, n_cus * 16)), dim3(256), 0, st>>>(
             d_unit_start, d_unit_count, d_unit_out, n_units, d_pool_term, d_pool_pos, d_term, d_pos);
-    return hipGetLastError();
-}
-
-size_t solve_lds_bytes(uint32_t present_words) { return (size_t)(kSolveBlockThreads / 64) * present_words * 4; }
-
-hipError_t launch_solve(const SolveParams& P, unsigned n_cus, hipStream_t st) {
-    if (!P.n_docs || !P.n_exprs) return hipSuccess;
-    const size_t lds = solve_lds_bytes(P.present_words);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_solve),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    const unsigned wpb = kSolveBlockThreads / 64;
-    k_solve<<<dim3(grid_for(P.n_docs, wpb, n_cus * 8)), dim3(kSolveBlockThreads), lds, st>>>(P);
     return hipGetLastError();
 }
 

@@ -40,17 +40,41 @@ struct ScanParams {
     uint32_t* unit_count;
 };
 
+// internal ("fused") form of an expression program, produced from the public postfix words at
+// gft_set_programs time: a right operand that is a plain UNIT folds into the operator, so left-deep chains
+// (the common shape: the parser is precedence-free and left-associative) never touch the operand stack.
+//   word = op << 28 | operand
+enum FusedOp : uint32_t {
+    kFopLoad = 1,     // push acc; acc = P[slot]
+    kFopAndS = 2,     // acc &= P[slot]
+    kFopOrS = 3,      // acc |= P[slot]
+    kFopAndNS = 4,    // acc &= ~P[slot]
+    kFopOrNS = 5,     // acc |= ~P[slot]
+    kFopAndPop = 6,   // acc = pop & acc
+    kFopOrPop = 7,    // acc = pop | acc
+    kFopNot = 8,      // acc = ~acc
+    kFopInord = 9     // acc = documents of acc whose INORD group `operand` has a non-empty position list
+};
+constexpr uint32_t kSolveTileWords = 64;         // bitmap words (x32 expressions) evaluated per LDS output tile
+
 struct SolveParams {
-    const uint64_t* match_off;
-    const uint32_t* term_id;
+    // matches: document d owns units [doc_unit_base[d], doc_unit_base[d+1]); unit u owns pool entries
+    // [unit_start[u], unit_start[u] + unit_count[u])
+    const uint64_t* doc_unit_base;
+    const uint64_t* unit_start;
+    const uint32_t* unit_count;
+    const uint32_t* term;
     const uint32_t* pos;
-    const uint64_t* x_off;       // extra (regex) matches, nullable
+    const uint64_t* x_off;       // caller-supplied matches (absolute slots), nullable
     const uint32_t* x_slot;
     const uint32_t* x_pos;
     uint64_t n_docs;
-    const uint32_t* prog;
-    const uint64_t* prog_off;
-    uint32_t n_exprs, n_terms, present_words;
+    const uint32_t* fprog;       // fused programs
+    const uint64_t* fprog_off;
+    const uint32_t* gprog;       // public postfix words (INORD group subtrees are interpreted from these)
+    const uint32_t* groups;      // [n_groups][2] = offset, length into gprog
+    uint32_t n_exprs, n_slots, tile_words;
+    uint64_t* p_scratch;         // presence matrix in HBM when it does not fit LDS: [grid][n_slots]
     uint32_t* bitmap;
 };
 
@@ -68,7 +92,7 @@ hipError_t launch_gather(const uint64_t* d_unit_start, const uint32_t* d_unit_co
                          uint64_t n_units, const uint32_t* d_pool_term, const uint32_t* d_pool_pos, uint32_t* d_term,
                          uint32_t* d_pos, const uint64_t* d_unit_base, uint64_t n_docs, uint64_t* d_match_off,
                          unsigned n_cus, hipStream_t st);
-size_t solve_lds_bytes(uint32_t present_words);
-hipError_t launch_solve(const SolveParams& P, unsigned n_cus, hipStream_t st);
+size_t solve_lds_bytes(uint32_t n_slots, uint32_t tile_words, bool p_in_lds);
+hipError_t launch_solve(const SolveParams& S, bool p_in_lds, unsigned grid, hipStream_t st);
 
 }  // namespace gft

@@ -1,0 +1,277 @@
+// gft_solve.hip -- the solver half of ProcessText on gfx950: addMatchesToSolverMap + solveExpressions
+// (finder/finder.go:181-215) and Expression.solve (dsl/expression.go:66-142) as ONE data-parallel kernel.
+//
+// Bit-sliced evaluation over groups of 64 documents.  One workgroup owns a group:
+//   1. presence matrix P[slot] = 64-bit mask "which of my 64 documents contain this slot", built in LDS from the
+//      scan kernel's match slabs with ds_or (UNIT truth == key presence, dsl/expression.go:68-72);
+//   2. every lane interprets ONE expression over 64-bit masks, so each AND/OR/NOT evaluates 64 documents at once
+//      (the reference evaluates every node, no short-circuit, so this is the same function, expression.go:74-127);
+//   3. INORD(...) groups: the boolean value of the group's subtree gives the candidate documents; only for those
+//      the position algebra runs, per document, on (slot, theta) pairs with successor queries;
+//   4. the 64 x 64 result tile of a wave is transposed with __ballot so that lane d holds the two bitmap words of
+//      document d, staged in LDS and written out as full rows.
+// No MFMA: boolean algebra on bit masks; LDS- and latency-bound.
+#include <hip/hip_runtime.h>
+
+#include "gft_kernels.hpp"
+
+namespace gft {
+
+namespace {
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+// ---- per-document view of the matches (slabs of the scan kernel + caller-supplied matches) -------------------
+struct DocHits {
+    const uint64_t* unit_start;
+    const uint32_t* unit_count;
+    const uint32_t* term;
+    const uint32_t* pos;
+    uint64_t u0, u1;            // units of this document
+    const uint32_t* xslot;
+    const uint32_t* xpos;
+    uint32_t nx;
+};
+
+// first position of `slot` that is > theta (theta == -1: any), or INT64_MAX.  A keyword and a regex with the same
+// literal share one map key (finder/finder.go:181-196): the caller maps both onto one slot, both lists are read.
+__device__ int64_t succ_query(const DocHits& M, uint32_t slot, int64_t theta) {
+    int64_t best = INT64_MAX;
+    for (uint64_t u = M.u0; u < M.u1; u++) {
+        const uint64_t s = M.unit_start[u];
+        const uint32_t n = M.unit_count[u];
+        for (uint32_t i = 0; i < n; i++)
+            if (M.term[s + i] == slot) {
+                const int64_t p = M.pos[s + i];
+                if (p > theta && p < best) best = p;
+            }
+    }
+    for (uint32_t i = 0; i < M.nx; i++)
+        if (M.xslot[i] == slot) {
+            const int64_t p = M.xpos[i];
+            if (p > theta && p < best) best = p;
+        }
+    return best;
+}
+
+struct Pair { uint32_t slot; int32_t theta; };
+
+// Position algebra of one INORD group for one document (dsl/expression.go:87-95,111-116,129-137).  `prog` is the
+// group's subtree in the public postfix form (UNIT/AND/OR words carrying GFT_K_INORD_FLAG).  Returns len(rpos) > 0.
+//   UNIT t    -> {(t, -1)}
+//   OR        -> union of the pair sets (only minimum and emptiness are ever observed, duplicates are harmless)
+//   AND(L, R) -> m = min over L of succ(t, theta); {} if m = +inf, else {(t, max(theta, m)) : (t, theta) in R}
+//                == rpos[getLowestIdxGTVal(rpos, lpos[0]):]   (expression.go:87-93,175-189)
+__device__ bool inord_group_nonempty(const uint32_t* __restrict__ prog, uint32_t len, const DocHits& M) {
+    Pair pairs[kMaxPairs];
+    uint16_t rbeg[kMaxPairDepth], rcnt[kMaxPairDepth];
+    uint32_t psp = 0;
+    for (uint32_t pc = 0; pc < len; pc++) {
+        const uint32_t w = prog[pc];
+        switch (w >> 28) {
+        case 1: {  // UNIT
+            const uint32_t b = psp ? rbeg[psp - 1] + rcnt[psp - 1] : 0;
+            pairs[b] = Pair{w & GFT_K_SLOT_MASK, -1};
+            rbeg[psp] = (uint16_t)b; rcnt[psp] = 1; psp++;
+            break;
+        }
+        case 2: {  // AND
+            const uint32_t lb = rbeg[psp - 2], lc = rcnt[psp - 2], rb = rbeg[psp - 1], rc = rcnt[psp - 1];
+            int64_t m = INT64_MAX;
+            for (uint32_t i = 0; i < lc; i++) {
+                const int64_t s = succ_query(M, pairs[lb + i].slot, pairs[lb + i].theta);
+                if (s < m) m = s;
+            }
+            uint32_t nc = 0;
+            if (m != INT64_MAX)
+                for (uint32_t i = 0; i < rc; i++) {
+                    Pair q = pairs[rb + i];
+                    if ((int64_t)q.theta < m) q.theta = (int32_t)m;
+                    pairs[lb + nc++] = q;
+                }
+            psp--;
+            rcnt[psp - 1] = (uint16_t)nc;
+            break;
+        }
+        case 3:  // OR: the two ranges are adjacent, union == concatenation
+            psp--;
+            rcnt[psp - 1] = (uint16_t)(rcnt[psp - 1] + rcnt[psp]);
+            break;
+        default:
+            break;
+        }
+    }
+    if (!psp) return false;
+    const uint32_t b = rbeg[psp - 1], c = rcnt[psp - 1];
+    for (uint32_t i = 0; i < c; i++)
+        if (succ_query(M, pairs[b + i].slot, pairs[b + i].theta) != INT64_MAX) return true;
+    return false;
+}
+
+template <bool P_LDS>
+__global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const SolveParams S) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    constexpr uint32_t kWaves = kSolveBlockThreads / 64;
+    const uint32_t tile_words = S.tile_words;                   // bitmap words covered by one pass (<= kSolveTileWords)
+    const uint32_t bm_words = (S.n_exprs + 31) / 32;
+    uint64_t* P = P_LDS ? reinterpret_cast<uint64_t*>(smem) : S.p_scratch + (size_t)blockIdx.x * S.n_slots;
+    uint32_t* O = reinterpret_cast<uint32_t*>(smem + (P_LDS ? (size_t)S.n_slots * 8 : 0));   // [64][tile_words]
+    uint32_t* Pw = reinterpret_cast<uint32_t*>(P);
+
+    for (uint32_t i = threadIdx.x; i < S.n_slots; i += kSolveBlockThreads) {
+        if (P_LDS) P[i] = 0;
+        else __hip_atomic_store(&P[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+
+    const uint64_t n_groups = (S.n_docs + 63) / 64;
+    for (uint64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        const uint64_t d0 = g * 64;
+        const uint32_t nd = (uint32_t)(S.n_docs - d0 < 64 ? S.n_docs - d0 : 64);
+
+        // ---- 1. presence matrix ------------------------------------------------------------------------------
+        for (uint32_t j = wave; j < nd; j += kWaves) {
+            const uint64_t d = d0 + j;
+            const uint32_t bit = 1u << (j & 31), half = j >> 5;
+            const uint64_t u0 = S.doc_unit_base[d], u1 = S.doc_unit_base[d + 1];
+            for (uint64_t u = u0; u < u1; u++) {
+                const uint64_t s = S.unit_start[u];
+                const uint32_t n = S.unit_count[u];
+                for (uint32_t i = lane; i < n; i += 64) {
+                    const uint32_t t = S.term[s + i];
+                    if (P_LDS) __hip_atomic_fetch_or(&Pw[t * 2 + half], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else atomicOr(&Pw[(size_t)t * 2 + half], bit);
+                }
+            }
+            if (S.x_off) {
+                const uint64_t x0 = S.x_off[d], x1 = S.x_off[d + 1];
+                for (uint64_t i = x0 + lane; i < x1; i += 64) {
+                    const uint32_t t = S.x_slot[i];
+                    if (P_LDS) __hip_atomic_fetch_or(&Pw[t * 2 + half], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else atomicOr(&Pw[(size_t)t * 2 + half], bit);
+                }
+            }
+        }
+        if (!P_LDS) __threadfence_block();
+        __syncthreads();
+
+        // ---- 2. expressions, 64 per wave round, tile by tile over the bitmap words -----------------------------------
+        for (uint32_t w0 = 0; w0 < bm_words; w0 += tile_words) {
+            const uint32_t tw = bm_words - w0 < tile_words ? bm_words - w0 : tile_words;
+            const uint32_t rounds = (tw + 1) / 2;
+            for (uint32_t r = wave; r < rounds; r += kWaves) {
+                const uint32_t e = (w0 << 5) + r * 64 + lane;
+                uint64_t acc = 0;
+                if (e < S.n_exprs) {
+                    uint64_t stk[kMaxBoolDepth];
+                    uint32_t sp = 0;
+                    const uint64_t po = S.fprog_off[e];
+                    const uint32_t len = (uint32_t)(S.fprog_off[e + 1] - po);
+                    const uint32_t* prog = S.fprog + po;
+                    for (uint32_t pc = 0; pc < len; pc++) {
+                        const uint32_t w = prog[pc];
+                        const uint32_t a = w & 0x0FFFFFFFu;
+                        // HBM-resident P was written with L2 atomics by other waves: read it past this CU's L1
+                        auto ld = [&](uint32_t slot) -> uint64_t {
+                            return P_LDS ? P[slot]
+                                         : __hip_atomic_load(&P[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        };
+                        switch (w >> 28) {
+                        case kFopLoad: stk[sp++] = acc; acc = ld(a); break;
+                        case kFopAndS: acc &= ld(a); break;
+                        case kFopOrS: acc |= ld(a); break;
+                        case kFopAndNS: acc &= ~ld(a); break;
+                        case kFopOrNS: acc |= ~ld(a); break;
+                        case kFopAndPop: acc &= stk[--sp]; break;
+                        case kFopOrPop: acc |= stk[--sp]; break;
+                        case kFopNot: acc = ~acc; break;
+                        case kFopInord: {
+                            // candidates: documents where the group's boolean value is true (rval, expression.go:137)
+                            uint64_t m = acc & (nd == 64 ? ~0ull : ((1ull << nd) - 1)), res = 0;
+                            const uint32_t goff = S.groups[a * 2], glen = S.groups[a * 2 + 1];
+                            while (m) {
+                                const uint32_t j = (uint32_t)__builtin_ctzll(m);
+                                m &= m - 1;
+                                const uint64_t d = d0 + j;
+                                DocHits M;
+                                M.unit_start = S.unit_start; M.unit_count = S.unit_count;
+                                M.term = S.term; M.pos = S.pos;
+                                M.u0 = S.doc_unit_base[d]; M.u1 = S.doc_unit_base[d + 1];
+                                M.nx = 0; M.xslot = nullptr; M.xpos = nullptr;
+                                if (S.x_off) {
+                                    const uint64_t x0 = S.x_off[d];
+                                    M.xslot = S.x_slot + x0; M.xpos = S.x_pos + x0; M.nx = (uint32_t)(S.x_off[d + 1] - x0);
+                                }
+                                if (inord_group_nonempty(S.gprog + goff, glen, M)) res |= 1ull << j;
+                            }
+                            acc = res;
+                            break;
+                        }
+                        default: break;
+                        }
+                    }
+                }
+                // transpose: lane j ends up with the two bitmap words of document j for these 64 expressions
+                uint64_t mine = 0;
+#pragma unroll 8
+                for (uint32_t j = 0; j < 64; j++) {
+                    const uint64_t b = __ballot((acc >> j) & 1);
+                    if (lane == j) mine = b;
+                }
+                O[lane * tile_words + r * 2] = (uint32_t)mine;
+                if (r * 2 + 1 < tw) O[lane * tile_words + r * 2 + 1] = (uint32_t)(mine >> 32);
+            }
+            __syncthreads();
+            // rows of the tile -> global bitmap
+            for (uint32_t i = threadIdx.x; i < nd * tw; i += kSolveBlockThreads) {
+                const uint32_t j = i / tw, c = i - j * tw;
+                S.bitmap[(d0 + j) * bm_words + w0 + c] = O[j * tile_words + c];
+            }
+            __syncthreads();
+        }
+
+        // ---- 3. clear the touched entries of P for the next group ---------------------------------------------------
+        for (uint32_t j = wave; j < nd; j += kWaves) {
+            const uint64_t d = d0 + j;
+            const uint64_t u0 = S.doc_unit_base[d], u1 = S.doc_unit_base[d + 1];
+            for (uint64_t u = u0; u < u1; u++) {
+                const uint64_t s = S.unit_start[u];
+                const uint32_t n = S.unit_count[u];
+                for (uint32_t i = lane; i < n; i += 64) {
+                    if (P_LDS) P[S.term[s + i]] = 0;
+                    else __hip_atomic_store(&P[S.term[s + i]], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (S.x_off) {
+                const uint64_t x0 = S.x_off[d], x1 = S.x_off[d + 1];
+                for (uint64_t i = x0 + lane; i < x1; i += 64) {
+                    if (P_LDS) P[S.x_slot[i]] = 0;
+                    else __hip_atomic_store(&P[S.x_slot[i]], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        if (!P_LDS) __threadfence_block();
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+size_t solve_lds_bytes(uint32_t n_slots, uint32_t tile_words, bool p_in_lds) {
+    return (p_in_lds ? (size_t)n_slots * 8 : 0) + (size_t)64 * tile_words * 4;
+}
+
+hipError_t launch_solve(const SolveParams& S, bool p_in_lds, unsigned grid, hipStream_t st) {
+    if (!S.n_docs || !S.n_exprs) return hipSuccess;
+    const size_t lds = solve_lds_bytes(S.n_slots, S.tile_words, p_in_lds);
+    const void* fn = p_in_lds ? reinterpret_cast<const void*>(k_solve_groups<true>)
+                              : reinterpret_cast<const void*>(k_solve_groups<false>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    if (p_in_lds) k_solve_groups<true><<<dim3(grid), dim3(kSolveBlockThreads), lds, st>>>(S);
+    else k_solve_groups<false><<<dim3(grid), dim3(kSolveBlockThreads), lds, st>>>(S);
+    return hipGetLastError();
+}
+
+}  // namespace gft

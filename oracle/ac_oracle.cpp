@@ -436,3 +436,27 @@ uint64_t orc_scan_count_batch(void* h, const uint8_t* blob, const uint64_t* doc_
 }
 
 }  // extern "C"
+
+// ---- analysis helper (design studies; not used by tests' parity checks) -----------------------------------------
+// histogram of automaton depth after each input byte, and of emitted matches by term length
+extern "C" void orc_depth_hist(void* h, const uint8_t* blob, const uint64_t* doc_off, uint64_t n_docs,
+                               uint64_t* depth_hist /*[64]*/, uint64_t* emit_len_hist /*[64]*/) {
+    Oracle& o = *(Oracle*)h;
+    const Node* T = o.trie.data();
+    for (uint64_t d = 0; d < n_docs; d++) {
+        const uint8_t* in = blob + doc_off[d];
+        size_t n = (size_t)(doc_off[d + 1] - doc_off[d]);
+        int32_t cur = 0;
+        for (size_t i = 0; i < n; i++) {
+            int c = in[i];
+            if (cur != 0 && T[cur].child[c] < 0) cur = T[cur].fails[c];
+            int32_t f = T[cur].child[c];
+            if (f >= 0) {
+                cur = f;
+                if (T[f].output) emit_len_hist[std::min(T[f].depth, 63)]++;
+                while (T[f].suffix != 0) { f = T[f].suffix; emit_len_hist[std::min(T[f].depth, 63)]++; }
+            }
+            depth_hist[std::min(T[cur].depth, 63)]++;
+        }
+    }
+}

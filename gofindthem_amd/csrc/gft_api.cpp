@@ -12,8 +12,11 @@
 #include <string>
 #include <vector>
 
+#include <cstdlib>
+
 #include "ac_tables.hpp"
 #include "gft_kernels.hpp"
+#include "scan2_tables.hpp"
 
 using namespace gft;
 
@@ -54,6 +57,10 @@ struct gft_engine {
     uint32_t build_flags = 0;
     uint32_t n_lds_states = 0;
     DevBuf d_byte_class, d_delta, d_out_term, d_out_link, d_term_len;
+    // suffix-window scan (gft_scan2.hip); the two-tier DFA kernel above stays as the general fallback
+    Scan2Tables s2;
+    bool use_scan2 = false;
+    DevBuf d_s2_filter, d_s2_slots, d_s2_more, d_s2_cls, d_s2_cls_fold, d_s2_term_blob, d_s2_term_off, d_nmatches;
 
     // programs
     bool have_programs = false;
@@ -245,7 +252,7 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         return GFT_OK;
     }
     const uint32_t warm = e->tab.max_term_len ? e->tab.max_term_len - 1 : 0;
-    const uint32_t unit_max = kTextBuf - warm;
+    const uint32_t unit_max = e->use_scan2 ? kScan2UnitMax : kTextBuf - warm;
 
     // 1. work units
     HIP_TRY(e->d_unit_cnt.ensure(n_docs * 4), "unit alloc");
@@ -279,7 +286,41 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
     int rc = ensure_pool(e, std::max<uint64_t>(1u << 20, (text_hi - text_lo) / 16));
     if (rc) return rc;
     uint64_t total = 0;
-    for (int attempt = 0; attempt < 3; attempt++) {
+    for (int attempt = 0; attempt < 3 && e->use_scan2; attempt++) {
+        HIP_TRY(hipMemsetAsync(e->d_cursor.p, 0, 8, st), "memset");
+        HIP_TRY(hipMemsetAsync(e->d_nmatches.p, 0, 8, st), "memset");
+        Scan2Params P;
+        P.text = d_text; P.doc_off = d_doc_off; P.units = e->d_units.as<Unit>(); P.n_units = n_units;
+        P.filter = e->d_s2_filter.as<uint32_t>(); P.filter_words = (uint32_t)e->s2.filter.size();
+        P.hashed = e->s2.hashed ? 1 : 0; P.hash_shift = e->s2.hash_shift;
+        P.slots = e->d_s2_slots.as<Scan2Slot>(); P.slot_shift = e->s2.slot_shift;
+        P.slot_mask = (uint32_t)e->s2.slots.size() - 1; P.more = e->d_s2_more.as<Scan2Entry>();
+        P.fold = (flags & GFT_FOLD_ASCII) ? 1 : 0;
+        P.cls = P.fold ? e->d_s2_cls_fold.as<uint8_t>() : e->d_s2_cls.as<uint8_t>();
+        P.term_blob = e->d_s2_term_blob.as<uint8_t>(); P.term_off = e->d_s2_term_off.as<uint32_t>();
+        P.kp = e->s2.kp; P.pad_class = e->s2.pad_class;
+        P.pos_end = (e->build_flags & GFT_POS_END) ? 1 : 0;
+        P.cursor = e->d_cursor.as<uint64_t>(); P.pool_cap = e->pool_cap;
+        P.pool_term = e->d_pool_term.as<uint32_t>(); P.pool_pos = e->d_pool_pos.as<uint32_t>();
+        P.unit_start = e->d_unit_start.as<uint64_t>(); P.unit_count = e->d_unit_count.as<uint32_t>();
+        P.n_matches = e->d_nmatches.as<uint64_t>();
+        // slab slack is at most one slab per resident wave: keep it below half the pool
+        const uint64_t n_waves = (uint64_t)e->n_cus * (kScan2Threads / 64);
+        P.slab = (uint32_t)std::min<uint64_t>(kScan2Slab, std::max<uint64_t>(64, e->pool_cap / (2 * n_waves)));
+        {
+            ProfScope ps(e, "scan");
+            HIP_TRY(launch_scan2(P, e->n_cus, st), "scan kernel launch");
+        }
+        uint64_t cursor = 0;
+        HIP_TRY(hipMemcpyAsync(&cursor, e->d_cursor.p, 8, hipMemcpyDeviceToHost, st), "readback");
+        HIP_TRY(hipMemcpyAsync(&total, e->d_nmatches.p, 8, hipMemcpyDeviceToHost, st), "readback");
+        HIP_TRY(hipStreamSynchronize(st), "scan kernel");
+        if (cursor <= e->pool_cap) break;
+        if (attempt == 2) return fail(e, GFT_E_HIP, "match pool overflow persisted");
+        rc = ensure_pool(e, cursor + cursor / 16);
+        if (rc) return rc;
+    }
+    for (int attempt = 0; attempt < 3 && !e->use_scan2; attempt++) {
         HIP_TRY(hipMemsetAsync(e->d_cursor.p, 0, 8, st), "memset");
         ScanParams P;
         P.text = d_text; P.doc_off = d_doc_off; P.units = e->d_units.as<Unit>(); P.n_units = n_units;
@@ -399,7 +440,9 @@ void gft_engine_destroy(gft_engine* e) {
         for (auto& kv : e->prof)
             for (auto& p : kv.second.ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
         DevBuf* all[] = {&e->d_byte_class, &e->d_delta, &e->d_out_term, &e->d_out_link, &e->d_term_len, &e->d_prog,
-                         &e->d_prog_off, &e->d_fprog, &e->d_fprog_off, &e->d_groups, &e->d_pscratch,
+                         &e->d_prog_off, &e->d_fprog, &e->d_fprog_off, &e->d_groups, &e->d_pscratch, &e->d_s2_filter,
+                         &e->d_s2_slots, &e->d_s2_more, &e->d_s2_cls, &e->d_s2_cls_fold, &e->d_s2_term_blob,
+                         &e->d_s2_term_off, &e->d_nmatches,
 &e->d_unit_cnt, &e->d_unit_base, &e->d_units, &e->d_partial, &e->d_cursor,
                          &e->d_pool_term, &e->d_pool_pos, &e->d_unit_start, &e->d_unit_count, &e->d_unit_out,
                          &e->d_term, &e->d_pos, &e->d_match_off, &e->d_text, &e->d_doc_off, &e->d_bitmap, &e->d_xoff,
@@ -456,6 +499,22 @@ int gft_build(gft_engine* e, const uint8_t* terms_blob, const uint64_t* term_off
     if ((rc = upload(e, e->d_out_term, e->tab.out_term, "table upload"))) return rc;
     if ((rc = upload(e, e->d_out_link, e->tab.out_link, "table upload"))) return rc;
     if ((rc = upload(e, e->d_term_len, e->tab.term_len, "table upload"))) return rc;
+    // suffix-window tables (the fast path); GFT_SCAN_KERNEL=dfa forces the general two-tier DFA kernel
+    build_scan2_tables(e->tab, e->s2);
+    const char* force = getenv("GFT_SCAN_KERNEL");
+    e->use_scan2 = e->s2.supported && !(force && std::string(force) == "dfa") &&
+                   scan2_lds_bytes((uint32_t)e->s2.filter.size()) + 1024 <= e->lds_max;
+    if (e->use_scan2) {
+        std::vector<uint8_t> c1(e->s2.cls, e->s2.cls + 256), c2(e->s2.cls_fold, e->s2.cls_fold + 256);
+        if ((rc = upload(e, e->d_s2_cls, c1, "table upload"))) return rc;
+        if ((rc = upload(e, e->d_s2_cls_fold, c2, "table upload"))) return rc;
+        if ((rc = upload(e, e->d_s2_filter, e->s2.filter, "table upload"))) return rc;
+        if ((rc = upload(e, e->d_s2_slots, e->s2.slots, "table upload"))) return rc;
+        if ((rc = upload(e, e->d_s2_more, e->s2.more, "table upload"))) return rc;
+        if ((rc = upload(e, e->d_s2_term_blob, e->s2.term_blob, "table upload"))) return rc;
+        if ((rc = upload(e, e->d_s2_term_off, e->s2.term_off, "table upload"))) return rc;
+    }
+    HIP_TRY(e->d_nmatches.ensure(8), "table upload");
     HIP_TRY(hipStreamSynchronize(e->stream), "table upload");
     e->built = true;
     e->have_programs = false;   // slots refer to the dictionary: programs must be set again

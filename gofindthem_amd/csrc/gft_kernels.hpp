@@ -78,6 +78,55 @@ struct SolveParams {
     uint32_t* bitmap;
 };
 
+// ---- suffix-window scan (gft_scan2.hip; tables built by scan2_tables.cpp) ---------------------------------------
+constexpr uint32_t kScan2Threads = 1024;         // 16 waves per workgroup share one LDS copy of the filter
+constexpr uint32_t kScan2StageCap = 6;           // matches a lane can stage in LDS before the direct-write path
+constexpr uint32_t kScan2Slab = 4096;            // pool entries a wave reserves per global atomic
+constexpr uint32_t kScan2UnitMax = 8192;         // bytes per work unit (128 per lane)
+constexpr uint32_t kGoldDev = 0x9E3779B1u;
+
+// one term of a bucket
+struct Scan2Entry {
+    uint32_t term_id;
+    uint32_t len;
+    uint32_t cmp_val;    // the (up to) 4 bytes in front of the window, as a little-endian load of text[p-7..p-4]
+    uint32_t cmp_mask;   // 0xFF per byte that exists (len >= 8: 0xFFFFFFFF; len <= 4: 0)
+};
+// hash-table slot, 32 bytes: key, bucket size, index of entries[1..] in `more`, first entry inline
+struct Scan2Slot {
+    uint32_t key;
+    uint32_t count;      // 0 == empty slot
+    uint32_t more;       // entries 1..count-1 live at more_entries[more ...]
+    uint32_t pad;
+    Scan2Entry first;
+};
+
+struct Scan2Params {
+    const uint8_t* text;
+    const uint64_t* doc_off;
+    const Unit* units;
+    uint64_t n_units;
+    const uint32_t* filter;
+    uint32_t filter_words, hashed, hash_shift;
+    const Scan2Slot* slots;
+    uint32_t slot_shift, slot_mask;
+    const Scan2Entry* more;
+    const uint8_t* cls;          // [256] byte -> class (the folded table when GFT_FOLD_ASCII)
+    const uint8_t* term_blob;
+    const uint32_t* term_off;
+    uint32_t kp, pad_class, fold, pos_end;
+    uint64_t* cursor;            // pool allocation cursor (entries, slab granular)
+    uint64_t pool_cap;
+    uint32_t* pool_term;
+    uint32_t* pool_pos;
+    uint64_t* unit_start;
+    uint32_t* unit_count;
+    uint64_t* n_matches;         // exact number of matches (the cursor includes slab slack)
+    uint32_t slab;               // pool entries a wave reserves per global atomic (<= kScan2Slab)
+};
+size_t scan2_lds_bytes(uint32_t filter_words);
+hipError_t launch_scan2(const Scan2Params& P, unsigned n_cus, hipStream_t st);
+
 hipError_t launch_unit_count(const uint64_t* d_doc_off, uint64_t n_docs, uint32_t unit_max, uint32_t* d_cnt,
                              hipStream_t st);
 hipError_t launch_unit_fill(const uint64_t* d_doc_off, uint64_t n_docs, const uint64_t* d_unit_base, Unit* d_units,

@@ -1,0 +1,286 @@
+// gft_scan2.hip -- the Aho-Corasick scan for gfx950, "suffix-window" form (tables: scan2_tables.hpp).
+// Replaces (*Matcher).MatchAll behind CloudflareForkEngine.FindSubstrings (finder/substringEngine.go:110-119).
+//
+// One wavefront per work unit (a document, or a slice of a long one); lane k owns C consecutive bytes.
+//   phase 1  FILTER  every lane streams its bytes from HBM with 16-byte loads, maps them to byte classes through a
+//            256-byte LDS table and probes the LDS-resident 4-window filter once per byte.  Neighbouring bytes are
+//            independent (the depth-4 automaton is 4-local), so there is no dependent lookup chain; the per-byte flag
+//            is shifted into a lane-private bit mask with v_alignbit.
+//   phase 2  VERIFY  only flagged positions (a few % of the text) touch the L2-resident bucket table: one 32-byte
+//            slot holds the window's longest term inline; terms longer than the window are confirmed by a masked
+//            dword compare of the 4 bytes in front of it (and a byte loop past 8).  Matches come out per lane in text
+//            order, longest first, i.e. in the reference's emission order.
+//   output   matches are staged per lane in LDS, a wave prefix sum (shuffles) gives every lane its offset, the wave
+//            takes its room from a private slab (one global atomic per ~4 K matches) and writes the unit's matches
+//            contiguously.  Nothing is ever truncated: the host re-runs with a larger pool if the cursor overran.
+// HBM traffic: text once + 8 B per match; tables are LDS / L2 resident.  No MFMA (byte automaton, not a contraction).
+#include <hip/hip_runtime.h>
+
+#include "gft_kernels.hpp"
+
+namespace gft {
+
+namespace {
+
+struct __attribute__((packed, aligned(1))) U32u { uint32_t v; };
+struct __attribute__((packed, aligned(1))) U128u { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+__device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p) { return reinterpret_cast<const U32u*>(p)->v; }
+
+// ASCII lower-casing of four packed bytes (finder/finder.go:140-142 for ASCII text)
+__device__ __forceinline__ uint32_t fold4(uint32_t w) {
+    const uint32_t h = w & 0x7F7F7F7Fu;
+    const uint32_t ge_a = h + 0x3F3F3F3Fu;          // bit 7 set where byte >= 'A'
+    const uint32_t gt_z = h + 0x25252525u;          // bit 7 set where byte >  'Z'
+    const uint32_t up = ge_a & ~gt_z & ~w & 0x80808080u;
+    return w | (up >> 2);
+}
+__device__ __forceinline__ uint32_t fold1(uint32_t b) { return (b - 'A' < 26u) ? b + 32 : b; }
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    const uint32_t l = lane_id();
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        uint32_t o = __shfl_up(v, s, 64);
+        if ((int)l >= s) v += o;
+    }
+    return v;
+}
+
+struct Ctx {
+    const Scan2Params& P;
+    const uint8_t* cls;        // LDS
+    const uint32_t* filt;      // LDS
+    const uint8_t* dbase;      // first byte of the document
+    uint64_t doc_abs;          // offset of the document inside the text blob
+};
+
+// class of document position q (may be negative: before the document start)
+__device__ __forceinline__ uint32_t class_at(const Ctx& c, int64_t q) {
+    return q >= 0 ? c.cls[c.dbase[q]] : c.P.pad_class;
+}
+
+// All terms that end at document position p, longest first.  MODE 0: count and stage in LDS; MODE 1: write to the pool.
+template <int MODE>
+__device__ __forceinline__ void verify(const Ctx& c, uint32_t p, uint32_t& cnt, uint2* stage, uint64_t out_base) {
+    const Scan2Params& P = c.P;
+    const uint32_t kp = P.kp;
+    uint32_t x;
+    if (p >= 3) {
+        const uint32_t w = load_u32_unaligned(c.dbase + p - 3);
+        x = ((c.cls[w & 0xFF] * kp + c.cls[(w >> 8) & 0xFF]) * kp + c.cls[(w >> 16) & 0xFF]) * kp + c.cls[w >> 24];
+    } else {
+        x = ((class_at(c, (int64_t)p - 3) * kp + class_at(c, (int64_t)p - 2)) * kp + class_at(c, (int64_t)p - 1)) * kp +
+            c.cls[c.dbase[p]];
+    }
+    // the 4 bytes in front of the window, speculatively (independent of the table walk)
+    const bool wide = c.doc_abs + p >= 7;
+    uint32_t tw = 0;
+    if (wide) {
+        tw = load_u32_unaligned(c.dbase + (int64_t)p - 7);
+        if (P.fold) tw = fold4(tw);
+    }
+    uint32_t h = (x * kGoldDev) >> P.slot_shift;
+    uint4 head;
+    for (;;) {
+        head = *reinterpret_cast<const uint4*>(&P.slots[h]);
+        if (head.y == 0) return;          // empty slot: a hashed-filter false positive
+        if (head.x == x) break;
+        h = (h + 1) & P.slot_mask;
+    }
+    uint4 e = *reinterpret_cast<const uint4*>(&P.slots[h].first);
+    for (uint32_t j = 0;;) {
+        const uint32_t L = e.y;
+        bool ok = L <= p + 1;
+        if (ok && L > 4) {
+            if (wide) {
+                ok = ((tw ^ e.z) & e.w) == 0;
+            } else {                       // within 7 bytes of the blob start: byte by byte
+                for (uint32_t k = 0; k < 4 && ok; k++)
+                    if ((e.w >> (8 * k)) & 0xFF) {
+                        uint32_t b = c.dbase[(int64_t)p - 7 + k];
+                        if (P.fold) b = fold1(b);
+                        ok = b == ((e.z >> (8 * k)) & 0xFF);
+                    }
+            }
+            if (ok && L > 8) {
+                const uint8_t* tb = P.term_blob + P.term_off[e.x];
+                const uint8_t* tp = c.dbase + p + 1 - L;
+                for (uint32_t i = 0; i + 8 < L && ok; i++) {
+                    uint32_t b = tp[i];
+                    if (P.fold) b = fold1(b);
+                    ok = b == tb[i];
+                }
+            }
+        }
+        if (ok) {
+            const uint32_t pos = P.pos_end ? p : p + 1 - L;
+            if (MODE == 0) {
+                if (cnt < kScan2StageCap) stage[cnt * 64] = make_uint2(e.x, pos);
+            } else {
+                P.pool_term[out_base + cnt] = e.x;
+                P.pool_pos[out_base + cnt] = pos;
+            }
+            cnt++;
+        }
+        if (++j >= head.y) break;
+        e = *reinterpret_cast<const uint4*>(&P.more[head.z + j - 1]);
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ void verify_masks(const Ctx& c, uint32_t my_lo, uint32_t m0, uint32_t m1, uint32_t m2,
+                                             uint32_t m3, uint32_t& cnt, uint2* stage, uint64_t out_base) {
+    uint32_t m[4] = {m0, m1, m2, m3};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t mk = m[k];
+        while (__any(mk != 0)) {
+            if (mk) {
+                const uint32_t i = __builtin_ctz(mk);
+                mk &= mk - 1;
+                verify<MODE>(c, my_lo + 32 * k + i, cnt, stage, out_base);
+            }
+        }
+    }
+}
+
+template <bool HASHED>
+__global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
+    extern __shared__ __align__(16) uint8_t smem[];
+    uint8_t* cls = smem;
+    uint32_t* filt = reinterpret_cast<uint32_t*>(smem + 256);
+    uint2* stage_all = reinterpret_cast<uint2*>(smem + 256 + (size_t)P.filter_words * 4);
+
+    for (uint32_t i = threadIdx.x; i < 256; i += kScan2Threads) cls[i] = P.cls[i];
+    for (uint32_t i = threadIdx.x; i < P.filter_words; i += kScan2Threads) filt[i] = P.filter[i];
+    __syncthreads();
+
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    constexpr uint32_t kWaves = kScan2Threads / 64;
+    uint2* stage = stage_all + (size_t)wave * 64 * kScan2StageCap + lane;   // entry k of this lane: stage[k * 64]
+    const uint32_t kp = P.kp, kp2 = kp * kp, kp3 = kp2 * kp;
+
+    uint64_t slab_next = 0, wave_matches = 0;   // wave-uniform
+    uint32_t slab_left = 0;
+
+    for (uint64_t u = (uint64_t)blockIdx.x * kWaves + wave; u < P.n_units; u += (uint64_t)gridDim.x * kWaves) {
+        const Unit un = P.units[u];
+        const uint64_t doc_abs = P.doc_off[un.doc];
+        const Ctx c{P, cls, filt, P.text + doc_abs, doc_abs};
+        const uint32_t own = un.hi - un.lo;
+        const uint32_t C = ((own + 63) / 64 + 3) & ~3u;            // bytes per lane (multiple of 4, <= 128)
+        const uint32_t my_lo = un.lo + lane * C;
+        const uint32_t my_hi = my_lo + C < un.hi ? my_lo + C : un.hi;
+        const uint32_t nvalid = my_lo < un.hi ? my_hi - my_lo : 0;
+
+        // ---- phase 1: filter ------------------------------------------------------------------------------
+        uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+        if (own) {
+            uint32_t a1 = 0, a2 = 0, a3 = 0;
+            if (nvalid) {
+                a1 = class_at(c, (int64_t)my_lo - 1) * kp;
+                a2 = class_at(c, (int64_t)my_lo - 2) * kp2;
+                a3 = class_at(c, (int64_t)my_lo - 3) * kp3;
+            }
+            uint32_t acc = 0;
+            const uint32_t npieces = (C + 15) >> 4;
+            const uint8_t* src = c.dbase + my_lo;
+            for (uint32_t q = 0; q < npieces; q++) {
+                uint32_t w[4] = {0, 0, 0, 0};
+                if (q * 16 < nvalid) {
+                    const U128u v = *reinterpret_cast<const U128u*>(src + q * 16);
+                    w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+                }
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        const uint32_t cl = cls[(w[d] >> (8 * b)) & 0xFF];
+                        const uint32_t x = a3 + a2 + a1 + cl;
+                        a3 = __umul24(a2, kp); a2 = __umul24(a1, kp); a1 = __umul24(cl, kp);
+                        const uint32_t fi = HASHED ? (x * kGoldDev) >> P.hash_shift : x;
+                        const uint32_t fw = filt[fi >> 5];
+                        acc = __builtin_amdgcn_alignbit(fw >> (fi & 31), acc, 1);
+                    }
+                }
+                if (q & 1) {
+                    if ((q >> 1) == 0) m0 = acc; else if ((q >> 1) == 1) m1 = acc; else if ((q >> 1) == 2) m2 = acc; else m3 = acc;
+                }
+            }
+            if (npieces & 1) {
+                const uint32_t v = acc >> 16;
+                const uint32_t k = npieces >> 1;
+                if (k == 0) m0 = v; else if (k == 1) m1 = v; else if (k == 2) m2 = v; else m3 = v;
+            }
+            // positions past the lane's range carry garbage flags
+            m0 = nvalid >= 32 ? m0 : (nvalid ? m0 & ((1u << nvalid) - 1) : 0);
+            m1 = nvalid >= 64 ? m1 : (nvalid > 32 ? m1 & ((1u << (nvalid - 32)) - 1) : 0);
+            m2 = nvalid >= 96 ? m2 : (nvalid > 64 ? m2 & ((1u << (nvalid - 64)) - 1) : 0);
+            m3 = nvalid >= 128 ? m3 : (nvalid > 96 ? m3 & ((1u << (nvalid - 96)) - 1) : 0);
+        }
+
+        // ---- phase 2: verify flagged positions, stage matches in LDS ----------------------------------------
+        uint32_t cnt = 0;
+        verify_masks<0>(c, my_lo, m0, m1, m2, m3, cnt, stage, 0);
+
+        // ---- output -------------------------------------------------------------------------------------------------
+        const uint32_t incl = wave_incl_scan(cnt);
+        const uint32_t total = __shfl(incl, 63, 64);
+        if (total > slab_left) {          // wave-uniform: take a new slab
+            const uint32_t want = total > P.slab ? total : P.slab;
+            uint64_t nb = 0;
+            if (lane == 0) nb = atomicAdd(reinterpret_cast<unsigned long long*>(P.cursor), (unsigned long long)want);
+            slab_next = __shfl(nb, 0, 64);
+            slab_left = want;
+        }
+        const uint64_t base = slab_next;
+        slab_next += total;
+        slab_left -= total;
+        wave_matches += total;
+        if (lane == 0) { P.unit_start[u] = base; P.unit_count[u] = total; }
+        if (total && base + total <= P.pool_cap) {
+            const uint64_t mine = base + incl - cnt;
+            if (cnt <= kScan2StageCap) {
+#pragma unroll
+                for (uint32_t k = 0; k < kScan2StageCap; k++)
+                    if (k < cnt) {
+                        const uint2 r = stage[k * 64];
+                        P.pool_term[mine + k] = r.x;
+                        P.pool_pos[mine + k] = r.y;
+                    }
+            }
+            // lanes whose matches did not fit the staging area run the verification again, writing directly
+            const bool over = cnt > kScan2StageCap;
+            if (__any(over)) {
+                uint32_t c2 = 0;
+                verify_masks<1>(c, my_lo, over ? m0 : 0, over ? m1 : 0, over ? m2 : 0, over ? m3 : 0, c2, stage, mine);
+            }
+        }
+    }
+    if (lane == 0 && wave_matches)
+        atomicAdd(reinterpret_cast<unsigned long long*>(P.n_matches), (unsigned long long)wave_matches);
+}
+
+}  // namespace
+
+size_t scan2_lds_bytes(uint32_t filter_words) {
+    return 256 + (size_t)filter_words * 4 + (size_t)kScan2Threads * kScan2StageCap * sizeof(uint2);
+}
+
+hipError_t launch_scan2(const Scan2Params& P, unsigned n_cus, hipStream_t st) {
+    if (!P.n_units) return hipSuccess;
+    const size_t lds = scan2_lds_bytes(P.filter_words);
+    const void* fn = P.hashed ? reinterpret_cast<const void*>(k_scan2<true>) : reinterpret_cast<const void*>(k_scan2<false>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    const unsigned wpb = kScan2Threads / 64;
+    uint64_t g = (P.n_units + wpb - 1) / wpb;
+    const unsigned grid = (unsigned)(g < n_cus ? (g ? g : 1) : n_cus);
+    if (P.hashed) k_scan2<true><<<dim3(grid), dim3(kScan2Threads), lds, st>>>(P);
+    else k_scan2<false><<<dim3(grid), dim3(kScan2Threads), lds, st>>>(P);
+    return hipGetLastError();
+}
+
+}  // namespace gft

@@ -1,0 +1,49 @@
+// Host-side compiler for the "suffix-window" scan kernel (gft_scan2.hip).
+//
+// The Aho-Corasick automaton truncated at depth 4 is a 4-local machine: which dictionary terms can END at text
+// position p is a function of the last four byte classes only.  That function is tabulated:
+//   * filter   one bit per 4-class window (direct-indexed, or hashed when the alphabet is large): "some term may end
+//              here".  It lives in LDS and is probed once per text byte with no dependent chain between bytes.
+//   * buckets  window -> the terms that end with exactly that window (terms shorter than 4 are entered under every
+//              window they are a suffix of), longest first == the reference's emission order (node, then its
+//              dictionary-suffix chain).  A term longer than 4 is confirmed by comparing the bytes in front of the
+//              window; every match is therefore found from its own END position and no failure links are needed.
+// Same inputs as NewStringMatcher (finder/substringEngine.go:103); same outputs as MatchAll (:111-116).
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "ac_tables.hpp"
+#include "gft_kernels.hpp"
+
+namespace gft {
+
+constexpr uint32_t kWin = 4;                        // window length in bytes
+constexpr uint32_t kFilterDirectMaxBits = 1u << 19 | 1u << 18;   // 768 Kbit = 96 KB of LDS for a direct-indexed filter
+constexpr uint32_t kFilterHashedBits = 1u << 19;    // 64 KB when hashed
+constexpr uint64_t kMaxWindowKeys = 1u << 21;       // budget for the expansion of terms shorter than the window
+
+struct Scan2Tables {
+    bool supported = false;
+    const char* why_not = "";
+    uint32_t kp = 0;                 // K' = n_classes + 1 (the extra class is PAD = "before the document start")
+    uint32_t pad_class = 0;
+    bool hashed = false;
+    uint32_t filter_bits = 0;        // number of bits in the filter
+    uint32_t hash_shift = 0;         // hashed: index = (key * kGold) >> hash_shift
+    std::vector<uint32_t> filter;    // filter_bits / 32 words
+    uint32_t slot_shift = 0;         // slot index = (key * kGold) >> slot_shift, linear probing
+    std::vector<Scan2Slot> slots;    // power-of-two table
+    std::vector<Scan2Entry> more;    // overflow entries of multi-term buckets
+    uint8_t cls[256];                // byte -> class
+    uint8_t cls_fold[256];           // byte -> class of its ASCII lower-case form
+    std::vector<uint8_t> term_blob;  // raw term bytes (for terms longer than 8)
+    std::vector<uint32_t> term_off;  // n_terms + 1
+    uint64_t n_keys = 0;
+};
+
+constexpr uint32_t kGold = kGoldDev;
+
+void build_scan2_tables(const AcTables& ac, Scan2Tables& out);
+
+}  // namespace gft

@@ -60,7 +60,7 @@ struct gft_engine {
     // suffix-window scan (gft_scan2.hip); the two-tier DFA kernel above stays as the general fallback
     Scan2Tables s2;
     bool use_scan2 = false;
-    DevBuf d_s2_filter, d_s2_slots, d_s2_more, d_s2_cls, d_s2_cls_fold, d_s2_term_blob, d_s2_term_off, d_nmatches;
+    DevBuf d_s2_filter, d_s2_slots, d_s2_more, d_s2_cls, d_s2_cls_fold, d_s2_term_blob, d_s2_term_off, d_nmatches, d_dbg;
 
     // programs
     bool have_programs = false;
@@ -307,6 +307,15 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         // slab slack is at most one slab per resident wave: keep it below half the pool
         const uint64_t n_waves = (uint64_t)e->n_cus * (kScan2Threads / 64);
         P.slab = (uint32_t)std::min<uint64_t>(kScan2Slab, std::max<uint64_t>(64, e->pool_cap / (2 * n_waves)));
+        P.ordered = need_csr ? 1 : 0;   // the solver reads presence / successor positions: any order will do
+        const char* dbg = getenv("GFT_SCAN_DEBUG");
+        P.dbg = dbg ? (uint32_t)atoi(dbg) : 0;
+        P.dbg_counters = nullptr;
+        if (P.dbg & 2) {
+            HIP_TRY(e->d_dbg.ensure(32), "debug alloc");
+            HIP_TRY(hipMemsetAsync(e->d_dbg.p, 0, 32, st), "memset");
+            P.dbg_counters = e->d_dbg.as<uint64_t>();
+        }
         {
             ProfScope ps(e, "scan");
             HIP_TRY(launch_scan2(P, e->n_cus, st), "scan kernel launch");
@@ -315,6 +324,13 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         HIP_TRY(hipMemcpyAsync(&cursor, e->d_cursor.p, 8, hipMemcpyDeviceToHost, st), "readback");
         HIP_TRY(hipMemcpyAsync(&total, e->d_nmatches.p, 8, hipMemcpyDeviceToHost, st), "readback");
         HIP_TRY(hipStreamSynchronize(st), "scan kernel");
+        if (P.dbg & 2) {
+            uint64_t c4[4] = {0, 0, 0, 0};
+            HIP_TRY(hipMemcpy(c4, e->d_dbg.p, 32, hipMemcpyDeviceToHost), "debug readback");
+            fprintf(stderr, "[gft scan debug] units=%llu flagged=%llu sum_of_per_unit_max_lane=%llu matches=%llu\n",
+                    (unsigned long long)n_units, (unsigned long long)c4[0], (unsigned long long)c4[1],
+                    (unsigned long long)total);
+        }
         if (cursor <= e->pool_cap) break;
         if (attempt == 2) return fail(e, GFT_E_HIP, "match pool overflow persisted");
         rc = ensure_pool(e, cursor + cursor / 16);

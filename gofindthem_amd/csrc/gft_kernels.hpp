@@ -81,6 +81,9 @@ struct SolveParams {
 // ---- suffix-window scan (gft_scan2.hip; tables built by scan2_tables.cpp) ---------------------------------------
 constexpr uint32_t kScan2Threads = 1024;         // 16 waves per workgroup share one LDS copy of the filter
 constexpr uint32_t kScan2StageCap = 6;           // matches a lane can stage in LDS before the direct-write path
+constexpr uint32_t kScan2FifoCap = 320;          // unordered path: matches of one unit buffered in LDS (>= 64 * kScan2StageCap)
+constexpr uint32_t kScan2CandCap = 760;          // unordered path: flagged positions of one unit listed in LDS
+constexpr uint32_t kScan2WaveLds = kScan2FifoCap * 8 + kScan2CandCap * 2 + 16;   // 4096 bytes per wave
 constexpr uint32_t kScan2Slab = 4096;            // pool entries a wave reserves per global atomic
 constexpr uint32_t kScan2UnitMax = 8192;         // bytes per work unit (128 per lane)
 constexpr uint32_t kGoldDev = 0x9E3779B1u;
@@ -92,13 +95,16 @@ struct Scan2Entry {
     uint32_t cmp_val;    // the (up to) 4 bytes in front of the window, as a little-endian load of text[p-7..p-4]
     uint32_t cmp_mask;   // 0xFF per byte that exists (len >= 8: 0xFFFFFFFF; len <= 4: 0)
 };
-// hash-table slot, 32 bytes: key, bucket size, index of entries[1..] in `more`, first entry inline
+// hash-table slot, 16 bytes.  A bucket holding ONE entry (len <= 255, term id < 2^23) is fully described by the
+// slot (info = kScan2Simple | len << 23 | term_id, cmp_* = that entry's); otherwise info indexes `more`, where a
+// header {count} is followed by the bucket's entries, longest first.
+constexpr uint32_t kScan2EmptyKey = 0xFFFFFFFFu;   // never a window: the newest class of a window is never PAD
+constexpr uint32_t kScan2Simple = 0x80000000u;
 struct Scan2Slot {
     uint32_t key;
-    uint32_t count;      // 0 == empty slot
-    uint32_t more;       // entries 1..count-1 live at more_entries[more ...]
-    uint32_t pad;
-    Scan2Entry first;
+    uint32_t cmp_val;
+    uint32_t cmp_mask;
+    uint32_t info;
 };
 
 struct Scan2Params {
@@ -123,6 +129,9 @@ struct Scan2Params {
     uint32_t* unit_count;
     uint64_t* n_matches;         // exact number of matches (the cursor includes slab slack)
     uint32_t slab;               // pool entries a wave reserves per global atomic (<= kScan2Slab)
+    uint32_t ordered;            // 1: matches of a unit in text order (CSR results); 0: any order (solver input)
+    uint32_t dbg;                // GFT_SCAN_DEBUG bits (timing studies only): 1 = skip verification, 2 = count flags
+    uint64_t* dbg_counters;      // [4] when dbg & 2: flagged positions, table probes, entries compared, -
 };
 size_t scan2_lds_bytes(uint32_t filter_words);
 hipError_t launch_scan2(const Scan2Params& P, unsigned n_cus, hipStream_t st);

@@ -24,6 +24,7 @@ namespace {
 
 struct __attribute__((packed, aligned(1))) U32u { uint32_t v; };
 struct __attribute__((packed, aligned(1))) U128u { uint32_t x, y, z, w; };
+struct __attribute__((packed, aligned(1))) U64u { uint32_t lo, hi; };
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p) { return reinterpret_cast<const U32u*>(p)->v; }
@@ -63,33 +64,49 @@ __device__ __forceinline__ uint32_t class_at(const Ctx& c, int64_t q) {
 
 // All terms that end at document position p, longest first.  MODE 0: count and stage in LDS; MODE 1: write to the pool.
 template <int MODE>
-__device__ __forceinline__ void verify(const Ctx& c, uint32_t p, uint32_t& cnt, uint2* stage, uint64_t out_base) {
+__device__ __forceinline__ void verify(const Ctx& c, uint32_t p, uint32_t& cnt, uint2* stage, uint64_t out_base,
+                                       uint32_t* fcnt) {
     const Scan2Params& P = c.P;
     const uint32_t kp = P.kp;
-    uint32_t x;
-    if (p >= 3) {
-        const uint32_t w = load_u32_unaligned(c.dbase + p - 3);
-        x = ((c.cls[w & 0xFF] * kp + c.cls[(w >> 8) & 0xFF]) * kp + c.cls[(w >> 16) & 0xFF]) * kp + c.cls[w >> 24];
+    // one 8-byte load brings the window (bytes p-3..p) and the 4 bytes in front of it (p-7..p-4)
+    const bool wide = c.doc_abs + p >= 7;
+    uint32_t x, tw = 0;
+    if (P.dbg & 8) {            // timing study: no text reload (wrong results)
+        x = p * 2654435761u % (kp * kp * kp * kp);
+    } else if (wide) {
+        const U64u v = *reinterpret_cast<const U64u*>(c.dbase + (int64_t)p - 7);
+        tw = P.fold ? fold4(v.lo) : v.lo;
+        const uint32_t w = v.hi;
+        const uint32_t c0 = p >= 3 ? c.cls[w & 0xFF] : P.pad_class, c1 = p >= 2 ? c.cls[(w >> 8) & 0xFF] : P.pad_class,
+                       c2 = p >= 1 ? c.cls[(w >> 16) & 0xFF] : P.pad_class;
+        x = ((c0 * kp + c1) * kp + c2) * kp + c.cls[w >> 24];
     } else {
         x = ((class_at(c, (int64_t)p - 3) * kp + class_at(c, (int64_t)p - 2)) * kp + class_at(c, (int64_t)p - 1)) * kp +
             c.cls[c.dbase[p]];
     }
-    // the 4 bytes in front of the window, speculatively (independent of the table walk)
-    const bool wide = c.doc_abs + p >= 7;
-    uint32_t tw = 0;
-    if (wide) {
-        tw = load_u32_unaligned(c.dbase + (int64_t)p - 7);
-        if (P.fold) tw = fold4(tw);
-    }
     uint32_t h = (x * kGoldDev) >> P.slot_shift;
-    uint4 head;
+    uint4 slot;
+    if (P.dbg & 4) {            // timing study: no table access (wrong results)
+        if (x == 0x12345678u && tw == 0x9abcdef0u) cnt++;
+        return;
+    }
     for (;;) {
-        head = *reinterpret_cast<const uint4*>(&P.slots[h]);
-        if (head.y == 0) return;          // empty slot: a hashed-filter false positive
-        if (head.x == x) break;
+        slot = *reinterpret_cast<const uint4*>(&P.slots[h]);
+        if (slot.x == x) break;
+        if (slot.x == kScan2EmptyKey) return;   // a hashed-filter false positive
         h = (h + 1) & P.slot_mask;
     }
-    uint4 e = *reinterpret_cast<const uint4*>(&P.slots[h].first);
+    // bucket entries as {term_id, len, cmp_val, cmp_mask}; the common one-entry bucket is the slot itself
+    const bool simple = (slot.w & kScan2Simple) != 0;
+    uint32_t n_ent = 1, more_at = 0;
+    uint4 e;
+    if (simple) {
+        e = make_uint4(slot.w & 0x7FFFFFu, (slot.w >> 23) & 0xFFu, slot.y, slot.z);
+    } else {
+        more_at = slot.w;
+        n_ent = P.more[more_at].term_id;
+        e = *reinterpret_cast<const uint4*>(&P.more[more_at + 1]);
+    }
     for (uint32_t j = 0;;) {
         const uint32_t L = e.y;
         bool ok = L <= p + 1;
@@ -118,14 +135,17 @@ __device__ __forceinline__ void verify(const Ctx& c, uint32_t p, uint32_t& cnt, 
             const uint32_t pos = P.pos_end ? p : p + 1 - L;
             if (MODE == 0) {
                 if (cnt < kScan2StageCap) stage[cnt * 64] = make_uint2(e.x, pos);
+            } else if (MODE == 2) {        // unordered: append to the wave's LDS fifo (stage = fifo)
+                const uint32_t idx = __hip_atomic_fetch_add(fcnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (idx < kScan2FifoCap) stage[idx] = make_uint2(e.x, pos);
             } else {
                 P.pool_term[out_base + cnt] = e.x;
                 P.pool_pos[out_base + cnt] = pos;
             }
             cnt++;
         }
-        if (++j >= head.y) break;
-        e = *reinterpret_cast<const uint4*>(&P.more[head.z + j - 1]);
+        if (++j >= n_ent) break;
+        e = *reinterpret_cast<const uint4*>(&P.more[more_at + 1 + j]);
     }
 }
 
@@ -140,7 +160,7 @@ __device__ __forceinline__ void verify_masks(const Ctx& c, uint32_t my_lo, uint3
             if (mk) {
                 const uint32_t i = __builtin_ctz(mk);
                 mk &= mk - 1;
-                verify<MODE>(c, my_lo + 32 * k + i, cnt, stage, out_base);
+                verify<MODE>(c, my_lo + 32 * k + i, cnt, stage, out_base, nullptr);
             }
         }
     }
@@ -151,7 +171,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
     extern __shared__ __align__(16) uint8_t smem[];
     uint8_t* cls = smem;
     uint32_t* filt = reinterpret_cast<uint32_t*>(smem + 256);
-    uint2* stage_all = reinterpret_cast<uint2*>(smem + 256 + (size_t)P.filter_words * 4);
+    uint8_t* wave_lds_all = smem + 256 + (size_t)P.filter_words * 4;
 
     for (uint32_t i = threadIdx.x; i < 256; i += kScan2Threads) cls[i] = P.cls[i];
     for (uint32_t i = threadIdx.x; i < P.filter_words; i += kScan2Threads) filt[i] = P.filter[i];
@@ -159,7 +179,12 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
 
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     constexpr uint32_t kWaves = kScan2Threads / 64;
-    uint2* stage = stage_all + (size_t)wave * 64 * kScan2StageCap + lane;   // entry k of this lane: stage[k * 64]
+    // per-wave LDS region: [fifo / ordered staging: kScan2FifoCap x 8 B][candidate list: kScan2CandCap x 2 B][counter]
+    uint8_t* wave_lds = wave_lds_all + (size_t)wave * kScan2WaveLds;
+    uint2* fifo = reinterpret_cast<uint2*>(wave_lds);
+    uint2* stage = fifo + lane;                                   // ordered path: entry k of this lane is stage[k * 64]
+    uint16_t* cand = reinterpret_cast<uint16_t*>(wave_lds + kScan2FifoCap * 8);
+    uint32_t* fcnt = reinterpret_cast<uint32_t*>(wave_lds + kScan2FifoCap * 8 + kScan2CandCap * 2);
     const uint32_t kp = P.kp, kp2 = kp * kp, kp3 = kp2 * kp;
 
     uint64_t slab_next = 0, wave_matches = 0;   // wave-uniform
@@ -223,6 +248,77 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
 
         // ---- phase 2: verify flagged positions, stage matches in LDS ----------------------------------------
         uint32_t cnt = 0;
+        if (P.dbg) {   // timing studies (GFT_SCAN_DEBUG): never set in production
+            if (P.dbg & 2) {
+                uint32_t f = __popc(m0) + __popc(m1) + __popc(m2) + __popc(m3);
+                uint32_t mx = f;
+                for (int s = 32; s; s >>= 1) { f += __shfl_xor(f, s, 64); uint32_t o = __shfl_xor(mx, s, 64); mx = o > mx ? o : mx; }
+                if (lane == 0) {
+                    atomicAdd(reinterpret_cast<unsigned long long*>(P.dbg_counters), (unsigned long long)f);
+                    atomicAdd(reinterpret_cast<unsigned long long*>(P.dbg_counters + 1), (unsigned long long)mx);
+                }
+            }
+            if (P.dbg & 1) m0 = m1 = m2 = m3 = 0;
+        }
+        // ---- phase 2, unordered fast path (the solver does not need text order): balance the flagged positions over
+        // the lanes through an LDS candidate list, append matches to an LDS fifo, flush the fifo coalesced ----------------
+        if (!P.ordered) {
+            const uint32_t f = __popc(m0) + __popc(m1) + __popc(m2) + __popc(m3);
+            const uint32_t fincl = wave_incl_scan(f);
+            const uint32_t ftotal = __shfl(fincl, 63, 64);
+            bool done = ftotal == 0;
+            if (ftotal && ftotal <= kScan2CandCap) {
+                uint32_t wpos = fincl - f;
+                const uint32_t rel = lane * C;
+                uint32_t mm[4] = {m0, m1, m2, m3};
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    uint32_t mk = mm[k];
+                    while (mk) {
+                        const uint32_t i = __builtin_ctz(mk);
+                        mk &= mk - 1;
+                        cand[wpos++] = (uint16_t)(rel + 32 * k + i);
+                    }
+                }
+                if (lane == 0) *fcnt = 0;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                uint32_t dummy = 0;
+                for (uint32_t i = lane; i < ftotal; i += 64)
+                    verify<2>(c, un.lo + cand[i], dummy, fifo, 0, fcnt);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const uint32_t nh = *fcnt;
+                if (nh <= kScan2FifoCap) {
+                    if (nh > slab_left) {
+                        const uint32_t want = nh > P.slab ? nh : P.slab;
+                        uint64_t nb = 0;
+                        if (lane == 0) nb = atomicAdd(reinterpret_cast<unsigned long long*>(P.cursor), (unsigned long long)want);
+                        slab_next = __shfl(nb, 0, 64);
+                        slab_left = want;
+                    }
+                    const uint64_t base = slab_next;
+                    slab_next += nh;
+                    slab_left -= nh;
+                    wave_matches += nh;
+                    if (lane == 0) { P.unit_start[u] = base; P.unit_count[u] = nh; }
+                    if (base + nh <= P.pool_cap)
+                        for (uint32_t i = lane; i < nh; i += 64) {
+                            const uint2 r = fifo[i];
+                            P.pool_term[base + i] = r.x;
+                            P.pool_pos[base + i] = r.y;
+                        }
+                    done = true;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (ftotal == 0 && lane == 0) { P.unit_start[u] = slab_next; P.unit_count[u] = 0; }
+            if (done) continue;
+        }
+
+        // ---- phase 2, ordered path: every lane verifies its own positions in text order, stages matches in LDS ---------
         verify_masks<0>(c, my_lo, m0, m1, m2, m3, cnt, stage, 0);
 
         // ---- output -------------------------------------------------------------------------------------------------
@@ -266,7 +362,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
 }  // namespace
 
 size_t scan2_lds_bytes(uint32_t filter_words) {
-    return 256 + (size_t)filter_words * 4 + (size_t)kScan2Threads * kScan2StageCap * sizeof(uint2);
+    return 256 + (size_t)filter_words * 4 + (size_t)(kScan2Threads / 64) * kScan2WaveLds;
 }
 
 hipError_t launch_scan2(const Scan2Params& P, unsigned n_cus, hipStream_t st) {

@@ -64,11 +64,11 @@ void build_scan2_tables(const AcTables& ac, Scan2Tables& t) {
     if (t.hashed) { uint32_t lg = 0; while ((1u << lg) < t.filter_bits) lg++; t.hash_shift = 32 - lg; }
     t.filter.assign(t.filter_bits / 32, 0);
 
-    // slots
+    // slots: 16 bytes each; a bucket with one plain entry is answered by the slot alone
     uint32_t lg = 10;
     while ((1ull << lg) < 2 * t.n_keys) lg++;
     t.slot_shift = 32 - lg;
-    t.slots.assign((size_t)1 << lg, Scan2Slot{0, 0, 0, 0, {0, 0, 0, 0}});
+    t.slots.assign((size_t)1 << lg, Scan2Slot{kScan2EmptyKey, 0, 0, 0});
     const uint32_t smask = (1u << lg) - 1;
     for (auto& kv : buckets) {
         auto& v = kv.second;
@@ -77,13 +77,22 @@ void build_scan2_tables(const AcTables& ac, Scan2Tables& t) {
         const uint32_t fi = t.hashed ? (key * kGold) >> t.hash_shift : key;
         t.filter[fi >> 5] |= 1u << (fi & 31);
         uint32_t h = (key * kGold) >> t.slot_shift;
-        while (t.slots[h].count) h = (h + 1) & smask;
+        while (t.slots[h].key != kScan2EmptyKey) h = (h + 1) & smask;
         Scan2Slot& s = t.slots[h];
-        s.key = key; s.count = (uint32_t)v.size(); s.more = (uint32_t)t.more.size(); s.first = v[0];
-        for (size_t i = 1; i < v.size(); i++) t.more.push_back(v[i]);
+        s.key = key;
+        if (v.size() == 1 && v[0].len <= 255 && v[0].term_id < (1u << 23)) {
+            s.cmp_val = v[0].cmp_val; s.cmp_mask = v[0].cmp_mask;
+            s.info = kScan2Simple | v[0].len << 23 | v[0].term_id;
+        } else {
+            s.cmp_val = 0; s.cmp_mask = 0;
+            s.info = (uint32_t)t.more.size();                       // header {count} then the entries, longest first
+            t.more.push_back(Scan2Entry{(uint32_t)v.size(), 0, 0, 0});
+            t.more.insert(t.more.end(), v.begin(), v.end());
+        }
     }
     if (t.more.empty()) t.more.push_back(Scan2Entry{0, 0, 0, 0});
-    t.supported = true;
+    t.supported = t.more.size() < (1u << 31);
+    if (!t.supported) t.why_not = "bucket table too large";
 }
 
 }  // namespace gft

@@ -399,6 +399,7 @@ int solve_pipeline(gft_engine* e, uint64_t n_docs, const gft_extra_matches* d_ex
     S.tile_words = std::min<uint32_t>(kSolveTileWords, (e->n_exprs + 31) / 32);
     S.bitmap = d_bitmap;
     S.p_scratch = nullptr;
+    { const char* dbg = getenv("GFT_SOLVE_DEBUG"); S.dbg = dbg ? (uint32_t)atoi(dbg) : 0; }
     // presence matrix (8 B per slot) in LDS when it fits next to the output tile, else in HBM (served by L2)
     const bool p_in_lds = solve_lds_bytes(S.n_slots, S.tile_words, true) + 1024 <= e->lds_max;
     const uint64_t n_groups = (n_docs + 63) / 64;

@@ -7,7 +7,7 @@ namespace gft {
 
 constexpr uint32_t kScanBlockThreads = 512;      // 8 waves: one work unit per wave
 constexpr uint32_t kTextBuf = 8448;              // per-wave LDS text buffer (bytes)
-constexpr uint32_t kSolveBlockThreads = 256;
+constexpr uint32_t kSolveBlockThreads = 1024;    // 16 waves: 64 documents x 16-lane teams; one expression round per wave
 constexpr uint32_t kMaxPairs = 64;               // (slot, theta) pairs alive inside one INORD group
 constexpr uint32_t kMaxPairDepth = 32;           // operand-stack depth inside one INORD group
 constexpr uint32_t kMaxBoolDepth = 128;          // operand-stack depth of a whole program
@@ -74,6 +74,7 @@ struct SolveParams {
     const uint32_t* gprog;       // public postfix words (INORD group subtrees are interpreted from these)
     const uint32_t* groups;      // [n_groups][2] = offset, length into gprog
     uint32_t n_exprs, n_slots, tile_words;
+    uint32_t dbg;                // GFT_SOLVE_DEBUG bits (timing studies): 1 skip presence build, 2 skip evaluation, 4 skip transpose/output
     uint64_t* p_scratch;         // presence matrix in HBM when it does not fit LDS: [grid][n_slots]
     uint32_t* bitmap;
 };

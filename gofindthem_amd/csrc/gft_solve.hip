@@ -20,6 +20,7 @@ namespace gft {
 namespace {
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+constexpr uint32_t kTeam = 16;   // lanes that share one document while the presence matrix is built
 
 // ---- per-document view of the matches (slabs of the scan kernel + caller-supplied matches) -------------------
 struct DocHits {
@@ -116,7 +117,7 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
     const uint32_t tile_words = S.tile_words;                   // bitmap words covered by one pass (<= kSolveTileWords)
     const uint32_t bm_words = (S.n_exprs + 31) / 32;
     uint64_t* P = P_LDS ? reinterpret_cast<uint64_t*>(smem) : S.p_scratch + (size_t)blockIdx.x * S.n_slots;
-    uint32_t* O = reinterpret_cast<uint32_t*>(smem + (P_LDS ? (size_t)S.n_slots * 8 : 0));   // [64][tile_words]
+    uint32_t* O = reinterpret_cast<uint32_t*>(smem + (P_LDS ? (((size_t)S.n_slots * 8 + 15) & ~(size_t)15) : 0));   // [64][tile_words]
     uint32_t* Pw = reinterpret_cast<uint32_t*>(P);
 
     for (uint32_t i = threadIdx.x; i < S.n_slots; i += kSolveBlockThreads) {
@@ -131,14 +132,16 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
         const uint32_t nd = (uint32_t)(S.n_docs - d0 < 64 ? S.n_docs - d0 : 64);
 
         // ---- 1. presence matrix ------------------------------------------------------------------------------
-        for (uint32_t j = wave; j < nd; j += kWaves) {
+        // a team of kTeam lanes per document, all documents of the group at once (short dependent-load chains)
+        for (uint32_t j = threadIdx.x / kTeam; j < nd && !(S.dbg & 1); j += kSolveBlockThreads / kTeam) {
+            const uint32_t member = threadIdx.x % kTeam;
             const uint64_t d = d0 + j;
             const uint32_t bit = 1u << (j & 31), half = j >> 5;
             const uint64_t u0 = S.doc_unit_base[d], u1 = S.doc_unit_base[d + 1];
             for (uint64_t u = u0; u < u1; u++) {
                 const uint64_t s = S.unit_start[u];
                 const uint32_t n = S.unit_count[u];
-                for (uint32_t i = lane; i < n; i += 64) {
+                for (uint32_t i = member; i < n; i += kTeam) {
                     const uint32_t t = S.term[s + i];
                     if (P_LDS) __hip_atomic_fetch_or(&Pw[t * 2 + half], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     else atomicOr(&Pw[(size_t)t * 2 + half], bit);
@@ -146,7 +149,7 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
             }
             if (S.x_off) {
                 const uint64_t x0 = S.x_off[d], x1 = S.x_off[d + 1];
-                for (uint64_t i = x0 + lane; i < x1; i += 64) {
+                for (uint64_t i = x0 + member; i < x1; i += kTeam) {
                     const uint32_t t = S.x_slot[i];
                     if (P_LDS) __hip_atomic_fetch_or(&Pw[t * 2 + half], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     else atomicOr(&Pw[(size_t)t * 2 + half], bit);
@@ -163,7 +166,7 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
             for (uint32_t r = wave; r < rounds; r += kWaves) {
                 const uint32_t e = (w0 << 5) + r * 64 + lane;
                 uint64_t acc = 0;
-                if (e < S.n_exprs) {
+                if (e < S.n_exprs && !(S.dbg & 2)) {
                     uint64_t stk[kMaxBoolDepth];
                     uint32_t sp = 0;
                     const uint64_t po = S.fprog_off[e];
@@ -215,7 +218,7 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
                 // transpose: lane j ends up with the two bitmap words of document j for these 64 expressions
                 uint64_t mine = 0;
 #pragma unroll 8
-                for (uint32_t j = 0; j < 64; j++) {
+                for (uint32_t j = 0; j < 64 && !(S.dbg & 4); j++) {
                     const uint64_t b = __ballot((acc >> j) & 1);
                     if (lane == j) mine = b;
                 }
@@ -232,26 +235,29 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
         }
 
         // ---- 3. clear the touched entries of P for the next group ---------------------------------------------------
-        for (uint32_t j = wave; j < nd; j += kWaves) {
-            const uint64_t d = d0 + j;
-            const uint64_t u0 = S.doc_unit_base[d], u1 = S.doc_unit_base[d + 1];
-            for (uint64_t u = u0; u < u1; u++) {
-                const uint64_t s = S.unit_start[u];
-                const uint32_t n = S.unit_count[u];
-                for (uint32_t i = lane; i < n; i += 64) {
-                    if (P_LDS) P[S.term[s + i]] = 0;
-                    else __hip_atomic_store(&P[S.term[s + i]], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (P_LDS) {
+            // LDS: wiping the whole matrix is a handful of wide stores per lane, no HBM re-read of the matches
+            uint4* P4 = reinterpret_cast<uint4*>(P);
+            for (uint32_t i = threadIdx.x; i < (S.n_slots + 1) / 2; i += kSolveBlockThreads) P4[i] = make_uint4(0, 0, 0, 0);
+        } else {
+            for (uint32_t j = threadIdx.x / kTeam; j < nd; j += kSolveBlockThreads / kTeam) {
+                const uint32_t member = threadIdx.x % kTeam;
+                const uint64_t d = d0 + j;
+                const uint64_t u0 = S.doc_unit_base[d], u1 = S.doc_unit_base[d + 1];
+                for (uint64_t u = u0; u < u1; u++) {
+                    const uint64_t s = S.unit_start[u];
+                    const uint32_t n = S.unit_count[u];
+                    for (uint32_t i = member; i < n; i += kTeam)
+                        __hip_atomic_store(&P[S.term[s + i]], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (S.x_off) {
+                    const uint64_t x0 = S.x_off[d], x1 = S.x_off[d + 1];
+                    for (uint64_t i = x0 + member; i < x1; i += kTeam)
+                        __hip_atomic_store(&P[S.x_slot[i]], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
-            if (S.x_off) {
-                const uint64_t x0 = S.x_off[d], x1 = S.x_off[d + 1];
-                for (uint64_t i = x0 + lane; i < x1; i += 64) {
-                    if (P_LDS) P[S.x_slot[i]] = 0;
-                    else __hip_atomic_store(&P[S.x_slot[i]], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
+            __threadfence_block();
         }
-        if (!P_LDS) __threadfence_block();
         __syncthreads();
     }
 }
@@ -259,7 +265,7 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
 }  // namespace
 
 size_t solve_lds_bytes(uint32_t n_slots, uint32_t tile_words, bool p_in_lds) {
-    return (p_in_lds ? (size_t)n_slots * 8 : 0) + (size_t)64 * tile_words * 4;
+    return (p_in_lds ? (((size_t)n_slots * 8 + 15) & ~(size_t)15) : 0) + (size_t)64 * tile_words * 4;
 }
 
 hipError_t launch_solve(const SolveParams& S, bool p_in_lds, unsigned grid, hipStream_t st) {

@@ -78,19 +78,17 @@ def main():
     eh = finder.engine_handle()
     stream = torch.cuda.current_stream().cuda_stream
     assert L.gft_set_stream(eh, stream) == 0
-    first = rank * args.docs
+    from gofindthem_amd.sharding import BitmapGather, all_ranks_ok, max_over_ranks, shard_range
+    first, _ = shard_range(rank, world, args.docs)
     text, doc_off = wl.docs_device(first, args.docs, device=dev)
     words = (args.exprs + 31) // 32
     bitmap = torch.zeros((args.docs, words), dtype=torch.int32, device=dev)
-    gather_list = None
-    if world > 1 and rank == 0:
-        gather_list = [torch.empty_like(bitmap) for _ in range(world)]
+    gather = BitmapGather(bitmap)          # rank 0 receives every rank's bitmap: the path's only exchange step
     text_bytes = int(text.numel())
 
     def step():
         finder.ProcessDevice(text.data_ptr(), doc_off.data_ptr(), args.docs, bitmap.data_ptr())
-        if world > 1:
-            dist.gather(bitmap, gather_list, dst=0)
+        gather()
 
     def fence():
         if world > 1:
@@ -116,10 +114,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     L.gft_profile_enable(eh, 0)
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = max_over_ranks(elapsed, dev)
 
     def prof(name):
         ms, n = C.c_double(), C.c_uint64()
@@ -141,12 +136,9 @@ def main():
     want = orc.process(h_text, h_off, fold=True, n_threads=min(8, os.cpu_count() or 1))
     got = bitmap[:S].cpu().numpy().view(np.uint32)
     parity_ok = gen_ok and bool(np.array_equal(got, want))
-    if world > 1:
-        flag = torch.tensor([1 if parity_ok else 0], device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        parity_ok = bool(flag.item())
-        if rank == 0:   # the gathered copy of the last rank equals what that rank computed (checked via its sample)
-            parity_ok = parity_ok and bool(torch.equal(gather_list[0], bitmap))
+    parity_ok = all_ranks_ok(parity_ok, dev)
+    if world > 1 and rank == 0:   # rank 0's slice of the gathered result is what it computed itself
+        parity_ok = parity_ok and bool(torch.equal(gather.parts[0], bitmap))
 
     # ---- CPU baseline (rank 0, N == 1): the oracle = our restatement of the reference path, on this host ---------------
     cpu = None
@@ -176,6 +168,16 @@ def main():
         alg_bytes = text_bytes + 8 * args.docs + 8 * n_matches
         scan_avg_ms = scan_ms / max(scan_n, 1)
         achieved = alg_bytes / (scan_avg_ms * 1e-3) / 1e9 if scan_n else 0.0
+        # HBM traffic of the scan kernel from rocprofv3 PMC passes (profiles/r1_pmc_traffic.json; it cannot be
+        # collected from inside this process) -- only attached when this run uses the profiled configuration
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as fh:
+                pmc = json.load(fh)
+            if pmc["config"] == {"docs": args.docs, "terms": args.terms, "exprs": args.exprs, "inord": args.inord}:
+                traffic = pmc["kernels"]["k_scan2"]["traffic_bytes"]
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "ProcessText throughput: documents/s (and input GB/s), %d-term dictionary + %d expressions, "
                       "%d docs of ~4 KB per GPU" % (args.terms, args.exprs, args.docs),
@@ -191,8 +193,8 @@ def main():
                                       "AND/OR/NOT + %.0f%% INORD" % (args.inord * 100), args.docs),
                        "docs_per_gpu": args.docs, "text_bytes_per_gpu": text_bytes, "matches_per_gpu": n_matches,
                        "matches_per_doc": n_matches / args.docs, "parallelism": "docs sharded x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "k_scan_units", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": "k_scan2 (suffix-window scan)", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": traffic,
                          "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": scan_avg_ms, "launches": scan_n},
             "kernels_ms_per_step": {"scan": scan_ms / args.steps, "solve": solve_ms / args.steps,
                                     "aux(units+prefix sums+gather)": aux_ms / args.steps},

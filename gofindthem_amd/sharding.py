@@ -1,0 +1,68 @@
+"""Document sharding across ranks (one process per GPU) and the single exchange step of the path.
+
+ProcessText keeps no state between documents (finder/finder.go:139-179), so the corpus is cut into contiguous
+document ranges, one per rank; the compiled dictionary and expression programs are replicated.  The only exchange
+is the gather of every rank's expression-hit bitmap to rank 0 -- one collective per batch (RCCL over xGMI when the
+process group's backend is "nccl"; the same code runs over gloo in the CPU tests).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(rank, world, docs_per_rank):
+    """weak scaling: every rank owns `docs_per_rank` consecutive documents -> [first, first + n)"""
+    return rank * docs_per_rank, docs_per_rank
+
+
+def split_docs(n_docs, world):
+    """strong scaling helper: n_docs cut into `world` contiguous ranges of near-equal size -> list of (first, n)"""
+    base, rem = divmod(n_docs, world)
+    out, first = [], 0
+    for r in range(world):
+        n = base + (1 if r < rem else 0)
+        out.append((first, n))
+        first += n
+    return out
+
+
+class BitmapGather:
+    """rank 0 receives every rank's [docs, words] int32 bitmap; buffers are allocated once and reused per step"""
+
+    def __init__(self, local_bitmap, rows_per_rank=None):
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.local = local_bitmap
+        self.parts = None
+        if self.world > 1 and self.rank == 0:
+            rows = rows_per_rank or [local_bitmap.shape[0]] * self.world
+            self.parts = [torch.empty((r, local_bitmap.shape[1]), dtype=local_bitmap.dtype, device=local_bitmap.device)
+                          for r in rows]
+        if self.world > 1 and rows_per_rank is not None and len(set(rows_per_rank)) > 1:
+            raise ValueError("dist.gather needs equal shard sizes; pad the last shard or use split sizes that divide")
+
+    def __call__(self):
+        if self.world > 1:
+            dist.gather(self.local, self.parts, dst=0)
+        return self.parts if self.world > 1 else [self.local]
+
+    def full(self):
+        """rank 0: the bitmap of all documents in document order"""
+        parts = self.parts if self.world > 1 else [self.local]
+        return torch.cat(parts, 0) if self.rank == 0 else None
+
+
+def all_ranks_ok(flag, device):
+    """logical AND of a per-rank boolean"""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return bool(flag)
+    t = torch.tensor([1 if flag else 0], device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item())
+
+
+def max_over_ranks(value, device):
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

@@ -1,0 +1,89 @@
+"""N > 1: document sharding + the bitmap gather (gofindthem_amd/sharding.py), world_size 2.
+
+CPU leg (gloo): the exchange logic runs for real; per-rank bitmaps come from the CPU oracle (test infrastructure --
+the product has no CPU path).  GPU leg: two processes share the one card of the GPU box, each runs the HIP path on
+its own shard, rank 0 checks the gathered result against the oracle over the whole range.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+N_DOCS, N_TERMS, N_EXPRS = 96, 300, 70
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, use_gpu, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gofindthem_amd.sharding import BitmapGather, all_ranks_ok, max_over_ranks, shard_range
+    from gofindthem_amd.workload import Workload, make_expressions
+    from oracle.pyoracle import Oracle
+
+    wl = Workload(N_TERMS)
+    terms = wl.terms()
+    exprs = make_expressions(terms, N_EXPRS, inord_fraction=0.4, cover=True)
+    per = N_DOCS // world
+    first, n = shard_range(rank, world, per)
+    text, off = wl.docs_host(first, n)
+    if use_gpu:
+        from gofindthem_amd.finder import EmptyRgxEngine, Finder, GpuEngine
+        f = Finder(GpuEngine.__new__(GpuEngine), EmptyRgxEngine(), False, device=0)
+        f.AddExpressions(exprs)
+        local = torch.from_numpy(f.ProcessTexts(blob=text, doc_off=off).view(np.int32))
+    else:
+        o = Oracle(terms)
+        o.set_expressions(exprs, False)
+        local = torch.from_numpy(o.process(text, off, fold=True).view(np.int32))
+    g = BitmapGather(local)
+    g()
+    ok = all_ranks_ok(True, "cpu")
+    t = max_over_ranks(float(rank), "cpu")
+    if rank == 0:
+        full = g.full().numpy().view(np.uint32)
+        o = Oracle(terms)
+        o.set_expressions(exprs, False)
+        wtext, woff = wl.docs_host(0, per * world)
+        want = o.process(wtext, woff, fold=True)
+        np.save(out_path, np.array([int(np.array_equal(full, want)), int(ok), int(t == world - 1), full.shape[0]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(use_gpu, tmp_path):
+    out = str(tmp_path / "res.npy")
+    port = _free_port()
+    mp.start_processes(_worker, args=(2, port, use_gpu, out), nprocs=2, join=True, start_method="spawn")
+    res = np.load(out)
+    assert res.tolist() == [1, 1, 1, N_DOCS]
+
+
+def test_gather_two_ranks_gloo_cpu(tmp_path):
+    _run(False, tmp_path)
+
+
+@pytest.mark.gpu
+def test_gather_two_ranks_gpu_compute(tmp_path):
+    _run(True, tmp_path)
+
+
+def test_split_docs():
+    from gofindthem_amd.sharding import shard_range, split_docs
+    assert split_docs(10, 4) == [(0, 3), (3, 3), (6, 2), (8, 2)]
+    assert split_docs(0, 2) == [(0, 0), (0, 0)]
+    assert shard_range(3, 8, 1000) == (3000, 1000)

@@ -61,6 +61,8 @@ struct gft_engine {
     Scan2Tables s2;
     bool use_scan2 = false;
     DevBuf d_s2_filter, d_s2_slots, d_s2_more, d_s2_cls, d_s2_cls_fold, d_s2_term_blob, d_s2_term_off, d_nmatches, d_dbg;
+    DevBuf d_s2_short3, d_s2_shorts, d_s2_fpt;
+    uint32_t scan2_waves = 0, scan2_short3_bytes = 0;
 
     // programs
     bool have_programs = false;
@@ -293,6 +295,8 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         P.text = d_text; P.doc_off = d_doc_off; P.units = e->d_units.as<Unit>(); P.n_units = n_units;
         P.filter = e->d_s2_filter.as<uint32_t>(); P.filter_words = (uint32_t)e->s2.filter.size();
         P.hashed = e->s2.hashed ? 1 : 0; P.hash_shift = e->s2.hash_shift;
+        P.short3 = e->d_s2_short3.as<uint8_t>(); P.short3_bytes = e->scan2_short3_bytes;
+        P.shorts = e->d_s2_shorts.as<Scan2Short>(); P.fpt = e->d_s2_fpt.as<uint8_t>();
         P.slots = e->d_s2_slots.as<Scan2Slot>(); P.slot_shift = e->s2.slot_shift;
         P.slot_mask = (uint32_t)e->s2.slots.size() - 1; P.more = e->d_s2_more.as<Scan2Entry>();
         P.fold = (flags & GFT_FOLD_ASCII) ? 1 : 0;
@@ -305,7 +309,7 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         P.unit_start = e->d_unit_start.as<uint64_t>(); P.unit_count = e->d_unit_count.as<uint32_t>();
         P.n_matches = e->d_nmatches.as<uint64_t>();
         // slab slack is at most one slab per resident wave: keep it below half the pool
-        const uint64_t n_waves = (uint64_t)e->n_cus * (kScan2Threads / 64);
+        const uint64_t n_waves = (uint64_t)e->n_cus * e->scan2_waves;
         P.slab = (uint32_t)std::min<uint64_t>(kScan2Slab, std::max<uint64_t>(64, e->pool_cap / (2 * n_waves)));
         P.ordered = need_csr ? 1 : 0;   // the solver reads presence / successor positions: any order will do
         const char* dbg = getenv("GFT_SCAN_DEBUG");
@@ -318,7 +322,7 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         }
         {
             ProfScope ps(e, "scan");
-            HIP_TRY(launch_scan2(P, e->n_cus, st), "scan kernel launch");
+            HIP_TRY(launch_scan2(P, e->scan2_waves, e->n_cus, st), "scan kernel launch");
         }
         uint64_t cursor = 0;
         HIP_TRY(hipMemcpyAsync(&cursor, e->d_cursor.p, 8, hipMemcpyDeviceToHost, st), "readback");
@@ -459,7 +463,7 @@ void gft_engine_destroy(gft_engine* e) {
         DevBuf* all[] = {&e->d_byte_class, &e->d_delta, &e->d_out_term, &e->d_out_link, &e->d_term_len, &e->d_prog,
                          &e->d_prog_off, &e->d_fprog, &e->d_fprog_off, &e->d_groups, &e->d_pscratch, &e->d_s2_filter,
                          &e->d_s2_slots, &e->d_s2_more, &e->d_s2_cls, &e->d_s2_cls_fold, &e->d_s2_term_blob,
-                         &e->d_s2_term_off, &e->d_nmatches,
+                         &e->d_s2_term_off, &e->d_nmatches, &e->d_dbg, &e->d_s2_short3, &e->d_s2_shorts, &e->d_s2_fpt,
 &e->d_unit_cnt, &e->d_unit_base, &e->d_units, &e->d_partial, &e->d_cursor,
                          &e->d_pool_term, &e->d_pool_pos, &e->d_unit_start, &e->d_unit_count, &e->d_unit_out,
                          &e->d_term, &e->d_pos, &e->d_match_off, &e->d_text, &e->d_doc_off, &e->d_bitmap, &e->d_xoff,
@@ -519,9 +523,15 @@ int gft_build(gft_engine* e, const uint8_t* terms_blob, const uint64_t* term_off
     // suffix-window tables (the fast path); GFT_SCAN_KERNEL=dfa forces the general two-tier DFA kernel
     build_scan2_tables(e->tab, e->s2);
     const char* force = getenv("GFT_SCAN_KERNEL");
-    e->use_scan2 = e->s2.supported && !(force && std::string(force) == "dfa") &&
-                   scan2_lds_bytes((uint32_t)e->s2.filter.size()) + 1024 <= e->lds_max;
+    e->scan2_waves = e->s2.supported ? scan2_pick_waves((uint32_t)e->s2.filter.size(), (uint32_t)e->s2.short3.size(),
+                                                         e->lds_max - 512) : 0;
+    e->use_scan2 = e->s2.supported && !(force && std::string(force) == "dfa") && e->scan2_waves > 0;
     if (e->use_scan2) {
+        e->scan2_short3_bytes = (uint32_t)e->s2.short3.size();
+        if (e->s2.short3.empty()) e->s2.short3.assign(16, 0);   // placeholder upload; short3_bytes stays 0
+        if ((rc = upload(e, e->d_s2_short3, e->s2.short3, "table upload"))) return rc;
+        if ((rc = upload(e, e->d_s2_shorts, e->s2.shorts, "table upload"))) return rc;
+        if ((rc = upload(e, e->d_s2_fpt, e->s2.fpt, "table upload"))) return rc;
         std::vector<uint8_t> c1(e->s2.cls, e->s2.cls + 256), c2(e->s2.cls_fold, e->s2.cls_fold + 256);
         if ((rc = upload(e, e->d_s2_cls, c1, "table upload"))) return rc;
         if ((rc = upload(e, e->d_s2_cls_fold, c2, "table upload"))) return rc;

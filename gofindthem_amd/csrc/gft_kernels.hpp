@@ -82,9 +82,10 @@ struct SolveParams {
 // ---- suffix-window scan (gft_scan2.hip; tables built by scan2_tables.cpp) ---------------------------------------
 constexpr uint32_t kScan2Threads = 1024;         // 16 waves per workgroup share one LDS copy of the filter
 constexpr uint32_t kScan2StageCap = 6;           // matches a lane can stage in LDS before the direct-write path
-constexpr uint32_t kScan2FifoCap = 320;          // unordered path: matches of one unit buffered in LDS (>= 64 * kScan2StageCap)
-constexpr uint32_t kScan2CandCap = 760;          // unordered path: flagged positions of one unit listed in LDS
-constexpr uint32_t kScan2WaveLds = kScan2FifoCap * 8 + kScan2CandCap * 2 + 16;   // 4096 bytes per wave
+constexpr uint32_t kScan2FifoCap = 256;          // unordered path: matches of one unit buffered in LDS (>= 64 * kScan2StageCap)
+constexpr uint32_t kScan2CandCap = 856;          // unordered path: flagged positions of one unit listed in LDS
+constexpr uint32_t kScan2WaveLds = kScan2FifoCap * 8 + kScan2CandCap * 2 + 16;   // 3776 bytes per wave
+constexpr uint32_t kScan2Batch = 2;             // unordered path: flagged positions a lane verifies per trip
 constexpr uint32_t kScan2Slab = 4096;            // pool entries a wave reserves per global atomic
 constexpr uint32_t kScan2UnitMax = 8192;         // bytes per work unit (128 per lane)
 constexpr uint32_t kGoldDev = 0x9E3779B1u;
@@ -108,6 +109,23 @@ struct Scan2Slot {
     uint32_t info;
 };
 
+// short3 record: the (up to three) terms of length <= 3 that end at a 3-window, longest first
+struct Scan2Short {
+    uint32_t n;
+    uint32_t term[3];
+    uint32_t len[3];
+    uint32_t pad;
+};
+constexpr uint32_t kScan2Short3Max = 32768;      // bytes of LDS a direct 3-window table may take (K' <= 32)
+constexpr uint32_t kScan2FptSize = 16384;        // one byte per hashed window key
+constexpr uint32_t kScan2FptShift = 32 - 14;
+constexpr uint32_t kScan2FptAmbiguous = 0xFF;    // several terms share the byte: always go to the bucket table
+// fingerprint byte = (front_bytes + 1) << 5 | fp5(front bytes as loaded from text[p-7..p-4], masked); 0 = no term
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline uint32_t scan2_fp5(uint32_t masked_front) { return (masked_front * 0x85EBCA6Bu) >> 27; }
+
 struct Scan2Params {
     const uint8_t* text;
     const uint64_t* doc_off;
@@ -115,6 +133,10 @@ struct Scan2Params {
     uint64_t n_units;
     const uint32_t* filter;
     uint32_t filter_words, hashed, hash_shift;
+    const uint8_t* short3;       // [short3_bytes] record id per 3-window, copied to LDS (short3_bytes == 0: no short terms)
+    uint32_t short3_bytes;
+    const Scan2Short* shorts;    // tiny, L1 resident
+    const uint8_t* fpt;          // [kScan2FptSize], copied to LDS
     const Scan2Slot* slots;
     uint32_t slot_shift, slot_mask;
     const Scan2Entry* more;
@@ -134,8 +156,10 @@ struct Scan2Params {
     uint32_t dbg;                // GFT_SCAN_DEBUG bits (timing studies only): 1 = skip verification, 2 = count flags
     uint64_t* dbg_counters;      // [4] when dbg & 2: flagged positions, table probes, entries compared, -
 };
-size_t scan2_lds_bytes(uint32_t filter_words);
-hipError_t launch_scan2(const Scan2Params& P, unsigned n_cus, hipStream_t st);
+size_t scan2_lds_bytes(uint32_t filter_words, uint32_t short3_bytes, uint32_t waves);
+// picks the largest workgroup (16, 12, 8 or 4 waves) whose LDS footprint fits lds_max; 0 if none does
+uint32_t scan2_pick_waves(uint32_t filter_words, uint32_t short3_bytes, size_t lds_max);
+hipError_t launch_scan2(const Scan2Params& P, uint32_t waves, unsigned n_cus, hipStream_t st);
 
 hipError_t launch_unit_count(const uint64_t* d_doc_off, uint64_t n_docs, uint32_t unit_max, uint32_t* d_cnt,
                              hipStream_t st);

@@ -53,6 +53,8 @@ struct Ctx {
     const Scan2Params& P;
     const uint8_t* cls;        // LDS
     const uint32_t* filt;      // LDS
+    const uint8_t* short3;     // LDS (nullptr: the dictionary has no term shorter than the window)
+    const uint8_t* fpt;        // LDS
     const uint8_t* dbase;      // first byte of the document
     uint64_t doc_abs;          // offset of the document inside the text blob
 };
@@ -62,100 +64,166 @@ __device__ __forceinline__ uint32_t class_at(const Ctx& c, int64_t q) {
     return q >= 0 ? c.cls[c.dbase[q]] : c.P.pad_class;
 }
 
-// All terms that end at document position p, longest first.  MODE 0: count and stage in LDS; MODE 1: write to the pool.
-template <int MODE>
-__device__ __forceinline__ void verify(const Ctx& c, uint32_t p, uint32_t& cnt, uint2* stage, uint64_t out_base,
-                                       uint32_t* fcnt) {
+// ---- verification of one flagged position p, in three separable steps so that several candidates can have their
+// loads in flight together (the unordered path runs kScan2Batch candidates per lane at once) -------------------------
+
+// step 1: one 8-byte load brings the window (bytes p-3..p) and the 4 bytes in front of it (p-7..p-4)
+struct Cand { uint32_t p, x, tw, h, sid; bool wide, go_long; };
+__device__ __forceinline__ void cand_text(const Ctx& c, uint32_t p, Cand& k) {
     const Scan2Params& P = c.P;
     const uint32_t kp = P.kp;
-    // one 8-byte load brings the window (bytes p-3..p) and the 4 bytes in front of it (p-7..p-4)
-    const bool wide = c.doc_abs + p >= 7;
-    uint32_t x, tw = 0;
-    if (P.dbg & 8) {            // timing study: no text reload (wrong results)
-        x = p * 2654435761u % (kp * kp * kp * kp);
-    } else if (wide) {
+    k.p = p;
+    k.wide = c.doc_abs + p >= 7;
+    k.tw = 0;
+    uint32_t x3;
+    if (k.wide) {
         const U64u v = *reinterpret_cast<const U64u*>(c.dbase + (int64_t)p - 7);
-        tw = P.fold ? fold4(v.lo) : v.lo;
+        k.tw = P.fold ? fold4(v.lo) : v.lo;
         const uint32_t w = v.hi;
         const uint32_t c0 = p >= 3 ? c.cls[w & 0xFF] : P.pad_class, c1 = p >= 2 ? c.cls[(w >> 8) & 0xFF] : P.pad_class,
                        c2 = p >= 1 ? c.cls[(w >> 16) & 0xFF] : P.pad_class;
-        x = ((c0 * kp + c1) * kp + c2) * kp + c.cls[w >> 24];
+        x3 = (c1 * kp + c2) * kp + c.cls[w >> 24];
+        k.x = c0 * kp * kp * kp + x3;
+    } else {    // within 7 bytes of the blob start
+        x3 = (class_at(c, (int64_t)p - 2) * kp + class_at(c, (int64_t)p - 1)) * kp + c.cls[c.dbase[p]];
+        k.x = class_at(c, (int64_t)p - 3) * kp * kp * kp + x3;
+    }
+    k.h = (k.x * kGoldDev) >> P.slot_shift;
+    // LDS-only decisions: which short-term record ends here, and whether a term of length >= 4 can end here at all
+    // (fingerprint of the bytes in front of the window) -- most flagged positions stop here without touching L2
+    k.sid = c.short3 ? c.short3[x3] : 0;
+    const uint32_t f = c.fpt[(k.x * kGoldDev) >> kScan2FptShift];
+    if (f == 0) {
+        k.go_long = false;
+    } else if (f == kScan2FptAmbiguous || !k.wide) {
+        k.go_long = true;
     } else {
-        x = ((class_at(c, (int64_t)p - 3) * kp + class_at(c, (int64_t)p - 2)) * kp + class_at(c, (int64_t)p - 1)) * kp +
-            c.cls[c.dbase[p]];
+        const uint32_t nf = (f >> 5) - 1;
+        const uint32_t mask = nf ? 0xFFFFFFFFu << (8 * (4 - nf)) : 0u;
+        k.go_long = scan2_fp5(k.tw & mask) == (f & 31u);
     }
-    uint32_t h = (x * kGoldDev) >> P.slot_shift;
-    uint4 slot;
-    if (P.dbg & 4) {            // timing study: no table access (wrong results)
-        if (x == 0x12345678u && tw == 0x9abcdef0u) cnt++;
-        return;
+    if (P.dbg & 12) {           // timing studies (wrong results): 4 = no bucket-table access, 8 = no short-term records
+        if (P.dbg & 4) k.go_long = false;
+        if (P.dbg & 8) k.sid = 0;
     }
-    for (;;) {
-        slot = *reinterpret_cast<const uint4*>(&P.slots[h]);
-        if (slot.x == x) break;
-        if (slot.x == kScan2EmptyKey) return;   // a hashed-filter false positive
+}
+
+// step 2: the first probe of the bucket table
+__device__ __forceinline__ uint4 cand_slot(const Ctx& c, const Cand& k) {
+    if (!k.go_long) return make_uint4(kScan2EmptyKey, 0, 0, 0);
+    return *reinterpret_cast<const uint4*>(&c.P.slots[k.h]);
+}
+
+// step 3: all terms that end at p, longest first.  MODE 0: count and stage per lane in LDS (ordered path);
+// MODE 1: write to the pool at out_base; MODE 2: append to the wave's LDS fifo (unordered path).
+// PARTS: bit 0 = terms of length >= 4 (bucket table), bit 1 = terms of length <= 3 (short record)
+template <int MODE, int PARTS = 3>
+__device__ __forceinline__ void cand_finish(const Ctx& c, const Cand& k, uint4 slot, uint32_t& cnt, uint2* stage,
+                                            uint64_t out_base, uint32_t* fcnt) {
+    const Scan2Params& P = c.P;
+    const uint32_t p = k.p;
+    auto emit = [&](uint32_t term, uint32_t L) {
+        const uint32_t pos = P.pos_end ? p : p + 1 - L;
+        if (MODE == 0) {
+            if (cnt < kScan2StageCap) stage[cnt * 64] = make_uint2(term, pos);
+        } else if (MODE == 2) {
+            const uint32_t idx = __hip_atomic_fetch_add(fcnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (idx < kScan2FifoCap) stage[idx] = make_uint2(term, pos);
+        } else {
+            P.pool_term[out_base + cnt] = term;
+            P.pool_pos[out_base + cnt] = pos;
+        }
+        cnt++;
+    };
+    // ---- terms of length >= 4, longest first ---------------------------------------------------------------------
+    bool have = (PARTS & 1) && k.go_long;
+    uint32_t h = k.h;
+    while (have && slot.x != k.x) {
+        if (slot.x == kScan2EmptyKey) { have = false; break; }   // fingerprint / hashed-filter false positive
         h = (h + 1) & P.slot_mask;
+        slot = *reinterpret_cast<const uint4*>(&P.slots[h]);
     }
-    // bucket entries as {term_id, len, cmp_val, cmp_mask}; the common one-entry bucket is the slot itself
-    const bool simple = (slot.w & kScan2Simple) != 0;
-    uint32_t n_ent = 1, more_at = 0;
-    uint4 e;
-    if (simple) {
-        e = make_uint4(slot.w & 0x7FFFFFu, (slot.w >> 23) & 0xFFu, slot.y, slot.z);
-    } else {
-        more_at = slot.w;
-        n_ent = P.more[more_at].term_id;
-        e = *reinterpret_cast<const uint4*>(&P.more[more_at + 1]);
-    }
-    for (uint32_t j = 0;;) {
-        const uint32_t L = e.y;
-        bool ok = L <= p + 1;
-        if (ok && L > 4) {
-            if (wide) {
-                ok = ((tw ^ e.z) & e.w) == 0;
-            } else {                       // within 7 bytes of the blob start: byte by byte
-                for (uint32_t k = 0; k < 4 && ok; k++)
-                    if ((e.w >> (8 * k)) & 0xFF) {
-                        uint32_t b = c.dbase[(int64_t)p - 7 + k];
-                        if (P.fold) b = fold1(b);
-                        ok = b == ((e.z >> (8 * k)) & 0xFF);
+    if (have) {
+        // bucket entries as {term_id, len, cmp_val, cmp_mask}; the common one-entry bucket is the slot itself
+        const bool simple = (slot.w & kScan2Simple) != 0;
+        uint32_t n_ent = 1, more_at = 0;
+        uint4 e;
+        if (simple) {
+            e = make_uint4(slot.w & 0x7FFFFFu, (slot.w >> 23) & 0xFFu, slot.y, slot.z);
+        } else {
+            more_at = slot.w;
+            n_ent = P.more[more_at].term_id;
+            e = *reinterpret_cast<const uint4*>(&P.more[more_at + 1]);
+        }
+        for (uint32_t j = 0;;) {
+            const uint32_t L = e.y;
+            bool ok = L <= p + 1;
+            if (ok && L > 4) {
+                if (k.wide) {
+                    ok = ((k.tw ^ e.z) & e.w) == 0;
+                } else {                       // byte by byte
+                    for (uint32_t b4 = 0; b4 < 4 && ok; b4++)
+                        if ((e.w >> (8 * b4)) & 0xFF) {
+                            uint32_t b = c.dbase[(int64_t)p - 7 + b4];
+                            if (P.fold) b = fold1(b);
+                            ok = b == ((e.z >> (8 * b4)) & 0xFF);
+                        }
+                }
+                if (ok && L > 8) {
+                    // the first L-8 bytes of the term against text[p+1-L .. p-8], four bytes at a time from the end;
+                    // all loads are independent (no early exit), so they are in flight together.  term_blob carries 4
+                    // bytes of slack in front of every term, the text side needs 3 bytes of slack before the match.
+                    const uint8_t* tb = P.term_blob + P.term_off[e.x];
+                    const uint8_t* tp = c.dbase + (int64_t)p + 1 - L;
+                    const uint32_t n = L - 8;
+                    if (c.doc_abs + p + 1 - L >= 3) {
+                        uint32_t diff = 0;
+                        for (uint32_t j = 0; j * 4 < n; j++) {
+                            const int32_t at = (int32_t)n - 4 - (int32_t)(j * 4);       // may be -1..-3 for the last chunk
+                            uint32_t tv = load_u32_unaligned(tp + at);
+                            const uint32_t wv = load_u32_unaligned(tb + at);
+                            if (P.fold) tv = fold4(tv);
+                            const uint32_t mask = at >= 0 ? 0xFFFFFFFFu : 0xFFFFFFFFu << (8 * (uint32_t)(-at));
+                            diff |= (tv ^ wv) & mask;
+                        }
+                        ok = diff == 0;
+                    } else {
+                        for (uint32_t i = 0; i < n && ok; i++) {
+                            uint32_t b = tp[i];
+                            if (P.fold) b = fold1(b);
+                            ok = b == tb[i];
+                        }
                     }
-            }
-            if (ok && L > 8) {
-                const uint8_t* tb = P.term_blob + P.term_off[e.x];
-                const uint8_t* tp = c.dbase + p + 1 - L;
-                for (uint32_t i = 0; i + 8 < L && ok; i++) {
-                    uint32_t b = tp[i];
-                    if (P.fold) b = fold1(b);
-                    ok = b == tb[i];
                 }
             }
+            if (ok) emit(e.x, L);
+            if (++j >= n_ent) break;
+            e = *reinterpret_cast<const uint4*>(&P.more[more_at + 1 + j]);
         }
-        if (ok) {
-            const uint32_t pos = P.pos_end ? p : p + 1 - L;
-            if (MODE == 0) {
-                if (cnt < kScan2StageCap) stage[cnt * 64] = make_uint2(e.x, pos);
-            } else if (MODE == 2) {        // unordered: append to the wave's LDS fifo (stage = fifo)
-                const uint32_t idx = __hip_atomic_fetch_add(fcnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (idx < kScan2FifoCap) stage[idx] = make_uint2(e.x, pos);
-            } else {
-                P.pool_term[out_base + cnt] = e.x;
-                P.pool_pos[out_base + cnt] = pos;
-            }
-            cnt++;
-        }
-        if (++j >= n_ent) break;
-        e = *reinterpret_cast<const uint4*>(&P.more[more_at + 1 + j]);
     }
+    // ---- terms of length <= 3 (record from the LDS 3-window table; the record array is tiny and L1 resident) -----------
+    if ((PARTS & 2) && k.sid) {
+        const Scan2Short r = P.shorts[k.sid];
+#pragma unroll
+        for (uint32_t j = 0; j < 3; j++)
+            if (j < r.n && r.len[j] <= p + 1) emit(r.term[j], r.len[j]);
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ void verify(const Ctx& c, uint32_t p, uint32_t& cnt, uint2* stage, uint64_t out_base,
+                                       uint32_t* fcnt) {
+    Cand k;
+    cand_text(c, p, k);
+    if (k.go_long || k.sid) cand_finish<MODE>(c, k, cand_slot(c, k), cnt, stage, out_base, fcnt);
 }
 
 template <int MODE>
 __device__ __forceinline__ void verify_masks(const Ctx& c, uint32_t my_lo, uint32_t m0, uint32_t m1, uint32_t m2,
                                              uint32_t m3, uint32_t& cnt, uint2* stage, uint64_t out_base) {
-    uint32_t m[4] = {m0, m1, m2, m3};
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        uint32_t mk = m[k];
+    // one copy of the (large) verification body: the 32-position block index k is a scalar loop variable
+    for (uint32_t k = 0; k < 4; k++) {
+        uint32_t mk = k == 0 ? m0 : k == 1 ? m1 : k == 2 ? m2 : m3;
         while (__any(mk != 0)) {
             if (mk) {
                 const uint32_t i = __builtin_ctz(mk);
@@ -171,14 +239,20 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
     extern __shared__ __align__(16) uint8_t smem[];
     uint8_t* cls = smem;
     uint32_t* filt = reinterpret_cast<uint32_t*>(smem + 256);
-    uint8_t* wave_lds_all = smem + 256 + (size_t)P.filter_words * 4;
+    uint8_t* short3 = smem + 256 + (size_t)P.filter_words * 4;
+    uint8_t* fpt = short3 + P.short3_bytes;
+    uint8_t* wave_lds_all = fpt + kScan2FptSize;
 
-    for (uint32_t i = threadIdx.x; i < 256; i += kScan2Threads) cls[i] = P.cls[i];
-    for (uint32_t i = threadIdx.x; i < P.filter_words; i += kScan2Threads) filt[i] = P.filter[i];
+    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) cls[i] = P.cls[i];
+    for (uint32_t i = threadIdx.x; i < P.filter_words; i += blockDim.x) filt[i] = P.filter[i];
+    for (uint32_t i = threadIdx.x; i < P.short3_bytes / 4; i += blockDim.x)
+        reinterpret_cast<uint32_t*>(short3)[i] = reinterpret_cast<const uint32_t*>(P.short3)[i];
+    for (uint32_t i = threadIdx.x; i < kScan2FptSize / 4; i += blockDim.x)
+        reinterpret_cast<uint32_t*>(fpt)[i] = reinterpret_cast<const uint32_t*>(P.fpt)[i];
     __syncthreads();
 
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
-    constexpr uint32_t kWaves = kScan2Threads / 64;
+    const uint32_t kWaves = blockDim.x >> 6;
     // per-wave LDS region: [fifo / ordered staging: kScan2FifoCap x 8 B][candidate list: kScan2CandCap x 2 B][counter]
     uint8_t* wave_lds = wave_lds_all + (size_t)wave * kScan2WaveLds;
     uint2* fifo = reinterpret_cast<uint2*>(wave_lds);
@@ -193,7 +267,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
     for (uint64_t u = (uint64_t)blockIdx.x * kWaves + wave; u < P.n_units; u += (uint64_t)gridDim.x * kWaves) {
         const Unit un = P.units[u];
         const uint64_t doc_abs = P.doc_off[un.doc];
-        const Ctx c{P, cls, filt, P.text + doc_abs, doc_abs};
+        const Ctx c{P, cls, filt, P.short3_bytes ? short3 : nullptr, fpt, P.text + doc_abs, doc_abs};
         const uint32_t own = un.hi - un.lo;
         const uint32_t C = ((own + 63) / 64 + 3) & ~3u;            // bytes per lane (multiple of 4, <= 128)
         const uint32_t my_lo = un.lo + lane * C;
@@ -267,29 +341,66 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
             const uint32_t fincl = wave_incl_scan(f);
             const uint32_t ftotal = __shfl(fincl, 63, 64);
             bool done = ftotal == 0;
-            if (ftotal && ftotal <= kScan2CandCap) {
-                uint32_t wpos = fincl - f;
-                const uint32_t rel = lane * C;
-                uint32_t mm[4] = {m0, m1, m2, m3};
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    uint32_t mk = mm[k];
-                    while (mk) {
-                        const uint32_t i = __builtin_ctz(mk);
-                        mk &= mk - 1;
-                        cand[wpos++] = (uint16_t)(rel + 32 * k + i);
-                    }
-                }
+            if (ftotal) {
                 if (lane == 0) *fcnt = 0;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 uint32_t dummy = 0;
-                for (uint32_t i = lane; i < ftotal; i += 64)
-                    verify<2>(c, un.lo + cand[i], dummy, fifo, 0, fcnt);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                // passes over lane ranges whose flagged positions fit the LDS list (one pass for a typical unit)
+                for (uint32_t l0 = 0; l0 < 64;) {
+                    const uint32_t before = l0 ? __shfl(fincl, (int)l0 - 1, 64) : 0;
+                    const bool fits = lane >= l0 && fincl - before <= kScan2CandCap;
+                    const uint64_t fm = __ballot(fits) >> l0;
+                    const uint32_t nl = fm == ~0ull >> l0 ? 64 - l0 : (uint32_t)__builtin_ctzll(~fm);   // lanes in this pass (>= 1)
+                    const uint32_t l1 = l0 + nl;
+                    const uint32_t ptotal = __shfl(fincl, (int)l1 - 1, 64) - before;
+                    if (lane >= l0 && lane < l1) {
+                        uint32_t wpos = fincl - f - before;
+                        const uint32_t rel = lane * C;
+                        uint32_t mm[4] = {m0, m1, m2, m3};
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            uint32_t mk = mm[k];
+                            while (mk) {
+                                const uint32_t i = __builtin_ctz(mk);
+                                mk &= mk - 1;
+                                cand[wpos++] = (uint16_t)(rel + 32 * k + i);
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    // stage A: every flagged position -> LDS-only decisions; short terms are emitted here, positions that may
+                    // end a term of length >= 4 are compacted in place to the front of the list (write index <= read index)
+                    uint32_t ns = 0;
+                    for (uint32_t i0 = 0; i0 < ptotal; i0 += 64) {
+                        const uint32_t i = i0 + lane;
+                        const bool on = i < ptotal;
+                        Cand k;
+                        k.go_long = false; k.sid = 0;
+                        uint32_t rel = 0;
+                        if (on) { rel = cand[i]; cand_text(c, un.lo + rel, k); }
+                        if (on && k.sid) cand_finish<2, 2>(c, k, make_uint4(0, 0, 0, 0), dummy, fifo, 0, fcnt);
+                        const uint64_t sb = __ballot(on && k.go_long);
+                        if (on && k.go_long) cand[ns + __popcll(sb & ((1ull << lane) - 1))] = (uint16_t)rel;
+                        ns += (uint32_t)__popcll(sb);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    // stage B: the survivors, densely packed over the lanes, go to the L2 bucket table
+                    for (uint32_t i0 = 0; i0 < ns; i0 += 64) {
+                        const uint32_t i = i0 + lane;
+                        if (i < ns) {
+                            Cand k;
+                            cand_text(c, un.lo + cand[i], k);
+                            if (k.go_long) cand_finish<2, 1>(c, k, cand_slot(c, k), dummy, fifo, 0, fcnt);
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    l0 = l1;
+                }
                 const uint32_t nh = *fcnt;
                 if (nh <= kScan2FifoCap) {
                     if (nh > slab_left) {
@@ -361,21 +472,26 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
 
 }  // namespace
 
-size_t scan2_lds_bytes(uint32_t filter_words) {
-    return 256 + (size_t)filter_words * 4 + (size_t)(kScan2Threads / 64) * kScan2WaveLds;
+size_t scan2_lds_bytes(uint32_t filter_words, uint32_t short3_bytes, uint32_t waves) {
+    return 256 + (size_t)filter_words * 4 + short3_bytes + kScan2FptSize + (size_t)waves * kScan2WaveLds;
 }
 
-hipError_t launch_scan2(const Scan2Params& P, unsigned n_cus, hipStream_t st) {
+uint32_t scan2_pick_waves(uint32_t filter_words, uint32_t short3_bytes, size_t lds_max) {
+    for (uint32_t w : {16u, 12u, 8u, 4u})
+        if (scan2_lds_bytes(filter_words, short3_bytes, w) <= lds_max) return w;
+    return 0;
+}
+
+hipError_t launch_scan2(const Scan2Params& P, uint32_t waves, unsigned n_cus, hipStream_t st) {
     if (!P.n_units) return hipSuccess;
-    const size_t lds = scan2_lds_bytes(P.filter_words);
+    const size_t lds = scan2_lds_bytes(P.filter_words, P.short3_bytes, waves);
     const void* fn = P.hashed ? reinterpret_cast<const void*>(k_scan2<true>) : reinterpret_cast<const void*>(k_scan2<false>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    const unsigned wpb = kScan2Threads / 64;
-    uint64_t g = (P.n_units + wpb - 1) / wpb;
+    uint64_t g = (P.n_units + waves - 1) / waves;
     const unsigned grid = (unsigned)(g < n_cus ? (g ? g : 1) : n_cus);
-    if (P.hashed) k_scan2<true><<<dim3(grid), dim3(kScan2Threads), lds, st>>>(P);
-    else k_scan2<false><<<dim3(grid), dim3(kScan2Threads), lds, st>>>(P);
+    if (P.hashed) k_scan2<true><<<dim3(grid), dim3(waves * 64), lds, st>>>(P);
+    else k_scan2<false><<<dim3(grid), dim3(waves * 64), lds, st>>>(P);
     return hipGetLastError();
 }
 

@@ -2,85 +2,119 @@
 
 #include <algorithm>
 #include <cstring>
+#include <map>
 #include <unordered_map>
 
 namespace gft {
 
 void build_scan2_tables(const AcTables& ac, Scan2Tables& t) {
     t = Scan2Tables();
-    const uint32_t kp = ac.n_classes + 1;
-    if (kp > 256) { t.why_not = "dictionary uses all 256 byte values"; return; }
+    // Positions before the document start behave like bytes that occur in no term, so they share class 0 ("other");
+    // that class exists unless the dictionary uses all 256 byte values.
+    bool has_other = false;
+    for (int b = 0; b < 256; b++) has_other |= ac.byte_class[b] == 0 && ac.n_classes < 256;
+    if (!has_other || ac.n_classes > 255) { t.why_not = "dictionary uses all 256 byte values"; return; }
+    const uint32_t kp = ac.n_classes;
     t.kp = kp;
-    t.pad_class = ac.n_classes;
+    t.pad_class = 0;
     memcpy(t.cls, ac.byte_class, 256);
     for (int b = 0; b < 256; b++) t.cls_fold[b] = ac.byte_class[(b >= 'A' && b <= 'Z') ? b + 32 : b];
 
-    // budget for entering short terms under every window they end
-    uint64_t expand = 0;
-    for (const auto& s : ac.terms) {
-        if (s.empty() || s.size() >= kWin) continue;
-        uint64_t n = 1;
-        for (size_t i = s.size(); i < kWin; i++) n *= kp;
-        expand += n;
-        if (expand > kMaxWindowKeys) { t.why_not = "too many short terms for this alphabet size"; return; }
-    }
+    const uint64_t kp3 = (uint64_t)kp * kp * kp;
+    bool any_short = false;
+    for (const auto& s : ac.terms) any_short |= !s.empty() && s.size() < kWin;
+    if (any_short && kp3 > kScan2Short3Max) { t.why_not = "terms shorter than 4 bytes over a large alphabet"; return; }
 
+    // ---- terms of length >= 4: buckets keyed by their last four classes ------------------------------------------
     std::unordered_map<uint32_t, std::vector<Scan2Entry>> buckets;
-    buckets.reserve(ac.terms.size() * 2 + (size_t)expand);
-    t.term_off.assign(1, 0);
+    buckets.reserve(ac.terms.size() * 2);
+    std::vector<std::vector<uint32_t>> content;   // per 3-window: short terms ending there
+    if (any_short) content.resize((size_t)kp3);
+    // term blob: 4 bytes of slack in front of every term (the kernel compares unaligned dwords that may start up to
+    // 3 bytes before a term); term_off[id] points at the term's first byte
+    t.term_off.clear();
     for (size_t id = 0; id < ac.terms.size(); id++) {
         const std::string& s = ac.terms[id];
-        t.term_blob.insert(t.term_blob.end(), s.begin(), s.end());
+        t.term_blob.insert(t.term_blob.end(), 4, 0);
         t.term_off.push_back((uint32_t)t.term_blob.size());
+        t.term_blob.insert(t.term_blob.end(), s.begin(), s.end());
         const uint32_t L = (uint32_t)s.size();
         if (L == 0) continue;   // the empty keyword never matches
-        Scan2Entry e{(uint32_t)id, L, 0, 0};
-        for (int k = 0; k < 4; k++) {
-            const int idx = (int)L - 8 + k;
-            if (idx >= 0 && idx < (int)L - 4) {
-                e.cmp_val |= (uint32_t)(uint8_t)s[idx] << (8 * k);
-                e.cmp_mask |= 0xFFu << (8 * k);
-            }
-        }
-        uint32_t tail = 0;            // radix value of the term's last min(L, 4) classes
+        uint32_t tail = 0;      // radix value of the term's last min(L, 4) classes
         const uint32_t m = std::min(L, kWin);
         for (uint32_t i = L - m; i < L; i++) tail = tail * kp + ac.byte_class[(uint8_t)s[i]];
         if (L >= kWin) {
+            Scan2Entry e{(uint32_t)id, L, 0, 0};
+            for (int k = 0; k < 4; k++) {
+                const int idx = (int)L - 8 + k;
+                if (idx >= 0 && idx < (int)L - 4) {
+                    e.cmp_val |= (uint32_t)(uint8_t)s[idx] << (8 * k);
+                    e.cmp_mask |= 0xFFu << (8 * k);
+                }
+            }
             buckets[tail].push_back(e);
         } else {
+            // a short term ends every 3-window whose last L classes are the term
             uint32_t scale = 1, combos = 1;
-            for (uint32_t i = 0; i < m; i++) scale *= kp;
-            for (uint32_t i = m; i < kWin; i++) combos *= kp;
-            for (uint32_t pre = 0; pre < combos; pre++) buckets[pre * scale + tail].push_back(e);
+            for (uint32_t i = 0; i < L; i++) scale *= kp;
+            for (uint32_t i = L; i < 3; i++) combos *= kp;
+            for (uint32_t pre = 0; pre < combos; pre++) content[(size_t)pre * scale + tail].push_back((uint32_t)id);
         }
     }
     t.n_keys = buckets.size();
 
-    // filter
-    uint64_t direct_bits = (uint64_t)kp * kp * kp * kp;
+    // ---- filter -----------------------------------------------------------------------------------------------------
+    const uint64_t direct_bits = kp3 * kp;
     t.hashed = direct_bits > kFilterDirectMaxBits;
     t.filter_bits = t.hashed ? kFilterHashedBits : (uint32_t)((direct_bits + 31) & ~31ull);
     t.hash_shift = 32;
     if (t.hashed) { uint32_t lg = 0; while ((1u << lg) < t.filter_bits) lg++; t.hash_shift = 32 - lg; }
     t.filter.assign(t.filter_bits / 32, 0);
+    auto set_filter = [&](uint32_t key) {
+        const uint32_t fi = t.hashed ? (key * kGold) >> t.hash_shift : key;
+        t.filter[fi >> 5] |= 1u << (fi & 31);
+    };
 
-    // slots: 16 bytes each; a bucket with one plain entry is answered by the slot alone
+    // ---- short3: records of up to three short terms, longest first -------------------------------------------------------
+    t.shorts.assign(1, Scan2Short{0, {0, 0, 0}, {0, 0, 0}, 0});
+    if (any_short) {
+        t.short3.assign(((size_t)kp3 + 15) & ~(size_t)15, 0);
+        std::map<std::vector<uint32_t>, uint32_t> ids;
+        for (size_t w = 0; w < content.size(); w++) {
+            auto& v = content[w];
+            if (v.empty()) continue;
+            std::sort(v.begin(), v.end(), [&](uint32_t a, uint32_t b) { return ac.terms[a].size() > ac.terms[b].size(); });
+            auto it = ids.find(v);
+            if (it == ids.end()) {
+                if (t.shorts.size() > 255) { t.why_not = "too many distinct short-term combinations"; return; }
+                Scan2Short r{(uint32_t)v.size(), {0, 0, 0}, {0, 0, 0}, 0};
+                for (size_t i = 0; i < v.size() && i < 3; i++) { r.term[i] = v[i]; r.len[i] = (uint32_t)ac.terms[v[i]].size(); }
+                it = ids.emplace(v, (uint32_t)t.shorts.size()).first;
+                t.shorts.push_back(r);
+            }
+            t.short3[w] = (uint8_t)it->second;
+            for (uint32_t c0 = 0; c0 < kp; c0++) set_filter((uint32_t)(c0 * kp3 + w));   // any class may precede
+        }
+    }
+
+    // ---- slots (16 bytes) + fingerprint table ---------------------------------------------------------------------------------
     uint32_t lg = 10;
-    while ((1ull << lg) < 2 * t.n_keys) lg++;
+    while ((1ull << lg) < 4 * t.n_keys) lg++;   // load <= 0.25: a miss ends at the first probe most of the time
     t.slot_shift = 32 - lg;
     t.slots.assign((size_t)1 << lg, Scan2Slot{kScan2EmptyKey, 0, 0, 0});
+    t.fpt.assign(kScan2FptSize, 0);
     const uint32_t smask = (1u << lg) - 1;
     for (auto& kv : buckets) {
         auto& v = kv.second;
         std::stable_sort(v.begin(), v.end(), [](const Scan2Entry& a, const Scan2Entry& b) { return a.len > b.len; });
         const uint32_t key = kv.first;
-        const uint32_t fi = t.hashed ? (key * kGold) >> t.hash_shift : key;
-        t.filter[fi >> 5] |= 1u << (fi & 31);
+        set_filter(key);
         uint32_t h = (key * kGold) >> t.slot_shift;
         while (t.slots[h].key != kScan2EmptyKey) h = (h + 1) & smask;
         Scan2Slot& s = t.slots[h];
         s.key = key;
-        if (v.size() == 1 && v[0].len <= 255 && v[0].term_id < (1u << 23)) {
+        const bool simple = v.size() == 1 && v[0].len <= 255 && v[0].term_id < (1u << 23);
+        if (simple) {
             s.cmp_val = v[0].cmp_val; s.cmp_mask = v[0].cmp_mask;
             s.info = kScan2Simple | v[0].len << 23 | v[0].term_id;
         } else {
@@ -89,7 +123,17 @@ void build_scan2_tables(const AcTables& ac, Scan2Tables& t) {
             t.more.push_back(Scan2Entry{(uint32_t)v.size(), 0, 0, 0});
             t.more.insert(t.more.end(), v.begin(), v.end());
         }
+        // fingerprint byte: exact for a window that ends one term; "ambiguous" when entries share it
+        uint8_t& f = t.fpt[(key * kGold) >> kScan2FptShift];
+        if (f == 0 && v.size() == 1) {
+            const uint32_t nf = std::min<uint32_t>(v[0].len - 4, 4);
+            f = (uint8_t)((nf + 1) << 5 | scan2_fp5(v[0].cmp_val & v[0].cmp_mask));
+        } else {
+            f = kScan2FptAmbiguous;
+        }
     }
+    t.term_blob.insert(t.term_blob.end(), 8, 0);
+    t.term_off.push_back((uint32_t)t.term_blob.size());
     if (t.more.empty()) t.more.push_back(Scan2Entry{0, 0, 0, 0});
     t.supported = t.more.size() < (1u << 31);
     if (!t.supported) t.why_not = "bucket table too large";

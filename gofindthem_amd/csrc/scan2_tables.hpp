@@ -3,11 +3,16 @@
 // The Aho-Corasick automaton truncated at depth 4 is a 4-local machine: which dictionary terms can END at text
 // position p is a function of the last four byte classes only.  That function is tabulated:
 //   * filter   one bit per 4-class window (direct-indexed, or hashed when the alphabet is large): "some term may end
-//              here".  It lives in LDS and is probed once per text byte with no dependent chain between bytes.
-//   * buckets  window -> the terms that end with exactly that window (terms shorter than 4 are entered under every
-//              window they are a suffix of), longest first == the reference's emission order (node, then its
-//              dictionary-suffix chain).  A term longer than 4 is confirmed by comparing the bytes in front of the
-//              window; every match is therefore found from its own END position and no failure links are needed.
+//              here".  LDS, probed once per text byte, no dependent chain between bytes.
+//   * short3   byte per 3-class window: which terms of length <= 3 end here (id of a small record holding up to three
+//              terms, longest first).  LDS; answers the bulk of all matches without leaving the CU.
+//   * fpt      byte per hashed window key: for windows that end exactly one term of length >= 4, how many bytes in
+//              front of the window that term has and a 5-bit fingerprint of them.  LDS; rejects most positions where
+//              the window matches but the bytes in front do not, before any L2 access.
+//   * slots    window -> the terms of length >= 4 that end with exactly that window, longest first == the reference's
+//              emission order (node, then its dictionary-suffix chain).  L2; a term longer than the window is confirmed
+//              by comparing the bytes in front of it, so every match is found from its own END position and no failure
+//              links are needed.
 // Same inputs as NewStringMatcher (finder/substringEngine.go:103); same outputs as MatchAll (:111-116).
 #pragma once
 #include <cstdint>
@@ -32,9 +37,12 @@ struct Scan2Tables {
     uint32_t filter_bits = 0;        // number of bits in the filter
     uint32_t hash_shift = 0;         // hashed: index = (key * kGold) >> hash_shift
     std::vector<uint32_t> filter;    // filter_bits / 32 words
+    std::vector<uint8_t> short3;     // [kp^3 rounded up to 16] record id (0 = none) per 3-window
+    std::vector<Scan2Short> shorts;  // record 0 unused
+    std::vector<uint8_t> fpt;        // [kScan2FptSize]
     uint32_t slot_shift = 0;         // slot index = (key * kGold) >> slot_shift, linear probing
-    std::vector<Scan2Slot> slots;    // power-of-two table
-    std::vector<Scan2Entry> more;    // overflow entries of multi-term buckets
+    std::vector<Scan2Slot> slots;    // power-of-two table, terms of length >= 4 only
+    std::vector<Scan2Entry> more;    // entry lists of multi-term buckets
     uint8_t cls[256];                // byte -> class
     uint8_t cls_fold[256];           // byte -> class of its ASCII lower-case form
     std::vector<uint8_t> term_blob;  // raw term bytes (for terms longer than 8)

@@ -322,7 +322,17 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         }
         {
             ProfScope ps(e, "scan");
-            HIP_TRY(launch_scan2(P, e->scan2_waves, e->n_cus, st), "scan kernel launch");
+            // process path: matches in any order -> gft_scan3 (coalesced rounds, candidates resolved from registers);
+            // CSR path, or no class-0 byte to stand in for "before the document": gft_scan2 (text order)
+            const int pad = P.fold ? e->s2.pad_byte_fold : e->s2.pad_byte;
+            const char* k3 = getenv("GFT_SCAN_KERNEL");
+            if (!need_csr && pad >= 0 && !(k3 && std::string(k3) == "window2")) {
+                P.pad_byte = (uint32_t)pad;
+                HIP_TRY(launch_scan3(P, e->scan2_waves, e->n_cus, st), "scan kernel launch");
+            } else {
+                P.pad_byte = 0;
+                HIP_TRY(launch_scan2(P, e->scan2_waves, e->n_cus, st), "scan kernel launch");
+            }
         }
         uint64_t cursor = 0;
         HIP_TRY(hipMemcpyAsync(&cursor, e->d_cursor.p, 8, hipMemcpyDeviceToHost, st), "readback");

@@ -85,7 +85,9 @@ constexpr uint32_t kScan2StageCap = 6;           // matches a lane can stage in 
 constexpr uint32_t kScan2FifoCap = 256;          // unordered path: matches of one unit buffered in LDS (>= 64 * kScan2StageCap)
 constexpr uint32_t kScan2CandCap = 856;          // unordered path: flagged positions of one unit listed in LDS
 constexpr uint32_t kScan2WaveLds = kScan2FifoCap * 8 + kScan2CandCap * 2 + 16;   // 3776 bytes per wave
-constexpr uint32_t kScan2Batch = 2;             // unordered path: flagged positions a lane verifies per trip
+constexpr uint32_t kScan2Batch = 2;
+constexpr uint32_t kScan3TextBytes = 1040;        // gft_scan3: one round of text in LDS (8 bytes of history + 1 KiB)
+constexpr uint32_t kScan3ListCap = 320;           // gft_scan3: flagged positions of a round listed in LDS             // unordered path: flagged positions a lane verifies per trip
 constexpr uint32_t kScan2Slab = 4096;            // pool entries a wave reserves per global atomic
 constexpr uint32_t kScan2UnitMax = 8192;         // bytes per work unit (128 per lane)
 constexpr uint32_t kGoldDev = 0x9E3779B1u;
@@ -144,6 +146,7 @@ struct Scan2Params {
     const uint8_t* term_blob;
     const uint32_t* term_off;
     uint32_t kp, pad_class, fold, pos_end;
+    uint32_t pad_byte;           // gft_scan3: a byte value of class 0 (stands in for positions before the document start)
     uint64_t* cursor;            // pool allocation cursor (entries, slab granular)
     uint64_t pool_cap;
     uint32_t* pool_term;
@@ -160,6 +163,7 @@ size_t scan2_lds_bytes(uint32_t filter_words, uint32_t short3_bytes, uint32_t wa
 // picks the largest workgroup (16, 12, 8 or 4 waves) whose LDS footprint fits lds_max; 0 if none does
 uint32_t scan2_pick_waves(uint32_t filter_words, uint32_t short3_bytes, size_t lds_max);
 hipError_t launch_scan2(const Scan2Params& P, uint32_t waves, unsigned n_cus, hipStream_t st);
+hipError_t launch_scan3(const Scan2Params& P, uint32_t waves, unsigned n_cus, hipStream_t st);
 
 hipError_t launch_unit_count(const uint64_t* d_doc_off, uint64_t n_docs, uint32_t unit_max, uint32_t* d_cnt,
                              hipStream_t st);

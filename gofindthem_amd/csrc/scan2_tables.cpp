@@ -20,6 +20,11 @@ void build_scan2_tables(const AcTables& ac, Scan2Tables& t) {
     memcpy(t.cls, ac.byte_class, 256);
     for (int b = 0; b < 256; b++) t.cls_fold[b] = ac.byte_class[(b >= 'A' && b <= 'Z') ? b + 32 : b];
 
+    for (int b = 255; b >= 0; b--) {
+        if (t.cls[b] == 0) t.pad_byte = b;
+        if (t.cls_fold[b] == 0) t.pad_byte_fold = b;
+    }
+
     const uint64_t kp3 = (uint64_t)kp * kp * kp;
     bool any_short = false;
     for (const auto& s : ac.terms) any_short |= !s.empty() && s.size() < kWin;

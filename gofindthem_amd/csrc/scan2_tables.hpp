@@ -48,6 +48,8 @@ struct Scan2Tables {
     std::vector<uint8_t> term_blob;  // raw term bytes (for terms longer than 8)
     std::vector<uint32_t> term_off;  // n_terms + 1
     uint64_t n_keys = 0;
+    int pad_byte = -1;               // a byte of class 0 in cls[] (gft_scan3 history at a document start), -1: none
+    int pad_byte_fold = -1;          // same for cls_fold[]
 };
 
 constexpr uint32_t kGold = kGoldDev;

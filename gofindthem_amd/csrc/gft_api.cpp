@@ -536,6 +536,14 @@ int gft_build(gft_engine* e, const uint8_t* terms_blob, const uint64_t* term_off
     e->scan2_waves = e->s2.supported ? scan2_pick_waves((uint32_t)e->s2.filter.size(), (uint32_t)e->s2.short3.size(),
                                                          e->lds_max - 512) : 0;
     e->use_scan2 = e->s2.supported && !(force && std::string(force) == "dfa") && e->scan2_waves > 0;
+    if (e->use_scan2 && getenv("GFT_SCAN_DEBUG")) {
+        size_t n_ff = 0, n_used = 0, n_simple = 0, n_slots = 0;
+        for (uint8_t b : e->s2.fpt) { n_ff += b == 0xFF; n_used += b != 0; }
+        for (const auto& s : e->s2.slots) { n_slots += s.key != kScan2EmptyKey; n_simple += s.key != kScan2EmptyKey && (s.info & kScan2Simple); }
+        fprintf(stderr, "[gft build debug] kp=%u keys=%zu (simple %zu) slots=%zu fpt: used=%zu always-pass=%zu of %u; shorts=%zu filter=%s %u bits waves=%u\n",
+                e->s2.kp, n_slots, n_simple, e->s2.slots.size(), n_used, n_ff, kScan2FptSize, e->s2.shorts.size() - 1,
+                e->s2.hashed ? "hashed" : "direct", e->s2.filter_bits, e->scan2_waves);
+    }
     if (e->use_scan2) {
         e->scan2_short3_bytes = (uint32_t)e->s2.short3.size();
         if (e->s2.short3.empty()) e->s2.short3.assign(16, 0);   // placeholder upload; short3_bytes stays 0

@@ -122,11 +122,38 @@ constexpr uint32_t kScan2Short3Max = 32768;      // bytes of LDS a direct 3-wind
 constexpr uint32_t kScan2FptSize = 16384;        // one byte per hashed window key
 constexpr uint32_t kScan2FptShift = 32 - 14;
 constexpr uint32_t kScan2FptAmbiguous = 0xFF;    // several terms share the byte: always go to the bucket table
-// fingerprint byte = (front_bytes + 1) << 5 | fp5(front bytes as loaded from text[p-7..p-4], masked); 0 = no term
+// Fingerprint table: every window key that ends a term of length >= 4 owns ONE of its two candidate cells (cuckoo
+// placement at build time).  cell byte = code << 5 | fp5(key, the term's bytes in front of the window); code 1..7
+// says how many front bytes the fingerprint covers (0, 1, 2, 3, 4, 6, 8); 0 = empty cell; 0xFF = always go to the
+// bucket table.  Front bytes as loaded from the text: `f_lo` = text[p-7..p-4], `f_hi` = text[p-11..p-8] (little endian).
+// A position passes if either of its two cells passes.
 #if defined(__HIPCC__)
-__host__ __device__
+#define GFT_HD __host__ __device__
+#else
+#define GFT_HD
 #endif
-inline uint32_t scan2_fp5(uint32_t masked_front) { return (masked_front * 0x85EBCA6Bu) >> 27; }
+GFT_HD inline uint32_t scan2_fpt_cell(uint32_t x, int which) {
+    return (x * (which ? 0xC2B2AE35u : kGoldDev)) >> kScan2FptShift;
+}
+GFT_HD inline uint32_t scan2_fpt_code(uint32_t term_len) {            // term_len >= 4
+    const uint32_t nf = term_len - 4;
+    return nf <= 4 ? nf + 1 : nf < 6 ? 5 : nf < 8 ? 6 : 7;
+}
+GFT_HD inline uint32_t scan2_fpt_byte(uint32_t code, uint32_t x, uint32_t f_lo, uint32_t f_hi) {
+    const uint32_t n = code <= 5 ? code - 1 : code == 6 ? 6 : 8;       // front bytes covered
+    const uint32_t m_lo = n >= 4 ? 0xFFFFFFFFu : n ? 0xFFFFFFFFu << (8 * (4 - n)) : 0u;
+    const uint32_t m_hi = n <= 4 ? 0u : n >= 8 ? 0xFFFFFFFFu : 0xFFFFFFFFu << (8 * (8 - n));
+    uint32_t h = (f_lo & m_lo) ^ (x * 0x27D4EB2Fu);
+    h = (h * 0x85EBCA6Bu) ^ ((f_hi & m_hi) * 0xC2B2AE3Du);
+    uint32_t fp = (h * 0x9E3779B1u) >> 27;
+    if (code == 7 && fp == 31) fp = 30;                                // 0xFF is the "ambiguous" marker
+    return code << 5 | fp;
+}
+GFT_HD inline bool scan2_fpt_pass(uint32_t cell, uint32_t x, uint32_t f_lo, uint32_t f_hi) {
+    if (cell == 0) return false;
+    if (cell == kScan2FptAmbiguous) return true;
+    return scan2_fpt_byte(cell >> 5, x, f_lo, f_hi) == cell;
+}
 
 struct Scan2Params {
     const uint8_t* text;

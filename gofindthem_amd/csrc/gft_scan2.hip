@@ -92,15 +92,13 @@ __device__ __forceinline__ void cand_text(const Ctx& c, uint32_t p, Cand& k) {
     // LDS-only decisions: which short-term record ends here, and whether a term of length >= 4 can end here at all
     // (fingerprint of the bytes in front of the window) -- most flagged positions stop here without touching L2
     k.sid = c.short3 ? c.short3[x3] : 0;
-    const uint32_t f = c.fpt[(k.x * kGoldDev) >> kScan2FptShift];
-    if (f == 0) {
-        k.go_long = false;
-    } else if (f == kScan2FptAmbiguous || !k.wide) {
-        k.go_long = true;
+    const uint32_t f0 = c.fpt[scan2_fpt_cell(k.x, 0)], f1 = c.fpt[scan2_fpt_cell(k.x, 1)];
+    if (c.doc_abs + p >= 11) {
+        uint32_t tw2 = load_u32_unaligned(c.dbase + (int64_t)p - 11);
+        if (P.fold) tw2 = fold4(tw2);
+        k.go_long = scan2_fpt_pass(f0, k.x, k.tw, tw2) || scan2_fpt_pass(f1, k.x, k.tw, tw2);
     } else {
-        const uint32_t nf = (f >> 5) - 1;
-        const uint32_t mask = nf ? 0xFFFFFFFFu << (8 * (4 - nf)) : 0u;
-        k.go_long = scan2_fp5(k.tw & mask) == (f & 31u);
+        k.go_long = (f0 | f1) != 0;       // not enough bytes in front to fingerprint this close to the blob start
     }
     if (P.dbg & 12) {           // timing studies (wrong results): 4 = no bucket-table access, 8 = no short-term records
         if (P.dbg & 4) k.go_long = false;

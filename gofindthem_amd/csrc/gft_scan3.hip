@@ -58,11 +58,12 @@ __device__ __forceinline__ void emit(const Out& o, uint32_t term, uint32_t pos) 
 }
 
 // terms of length >= 4 ending at document position p (window key x, the 4 bytes in front of the window in tw)
+// `slot` = the first probe of the bucket table, loaded ahead of time by the caller
 __device__ __forceinline__ void long_terms(const Out& o, const uint8_t* dbase, uint64_t doc_abs, uint32_t p, uint32_t x,
-                                           uint32_t tw) {
+                                           uint32_t tw, uint4 slot) {
     const Scan2Params& P = o.P;
     uint32_t h = (x * kGoldDev) >> P.slot_shift;
-    uint4 slot = *reinterpret_cast<const uint4*>(&P.slots[h]);
+    if (P.dbg & 64) return;
     while (slot.x != x) {
         if (slot.x == kScan2EmptyKey) return;     // fingerprint / hashed-filter false positive
         h = (h + 1) & P.slot_mask;
@@ -81,7 +82,7 @@ __device__ __forceinline__ void long_terms(const Out& o, const uint8_t* dbase, u
     for (uint32_t j = 0;;) {
         const uint32_t L = e.y;
         bool ok = L <= p + 1 && ((tw ^ e.z) & e.w) == 0;
-        if (ok && L > 8) {
+        if (ok && L > 8 && !(P.dbg & 16)) {
             // the first L-8 bytes of the term against text[p+1-L .. p-8], four bytes at a time from the end; the loads
             // are independent.  term_blob has 4 bytes of slack before every term; the text needs 3 before the match.
             const uint8_t* tb = P.term_blob + P.term_off[e.x];
@@ -106,7 +107,7 @@ __device__ __forceinline__ void long_terms(const Out& o, const uint8_t* dbase, u
                 }
             }
         }
-        if (ok) emit(o, e.x, P.pos_end ? p : p + 1 - L);
+        if (ok && !(P.dbg & 32)) emit(o, e.x, P.pos_end ? p : p + 1 - L);
         if (++j >= n_ent) break;
         e = *reinterpret_cast<const uint4*>(&P.more[more_at + 1 + j]);
     }
@@ -157,7 +158,12 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan3(const Scan2Params P) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             // history of lane 0 in the first round: the 8 bytes in front of the unit, or "no-term" bytes at a document start
-            uint32_t carry2, carry3;
+            uint32_t carry0, carry1, carry2, carry3;
+            carry0 = carry1 = P.pad_byte * 0x01010101u;
+            if (un.lo >= 16) {
+                const U64u hv0 = *reinterpret_cast<const U64u*>(dbase + un.lo - 16);
+                carry0 = hv0.lo; carry1 = hv0.hi;
+            }
             if (un.lo >= 8) {
                 const U64u hv = *reinterpret_cast<const U64u*>(dbase + un.lo - 8);
                 carry2 = hv.lo; carry3 = hv.hi;
@@ -169,6 +175,17 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan3(const Scan2Params P) {
                 }
             }
 
+            // a bucket probe in flight per lane (see stage B)
+            bool pend = false;
+            uint32_t pend_x = 0, pend_tw = 0, pend_p = 0;
+            uint4 pend_slot = make_uint4(0, 0, 0, 0);
+            auto finish_pending = [&]() {
+                if (__any(pend)) {
+                    if (pend) long_terms(o, dbase, doc_abs, pend_p, pend_x, pend_tw, pend_slot);
+                    pend = false;
+                }
+            };
+
             for (uint32_t r = 0; r < rounds; r++) {
                 const uint32_t p0 = un.lo + (r << 10) + lane * 16;
                 const uint32_t nvalid = p0 < un.hi ? (un.hi - p0 < 16 ? un.hi - p0 : 16) : 0;
@@ -179,6 +196,8 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan3(const Scan2Params P) {
                 }
                 uint32_t h0 = __shfl_up(w2, 1, 64), h1 = __shfl_up(w3, 1, 64);
                 if (lane == 0) { h0 = carry2; h1 = carry3; }
+                const uint32_t g0 = carry0, g1 = carry1;       // 8 more bytes of history for the fingerprints (lane 0 only)
+                carry0 = __shfl(w0, 63, 64); carry1 = __shfl(w1, 63, 64);
                 carry2 = __shfl(w2, 63, 64);
                 carry3 = __shfl(w3, 63, 64);
 
@@ -203,7 +222,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan3(const Scan2Params P) {
                 if (P.dbg & 1) fm = 0;        // timing study: filter only
 
                 // ---- this round's text to LDS: flagged positions are resolved from there, balanced over the lanes -----------
-                if (lane == 0) { txt[2] = h0; txt[3] = h1; }
+                if (lane == 0) { txt[0] = g0; txt[1] = g1; txt[2] = h0; txt[3] = h1; }
                 if (nvalid) *reinterpret_cast<uint4*>(&txt[4 + lane * 4]) = make_uint4(w0, w1, w2, w3);
                 const uint32_t f = __popc(fm);
                 uint32_t fincl = f;
@@ -215,12 +234,13 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan3(const Scan2Params P) {
                 const uint32_t ftotal = __shfl(fincl, 63, 64);
                 const uint32_t round_base = un.lo + (r << 10);
                 // 8 bytes ending at round offset q: tw = bytes q-7..q-4, win = q-3..q (LDS text, byte 16 + q = offset q)
-                auto context = [&](uint32_t q, uint32_t& tw, uint32_t& x, uint32_t& x3) {
+                auto context = [&](uint32_t q, uint32_t& tw, uint32_t& tw2, uint32_t& x, uint32_t& x3) {
                     const uint32_t s0 = q + 9, sh = (s0 & 3) * 8;
-                    const uint32_t d0 = txt[s0 >> 2], d1 = txt[(s0 >> 2) + 1], d2 = txt[(s0 >> 2) + 2];
+                    const uint32_t dm = txt[(s0 >> 2) - 1], d0 = txt[s0 >> 2], d1 = txt[(s0 >> 2) + 1], d2 = txt[(s0 >> 2) + 2];
+                    tw2 = __builtin_amdgcn_alignbit(d0, dm, sh);      // bytes q-11..q-8 (q >= 0: s0 >= 9, index >= 1)
                     tw = __builtin_amdgcn_alignbit(d1, d0, sh);
                     const uint32_t win = __builtin_amdgcn_alignbit(d2, d1, sh);
-                    if (P.fold) tw = fold4(tw);
+                    if (P.fold) { tw = fold4(tw); tw2 = fold4(tw2); }
                     x3 = (cls[(win >> 8) & 0xFF] * kp + cls[(win >> 16) & 0xFF]) * kp + cls[win >> 24];
                     x = cls[win & 0xFF] * kp3 + x3;
                 };
@@ -249,17 +269,13 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan3(const Scan2Params P) {
                         const uint32_t i = i0 + lane;
                         const bool on = i < ptotal;
                         const uint32_t q = on ? cand[i] : 0;
-                        uint32_t tw, x, x3;
-                        context(q, tw, x, x3);
+                        uint32_t tw, tw2, x, x3;
+                        context(q, tw, tw2, x, x3);
                         const uint32_t p = round_base + q;
                         const uint32_t sid = on && have_short ? short3[x3] : 0;
-                        const uint32_t fb = fpt[(x * kGoldDev) >> kScan2FptShift];
-                        bool go_long = on && fb != 0;
-                        if (go_long && fb != kScan2FptAmbiguous) {
-                            const uint32_t nf = (fb >> 5) - 1;
-                            const uint32_t mask = nf ? 0xFFFFFFFFu << (8 * (4 - nf)) : 0u;
-                            go_long = scan2_fp5(tw & mask) == (fb & 31u);
-                        }
+                        const bool go0 = scan2_fpt_pass(fpt[scan2_fpt_cell(x, 0)], x, tw, tw2);
+                        const bool go1 = scan2_fpt_pass(fpt[scan2_fpt_cell(x, 1)], x, tw, tw2);
+                        bool go_long = on && (go0 || go1);
                         if (P.dbg & 4) go_long = false;
                         if (sid && !(P.dbg & 8)) {   // terms of length <= 3 (record array: tiny, L1 resident)
                             const Scan2Short rec = P.shorts[sid];
@@ -271,15 +287,27 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan3(const Scan2Params P) {
                         if (go_long) cand[ns + (uint32_t)__popcll(sb & lt_mask)] = (uint16_t)q;
                         ns += (uint32_t)__popcll(sb);
                     }
+                    if ((P.dbg & 2) && lane == 0) {
+                        atomicAdd(reinterpret_cast<unsigned long long*>(P.dbg_counters), (unsigned long long)ptotal);
+                        atomicAdd(reinterpret_cast<unsigned long long*>(P.dbg_counters + 1), (unsigned long long)ns);
+                    }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    // stage B: the survivors, densely packed over the lanes, go to the L2 bucket table
-                    for (uint32_t i = lane; i < ns; i += 64) {
-                        const uint32_t q = cand[i];
-                        uint32_t tw, x, x3;
-                        context(q, tw, x, x3);
-                        long_terms(o, dbase, doc_abs, round_base + q, x, tw);
+                    // stage B: the survivors, densely packed over the lanes, go to the L2 bucket table.  Software pipeline:
+                    // the probe is only ISSUED here; it is consumed one trip later (normally in the next round, after that
+                    // round's filter and stage A), so its L2 latency is off the critical path.
+                    for (uint32_t i0 = 0; i0 < ns; i0 += 64) {
+                        finish_pending();
+                        const uint32_t i = i0 + lane;
+                        if (i < ns) {
+                            const uint32_t q = cand[i];
+                            uint32_t x3, tw2;
+                            context(q, pend_tw, tw2, pend_x, x3);
+                            pend_p = round_base + q;
+                            pend_slot = *reinterpret_cast<const uint4*>(&P.slots[(pend_x * kGoldDev) >> P.slot_shift]);
+                            pend = true;
+                        }
                     }
                     __builtin_amdgcn_wave_barrier();
                     l0 = l1;
@@ -287,6 +315,9 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan3(const Scan2Params P) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();      // the next round overwrites the LDS text
             }
+            finish_pending();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             const uint32_t nh = *fcnt;
             if (o.direct) break;

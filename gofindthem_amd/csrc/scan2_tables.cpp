@@ -108,6 +108,9 @@ void build_scan2_tables(const AcTables& ac, Scan2Tables& t) {
     t.slot_shift = 32 - lg;
     t.slots.assign((size_t)1 << lg, Scan2Slot{kScan2EmptyKey, 0, 0, 0});
     t.fpt.assign(kScan2FptSize, 0);
+    struct FpItem { uint32_t key; uint8_t val[2]; uint32_t n; };
+    std::vector<FpItem> fp_items;
+    std::vector<uint32_t> homeless;
     const uint32_t smask = (1u << lg) - 1;
     for (auto& kv : buckets) {
         auto& v = kv.second;
@@ -128,15 +131,58 @@ void build_scan2_tables(const AcTables& ac, Scan2Tables& t) {
             t.more.push_back(Scan2Entry{(uint32_t)v.size(), 0, 0, 0});
             t.more.insert(t.more.end(), v.begin(), v.end());
         }
-        // fingerprint byte: exact for a window that ends one term; "ambiguous" when entries share it
-        uint8_t& f = t.fpt[(key * kGold) >> kScan2FptShift];
-        if (f == 0 && v.size() == 1) {
-            const uint32_t nf = std::min<uint32_t>(v[0].len - 4, 4);
-            f = (uint8_t)((nf + 1) << 5 | scan2_fp5(v[0].cmp_val & v[0].cmp_mask));
-        } else {
-            f = kScan2FptAmbiguous;
+        // fingerprint cells (cuckoo: two candidate cells per key).  A one-term bucket owns one cell; a two-term bucket
+        // needs both of its cells (one fingerprint each); larger buckets pass everything.
+        fp_items.push_back(FpItem{key, {0, 0}, (uint32_t)std::min<size_t>(v.size(), 3)});
+        for (size_t i = 0; i < v.size() && i < 2; i++) {
+            // front bytes as a text load would see them: f_lo = term[L-8..L-4), f_hi = term[L-12..L-8)
+            const std::string& s = ac.terms[v[i].term_id];
+            const int L = (int)s.size();
+            uint32_t f_lo = 0, f_hi = 0;
+            for (int k = 0; k < 4; k++) {
+                if (L - 8 + k >= 0) f_lo |= (uint32_t)(uint8_t)s[L - 8 + k] << (8 * k);
+                if (L - 12 + k >= 0) f_hi |= (uint32_t)(uint8_t)s[L - 12 + k] << (8 * k);
+            }
+            fp_items.back().val[i] = (uint8_t)scan2_fpt_byte(scan2_fpt_code((uint32_t)L), key, f_lo, f_hi);
         }
     }
+    {
+        std::vector<uint32_t> owner(kScan2FptSize, 0);
+        std::vector<uint8_t> pinned(kScan2FptSize, 0);     // cells of two-term buckets cannot be displaced
+        // two-term buckets first (they have no freedom), then the one-term buckets by random-walk cuckoo
+        for (const FpItem& it : fp_items) {
+            const uint32_t c0 = scan2_fpt_cell(it.key, 0), c1 = scan2_fpt_cell(it.key, 1);
+            if (it.n >= 3 || (it.n == 2 && c0 == c1)) { homeless.push_back(it.key); continue; }
+            if (it.n != 2) continue;
+            if (t.fpt[c0] == 0 && t.fpt[c1] == 0) {
+                t.fpt[c0] = it.val[0]; t.fpt[c1] = it.val[1];
+                pinned[c0] = pinned[c1] = 1;
+            } else {
+                homeless.push_back(it.key);
+            }
+        }
+        uint32_t rng = 0x12345u;
+        for (const FpItem& it : fp_items) {
+            if (it.n != 1) continue;
+            uint32_t ck = it.key;
+            uint8_t cv = it.val[0];
+            bool placed = false;
+            for (int kick = 0; kick < 500 && !placed; kick++) {
+                const uint32_t c0 = scan2_fpt_cell(ck, 0), c1 = scan2_fpt_cell(ck, 1);
+                if (t.fpt[c0] == 0) { t.fpt[c0] = cv; owner[c0] = ck; placed = true; break; }
+                if (t.fpt[c1] == 0) { t.fpt[c1] = cv; owner[c1] = ck; placed = true; break; }
+                rng = rng * 1664525u + 1013904223u;
+                uint32_t victim = (rng >> 16) & 1 ? c1 : c0;
+                if (pinned[victim]) victim = victim == c0 ? c1 : c0;
+                if (pinned[victim]) break;                      // both cells belong to two-term buckets
+                std::swap(cv, t.fpt[victim]);
+                std::swap(ck, owner[victim]);
+            }
+            if (!placed) homeless.push_back(ck);
+        }
+    }
+    // keys the cuckoo walk could not place: their first cell passes everything (set last, nothing moves any more)
+    for (uint32_t k : homeless) t.fpt[scan2_fpt_cell(k, 0)] = kScan2FptAmbiguous;
     t.term_blob.insert(t.term_blob.end(), 8, 0);
     t.term_off.push_back((uint32_t)t.term_blob.size());
     if (t.more.empty()) t.more.push_back(Scan2Entry{0, 0, 0, 0});

@@ -322,11 +322,12 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         }
         {
             ProfScope ps(e, "scan");
-            // process path: matches in any order -> gft_scan3 (coalesced rounds, candidates resolved from registers);
-            // CSR path, or no class-0 byte to stand in for "before the document": gft_scan2 (text order)
+            // gft_scan2 serves both paths (ordered for CSR results, unordered + balanced for the solver).
+            // GFT_SCAN_KERNEL=rounds selects gft_scan3 for the process path (coalesced 1 KiB rounds, text in LDS: 2.8x
+            // fewer L2 requests but more instructions -- measured 15 % slower on MI355X, kept as a tested alternative)
             const int pad = P.fold ? e->s2.pad_byte_fold : e->s2.pad_byte;
             const char* k3 = getenv("GFT_SCAN_KERNEL");
-            if (!need_csr && pad >= 0 && !(k3 && std::string(k3) == "window2")) {
+            if (!need_csr && pad >= 0 && k3 && std::string(k3) == "rounds") {
                 P.pad_byte = (uint32_t)pad;
                 HIP_TRY(launch_scan3(P, e->scan2_waves, e->n_cus, st), "scan kernel launch");
             } else {

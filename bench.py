@@ -145,7 +145,7 @@ def main():
     if rank == 0 and world == 1 and args.cpu_docs != 0:
         cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         cores = min(cores, args.cpu_threads)      # a 1-GPU box's CPU share is 16 cores
-        n_cpu = args.cpu_docs if args.cpu_docs > 0 else min(args.docs, 4000 * cores)
+        n_cpu = args.cpu_docs if args.cpu_docs > 0 else min(args.docs, 24000 * cores)   # ~10-15 s of CPU work
         n_cpu = min(n_cpu, args.docs)
         c_off = doc_off[:n_cpu + 1].cpu().numpy().astype(np.uint64)
         c_text = text[:int(c_off[-1])].cpu().numpy()
@@ -175,7 +175,7 @@ def main():
             with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as fh:
                 pmc = json.load(fh)
             if pmc["config"] == {"docs": args.docs, "terms": args.terms, "exprs": args.exprs, "inord": args.inord}:
-                traffic = pmc["kernels"]["k_scan2"]["traffic_bytes"]
+                traffic = next(v["traffic_bytes"] for k, v in pmc["kernels"].items() if k.startswith("k_scan2"))
         except (OSError, KeyError, ValueError):
             pass
         out = {

@@ -85,7 +85,6 @@ constexpr uint32_t kScan2StageCap = 6;           // matches a lane can stage in 
 constexpr uint32_t kScan2FifoCap = 256;          // unordered path: matches of one unit buffered in LDS (>= 64 * kScan2StageCap)
 constexpr uint32_t kScan2CandCap = 856;          // unordered path: flagged positions of one unit listed in LDS
 constexpr uint32_t kScan2WaveLds = kScan2FifoCap * 8 + kScan2CandCap * 2 + 16;   // 3776 bytes per wave
-constexpr uint32_t kScan2Batch = 2;
 constexpr uint32_t kScan3TextBytes = 1040;        // gft_scan3: one round of text in LDS (8 bytes of history + 1 KiB)
 constexpr uint32_t kScan3ListCap = 320;           // gft_scan3: flagged positions of a round listed in LDS             // unordered path: flagged positions a lane verifies per trip
 constexpr uint32_t kScan2Slab = 4096;            // pool entries a wave reserves per global atomic

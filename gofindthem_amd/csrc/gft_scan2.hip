@@ -65,7 +65,7 @@ __device__ __forceinline__ uint32_t class_at(const Ctx& c, int64_t q) {
 }
 
 // ---- verification of one flagged position p, in three separable steps so that several candidates can have their
-// loads in flight together (the unordered path runs kScan2Batch candidates per lane at once) -------------------------
+// the cheap LDS-only decisions (stage A) and the L2 bucket probes (stage B) can run as separate, dense passes ------------
 
 // step 1: one 8-byte load brings the window (bytes p-3..p) and the 4 bytes in front of it (p-7..p-4)
 struct Cand { uint32_t p, x, tw, h, sid; bool wide, go_long; };
@@ -232,7 +232,8 @@ __device__ __forceinline__ void verify_masks(const Ctx& c, uint32_t my_lo, uint3
     }
 }
 
-template <bool HASHED>
+// ORDERED: matches of a unit leave in text order (CSR results); otherwise any order (solver input)
+template <bool HASHED, bool ORDERED>
 __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
     extern __shared__ __align__(16) uint8_t smem[];
     uint8_t* cls = smem;
@@ -334,7 +335,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
         }
         // ---- phase 2, unordered fast path (the solver does not need text order): balance the flagged positions over
         // the lanes through an LDS candidate list, append matches to an LDS fifo, flush the fifo coalesced ----------------
-        if (!P.ordered) {
+        if (!ORDERED) {
             const uint32_t f = __popc(m0) + __popc(m1) + __popc(m2) + __popc(m3);
             const uint32_t fincl = wave_incl_scan(f);
             const uint32_t ftotal = __shfl(fincl, 63, 64);
@@ -483,13 +484,14 @@ uint32_t scan2_pick_waves(uint32_t filter_words, uint32_t short3_bytes, size_t l
 hipError_t launch_scan2(const Scan2Params& P, uint32_t waves, unsigned n_cus, hipStream_t st) {
     if (!P.n_units) return hipSuccess;
     const size_t lds = scan2_lds_bytes(P.filter_words, P.short3_bytes, waves);
-    const void* fn = P.hashed ? reinterpret_cast<const void*>(k_scan2<true>) : reinterpret_cast<const void*>(k_scan2<false>);
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    using Kern = void (*)(const Scan2Params);
+    const Kern fn = P.hashed ? (P.ordered ? k_scan2<true, true> : k_scan2<true, false>)
+                             : (P.ordered ? k_scan2<false, true> : k_scan2<false, false>);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     uint64_t g = (P.n_units + waves - 1) / waves;
     const unsigned grid = (unsigned)(g < n_cus ? (g ? g : 1) : n_cus);
-    if (P.hashed) k_scan2<true><<<dim3(grid), dim3(waves * 64), lds, st>>>(P);
-    else k_scan2<false><<<dim3(grid), dim3(waves * 64), lds, st>>>(P);
+    fn<<<dim3(grid), dim3(waves * 64), lds, st>>>(P);
     return hipGetLastError();
 }
 

@@ -63,7 +63,6 @@ __device__ __forceinline__ void long_terms(const Out& o, const uint8_t* dbase, u
                                            uint32_t tw, uint4 slot) {
     const Scan2Params& P = o.P;
     uint32_t h = (x * kGoldDev) >> P.slot_shift;
-    if (P.dbg & 64) return;
     while (slot.x != x) {
         if (slot.x == kScan2EmptyKey) return;     // fingerprint / hashed-filter false positive
         h = (h + 1) & P.slot_mask;
@@ -82,7 +81,7 @@ __device__ __forceinline__ void long_terms(const Out& o, const uint8_t* dbase, u
     for (uint32_t j = 0;;) {
         const uint32_t L = e.y;
         bool ok = L <= p + 1 && ((tw ^ e.z) & e.w) == 0;
-        if (ok && L > 8 && !(P.dbg & 16)) {
+        if (ok && L > 8) {
             // the first L-8 bytes of the term against text[p+1-L .. p-8], four bytes at a time from the end; the loads
             // are independent.  term_blob has 4 bytes of slack before every term; the text needs 3 before the match.
             const uint8_t* tb = P.term_blob + P.term_off[e.x];
@@ -107,7 +106,7 @@ __device__ __forceinline__ void long_terms(const Out& o, const uint8_t* dbase, u
                 }
             }
         }
-        if (ok && !(P.dbg & 32)) emit(o, e.x, P.pos_end ? p : p + 1 - L);
+        if (ok) emit(o, e.x, P.pos_end ? p : p + 1 - L);
         if (++j >= n_ent) break;
         e = *reinterpret_cast<const uint4*>(&P.more[more_at + 1 + j]);
     }

@@ -342,9 +342,9 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         if (P.dbg & 2) {
             uint64_t c4[4] = {0, 0, 0, 0};
             HIP_TRY(hipMemcpy(c4, e->d_dbg.p, 32, hipMemcpyDeviceToHost), "debug readback");
-            fprintf(stderr, "[gft scan debug] units=%llu flagged=%llu sum_of_per_unit_max_lane=%llu matches=%llu\n",
+            fprintf(stderr, "[gft scan debug] units=%llu flagged=%llu sum_of_per_unit_max_lane=%llu to_bucket_table=%llu matches=%llu\n",
                     (unsigned long long)n_units, (unsigned long long)c4[0], (unsigned long long)c4[1],
-                    (unsigned long long)total);
+                    (unsigned long long)c4[2], (unsigned long long)total);
         }
         if (cursor <= e->pool_cap) break;
         if (attempt == 2) return fail(e, GFT_E_HIP, "match pool overflow persisted");

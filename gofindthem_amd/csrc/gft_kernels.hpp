@@ -119,39 +119,44 @@ struct Scan2Short {
 };
 constexpr uint32_t kScan2Short3Max = 32768;      // bytes of LDS a direct 3-window table may take (K' <= 32)
 constexpr uint32_t kScan2FptSize = 16384;        // one byte per hashed window key
-constexpr uint32_t kScan2FptShift = 32 - 14;
 constexpr uint32_t kScan2FptAmbiguous = 0xFF;    // several terms share the byte: always go to the bucket table
 // Fingerprint table: every window key that ends a term of length >= 4 owns ONE of its two candidate cells (cuckoo
-// placement at build time).  cell byte = code << 5 | fp5(key, the term's bytes in front of the window); code 1..7
-// says how many front bytes the fingerprint covers (0, 1, 2, 3, 4, 6, 8); 0 = empty cell; 0xFF = always go to the
-// bucket table.  Front bytes as loaded from the text: `f_lo` = text[p-7..p-4], `f_hi` = text[p-11..p-8] (little endian).
-// A position passes if either of its two cells passes.
+// placement at build time).  cell byte = code << 5 | fp5(key, the term's bytes in front of the window); code 1..5
+// says how many front bytes the fingerprint covers (0..4); 0 = empty cell; 0xFF = always go to the bucket table.
+// Front bytes as loaded from the text: `f_lo` = text[p-7..p-4] (little endian), case bit cleared on both sides so the
+// same table serves exact and ASCII-folded scans (the bucket table does the exact compare).  A position passes if
+// either of its two cells passes.  All hashing is 24-bit multiplies (v_mul_u32_u24 / v_mad_u32_u24: full rate).
 #if defined(__HIPCC__)
 #define GFT_HD __host__ __device__
 #else
 #define GFT_HD
 #endif
+GFT_HD inline uint32_t scan2_mul24(uint32_t a, uint32_t b) {           // low 32 bits of (a mod 2^24) * (b mod 2^24)
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(a, b);
+#else
+    return (uint32_t)((uint64_t)(a & 0xFFFFFFu) * (uint64_t)(b & 0xFFFFFFu));
+#endif
+}
 GFT_HD inline uint32_t scan2_fpt_cell(uint32_t x, int which) {
-    return (x * (which ? 0xC2B2AE35u : kGoldDev)) >> kScan2FptShift;
+    return scan2_mul24(x, which ? 0xB2AE35u : 0x3779B1u) >> 18;         // 14 bits
 }
 GFT_HD inline uint32_t scan2_fpt_code(uint32_t term_len) {            // term_len >= 4
     const uint32_t nf = term_len - 4;
-    return nf <= 4 ? nf + 1 : nf < 6 ? 5 : nf < 8 ? 6 : 7;
+    return nf < 4 ? nf + 1 : 5;
 }
-GFT_HD inline uint32_t scan2_fpt_byte(uint32_t code, uint32_t x, uint32_t f_lo, uint32_t f_hi) {
-    const uint32_t n = code <= 5 ? code - 1 : code == 6 ? 6 : 8;       // front bytes covered
-    const uint32_t m_lo = n >= 4 ? 0xFFFFFFFFu : n ? 0xFFFFFFFFu << (8 * (4 - n)) : 0u;
-    const uint32_t m_hi = n <= 4 ? 0u : n >= 8 ? 0xFFFFFFFFu : 0xFFFFFFFFu << (8 * (8 - n));
-    uint32_t h = (f_lo & m_lo) ^ (x * 0x27D4EB2Fu);
-    h = (h * 0x85EBCA6Bu) ^ ((f_hi & m_hi) * 0xC2B2AE3Du);
-    uint32_t fp = (h * 0x9E3779B1u) >> 27;
-    if (code == 7 && fp == 31) fp = 30;                                // 0xFF is the "ambiguous" marker
-    return code << 5 | fp;
+GFT_HD inline uint32_t scan2_fpt_xmix(uint32_t x) { return scan2_mul24(x, 0xD4EB2Fu); }
+GFT_HD inline uint32_t scan2_fpt_byte(uint32_t code, uint32_t xmix, uint32_t f_lo) {
+    // the n = code - 1 bytes next to the window, right-justified; n == 0 covers nothing
+    const uint32_t f = f_lo & 0xDFDFDFDFu;
+    const uint32_t a = code == 1 ? 0u : f >> ((40u - 8u * code) & 31u);
+    const uint32_t h = scan2_mul24(a ^ (a >> 11), 0xEBCA6Bu) + xmix;
+    return code << 5 | h >> 27;
 }
-GFT_HD inline bool scan2_fpt_pass(uint32_t cell, uint32_t x, uint32_t f_lo, uint32_t f_hi) {
+GFT_HD inline bool scan2_fpt_pass(uint32_t cell, uint32_t xmix, uint32_t f_lo) {
     if (cell == 0) return false;
     if (cell == kScan2FptAmbiguous) return true;
-    return scan2_fpt_byte(cell >> 5, x, f_lo, f_hi) == cell;
+    return scan2_fpt_byte(cell >> 5, xmix, f_lo) == cell;
 }
 
 struct Scan2Params {

@@ -49,6 +49,11 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
     return v;
 }
 
+// max over the wave of a value in 0..3
+__device__ __forceinline__ uint32_t wave_max3(uint32_t v) {
+    return __any(v >= 3) ? 3u : __any(v == 2) ? 2u : __any(v == 1) ? 1u : 0u;
+}
+
 struct Ctx {
     const Scan2Params& P;
     const uint8_t* cls;        // LDS
@@ -68,38 +73,39 @@ __device__ __forceinline__ uint32_t class_at(const Ctx& c, int64_t q) {
 // the cheap LDS-only decisions (stage A) and the L2 bucket probes (stage B) can run as separate, dense passes ------------
 
 // step 1: one 8-byte load brings the window (bytes p-3..p) and the 4 bytes in front of it (p-7..p-4)
-struct Cand { uint32_t p, x, tw, h, sid; bool wide, go_long; };
+struct Cand { uint32_t p, x, tw, h, sid; bool go_long; };
 __device__ __forceinline__ void cand_text(const Ctx& c, uint32_t p, Cand& k) {
     const Scan2Params& P = c.P;
     const uint32_t kp = P.kp;
     k.p = p;
-    k.wide = c.doc_abs + p >= 7;
-    k.tw = 0;
-    uint32_t x3;
-    if (k.wide) {
+    uint32_t tw, w;
+    const uint64_t ab = c.doc_abs + p;
+    if (__builtin_expect(ab >= 7, 1)) {
         const U64u v = *reinterpret_cast<const U64u*>(c.dbase + (int64_t)p - 7);
-        k.tw = P.fold ? fold4(v.lo) : v.lo;
-        const uint32_t w = v.hi;
-        const uint32_t c0 = p >= 3 ? c.cls[w & 0xFF] : P.pad_class, c1 = p >= 2 ? c.cls[(w >> 8) & 0xFF] : P.pad_class,
-                       c2 = p >= 1 ? c.cls[(w >> 16) & 0xFF] : P.pad_class;
-        x3 = (c1 * kp + c2) * kp + c.cls[w >> 24];
-        k.x = c0 * kp * kp * kp + x3;
-    } else {    // within 7 bytes of the blob start
-        x3 = (class_at(c, (int64_t)p - 2) * kp + class_at(c, (int64_t)p - 1)) * kp + c.cls[c.dbase[p]];
-        k.x = class_at(c, (int64_t)p - 3) * kp * kp * kp + x3;
+        tw = v.lo; w = v.hi;
+    } else {    // within 7 bytes of the blob start: bytes in front of the blob read as 0 (no term reaches them)
+        tw = 0; w = 0;
+        for (uint32_t i = 0; i <= (uint32_t)ab; i++) {        // oldest byte first; byte p ends up on top of w
+            tw = tw >> 8 | w << 24;
+            w = w >> 8 | (uint32_t)c.dbase[(int64_t)p - (int64_t)ab + i] << 24;
+        }
     }
+    k.tw = tw;          // raw: the fingerprint ignores the case bit, the bucket compare folds when asked to
+    uint32_t c0 = c.cls[w & 0xFF], c1 = c.cls[(w >> 8) & 0xFF], c2 = c.cls[(w >> 16) & 0xFF];
+    if (__builtin_expect(p < 3, 0)) {                         // positions before the document start
+        c0 = P.pad_class;
+        if (p < 2) c1 = P.pad_class;
+        if (p < 1) c2 = P.pad_class;
+    }
+    const uint32_t x3 = __umul24(__umul24(c1, kp) + c2, kp) + c.cls[w >> 24];
+    k.x = __umul24(c0, __umul24(__umul24(kp, kp), kp)) + x3;
     k.h = (k.x * kGoldDev) >> P.slot_shift;
     // LDS-only decisions: which short-term record ends here, and whether a term of length >= 4 can end here at all
     // (fingerprint of the bytes in front of the window) -- most flagged positions stop here without touching L2
     k.sid = c.short3 ? c.short3[x3] : 0;
     const uint32_t f0 = c.fpt[scan2_fpt_cell(k.x, 0)], f1 = c.fpt[scan2_fpt_cell(k.x, 1)];
-    if (c.doc_abs + p >= 11) {
-        uint32_t tw2 = load_u32_unaligned(c.dbase + (int64_t)p - 11);
-        if (P.fold) tw2 = fold4(tw2);
-        k.go_long = scan2_fpt_pass(f0, k.x, k.tw, tw2) || scan2_fpt_pass(f1, k.x, k.tw, tw2);
-    } else {
-        k.go_long = (f0 | f1) != 0;       // not enough bytes in front to fingerprint this close to the blob start
-    }
+    const uint32_t xm = scan2_fpt_xmix(k.x);
+    k.go_long = scan2_fpt_pass(f0, xm, tw) || scan2_fpt_pass(f1, xm, tw);
     if (P.dbg & 12) {           // timing studies (wrong results): 4 = no bucket-table access, 8 = no short-term records
         if (P.dbg & 4) k.go_long = false;
         if (P.dbg & 8) k.sid = 0;
@@ -112,21 +118,62 @@ __device__ __forceinline__ uint4 cand_slot(const Ctx& c, const Cand& k) {
     return *reinterpret_cast<const uint4*>(&c.P.slots[k.h]);
 }
 
-// step 3: all terms that end at p, longest first.  MODE 0: count and stage per lane in LDS (ordered path);
-// MODE 1: write to the pool at out_base; MODE 2: append to the wave's LDS fifo (unordered path).
-// PARTS: bit 0 = terms of length >= 4 (bucket table), bit 1 = terms of length <= 3 (short record)
-template <int MODE, int PARTS = 3>
+// does bucket entry e = {term_id, len, cmp_val, cmp_mask} end at k.p?  twf = the (folded) bytes p-7..p-4
+__device__ __forceinline__ bool entry_ok(const Ctx& c, const Cand& k, uint32_t twf, const uint4 e) {
+    const Scan2Params& P = c.P;
+    const uint32_t p = k.p, L = e.y;
+    bool ok = L <= p + 1 && ((twf ^ e.z) & e.w) == 0;          // len <= 4: mask 0
+    if (ok && L > 8) {
+        // the first L-8 bytes of the term against text[p+1-L .. p-8], four bytes at a time from the end;
+        // all loads are independent (no early exit), so they are in flight together.  term_blob carries 4
+        // bytes of slack in front of every term, the text side needs 3 bytes of slack before the match.
+        const uint8_t* tb = P.term_blob + P.term_off[e.x];
+        const uint8_t* tp = c.dbase + (int64_t)p + 1 - L;
+        const uint32_t n = L - 8;
+        if (c.doc_abs + p + 1 - L >= 3) {
+            uint32_t diff = 0;
+            for (uint32_t j = 0; j * 4 < n; j++) {
+                const int32_t at = (int32_t)n - 4 - (int32_t)(j * 4);       // may be -1..-3 for the last chunk
+                uint32_t tv = load_u32_unaligned(tp + at);
+                const uint32_t wv = load_u32_unaligned(tb + at);
+                if (P.fold) tv = fold4(tv);
+                const uint32_t mask = at >= 0 ? 0xFFFFFFFFu : 0xFFFFFFFFu << (8 * (uint32_t)(-at));
+                diff |= (tv ^ wv) & mask;
+            }
+            ok = diff == 0;
+        } else {
+            for (uint32_t i = 0; i < n && ok; i++) {
+                uint32_t b = tp[i];
+                if (P.fold) b = fold1(b);
+                ok = b == tb[i];
+            }
+        }
+    }
+    return ok;
+}
+
+// first probe result -> the slot holding key k.x (or "no such bucket"); returns false when the bucket does not exist
+__device__ __forceinline__ bool find_bucket(const Ctx& c, const Cand& k, uint4& slot) {
+    uint32_t h = k.h;
+    while (slot.x != k.x) {
+        if (slot.x == kScan2EmptyKey) return false;             // fingerprint / hashed-filter false positive
+        h = (h + 1) & c.P.slot_mask;
+        slot = *reinterpret_cast<const uint4*>(&c.P.slots[h]);
+    }
+    return true;
+}
+
+// step 3 (ordered path): all terms that end at p, longest first.  MODE 0: count and stage per lane in LDS;
+// MODE 1: write to the pool at out_base.
+template <int MODE>
 __device__ __forceinline__ void cand_finish(const Ctx& c, const Cand& k, uint4 slot, uint32_t& cnt, uint2* stage,
-                                            uint64_t out_base, uint32_t* fcnt) {
+                                            uint64_t out_base) {
     const Scan2Params& P = c.P;
     const uint32_t p = k.p;
     auto emit = [&](uint32_t term, uint32_t L) {
         const uint32_t pos = P.pos_end ? p : p + 1 - L;
         if (MODE == 0) {
             if (cnt < kScan2StageCap) stage[cnt * 64] = make_uint2(term, pos);
-        } else if (MODE == 2) {
-            const uint32_t idx = __hip_atomic_fetch_add(fcnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (idx < kScan2FifoCap) stage[idx] = make_uint2(term, pos);
         } else {
             P.pool_term[out_base + cnt] = term;
             P.pool_pos[out_base + cnt] = pos;
@@ -134,15 +181,9 @@ __device__ __forceinline__ void cand_finish(const Ctx& c, const Cand& k, uint4 s
         cnt++;
     };
     // ---- terms of length >= 4, longest first ---------------------------------------------------------------------
-    bool have = (PARTS & 1) && k.go_long;
-    uint32_t h = k.h;
-    while (have && slot.x != k.x) {
-        if (slot.x == kScan2EmptyKey) { have = false; break; }   // fingerprint / hashed-filter false positive
-        h = (h + 1) & P.slot_mask;
-        slot = *reinterpret_cast<const uint4*>(&P.slots[h]);
-    }
-    if (have) {
+    if (k.go_long && find_bucket(c, k, slot)) {
         // bucket entries as {term_id, len, cmp_val, cmp_mask}; the common one-entry bucket is the slot itself
+        const uint32_t twf = P.fold ? fold4(k.tw) : k.tw;
         const bool simple = (slot.w & kScan2Simple) != 0;
         uint32_t n_ent = 1, more_at = 0;
         uint4 e;
@@ -154,53 +195,13 @@ __device__ __forceinline__ void cand_finish(const Ctx& c, const Cand& k, uint4 s
             e = *reinterpret_cast<const uint4*>(&P.more[more_at + 1]);
         }
         for (uint32_t j = 0;;) {
-            const uint32_t L = e.y;
-            bool ok = L <= p + 1;
-            if (ok && L > 4) {
-                if (k.wide) {
-                    ok = ((k.tw ^ e.z) & e.w) == 0;
-                } else {                       // byte by byte
-                    for (uint32_t b4 = 0; b4 < 4 && ok; b4++)
-                        if ((e.w >> (8 * b4)) & 0xFF) {
-                            uint32_t b = c.dbase[(int64_t)p - 7 + b4];
-                            if (P.fold) b = fold1(b);
-                            ok = b == ((e.z >> (8 * b4)) & 0xFF);
-                        }
-                }
-                if (ok && L > 8) {
-                    // the first L-8 bytes of the term against text[p+1-L .. p-8], four bytes at a time from the end;
-                    // all loads are independent (no early exit), so they are in flight together.  term_blob carries 4
-                    // bytes of slack in front of every term, the text side needs 3 bytes of slack before the match.
-                    const uint8_t* tb = P.term_blob + P.term_off[e.x];
-                    const uint8_t* tp = c.dbase + (int64_t)p + 1 - L;
-                    const uint32_t n = L - 8;
-                    if (c.doc_abs + p + 1 - L >= 3) {
-                        uint32_t diff = 0;
-                        for (uint32_t j = 0; j * 4 < n; j++) {
-                            const int32_t at = (int32_t)n - 4 - (int32_t)(j * 4);       // may be -1..-3 for the last chunk
-                            uint32_t tv = load_u32_unaligned(tp + at);
-                            const uint32_t wv = load_u32_unaligned(tb + at);
-                            if (P.fold) tv = fold4(tv);
-                            const uint32_t mask = at >= 0 ? 0xFFFFFFFFu : 0xFFFFFFFFu << (8 * (uint32_t)(-at));
-                            diff |= (tv ^ wv) & mask;
-                        }
-                        ok = diff == 0;
-                    } else {
-                        for (uint32_t i = 0; i < n && ok; i++) {
-                            uint32_t b = tp[i];
-                            if (P.fold) b = fold1(b);
-                            ok = b == tb[i];
-                        }
-                    }
-                }
-            }
-            if (ok) emit(e.x, L);
+            if (entry_ok(c, k, twf, e)) emit(e.x, e.y);
             if (++j >= n_ent) break;
             e = *reinterpret_cast<const uint4*>(&P.more[more_at + 1 + j]);
         }
     }
     // ---- terms of length <= 3 (record from the LDS 3-window table; the record array is tiny and L1 resident) -----------
-    if ((PARTS & 2) && k.sid) {
+    if (k.sid) {
         const Scan2Short r = P.shorts[k.sid];
 #pragma unroll
         for (uint32_t j = 0; j < 3; j++)
@@ -208,12 +209,62 @@ __device__ __forceinline__ void cand_finish(const Ctx& c, const Cand& k, uint4 s
     }
 }
 
+// ---- unordered path: matches go to the wave's LDS fifo.  `nf` (matches so far) is wave-uniform: every append happens
+// in wave-uniform control flow, lanes that have something to append take consecutive cells (ballot + mbcnt) -------------
+__device__ __forceinline__ void fifo_append(bool em, uint32_t term, uint32_t pos, uint2* fifo, uint32_t& nf) {
+    const uint64_t mask = __ballot(em);
+    if (em) {
+        const uint32_t idx = nf + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+        if (idx < kScan2FifoCap) fifo[idx] = make_uint2(term, pos);
+    }
+    nf += (uint32_t)__popcll(mask);
+}
+
+// terms of length <= 3 ending at the lanes' positions (sid = 0: none); wave-uniform call
+__device__ __forceinline__ void finish_short(const Ctx& c, uint32_t p, uint32_t sid, uint2* fifo, uint32_t& nf) {
+    const Scan2Params& P = c.P;
+    if (!__any(sid != 0)) return;
+    Scan2Short r;
+    r.n = 0;
+    if (sid) r = P.shorts[sid];
+    const uint32_t nmax = (uint32_t)__builtin_amdgcn_readfirstlane(wave_max3(r.n));
+    for (uint32_t j = 0; j < nmax; j++) {
+        const uint32_t L = j == 0 ? r.len[0] : j == 1 ? r.len[1] : r.len[2];
+        const uint32_t t = j == 0 ? r.term[0] : j == 1 ? r.term[1] : r.term[2];
+        fifo_append(j < r.n && L <= p + 1, t, P.pos_end ? p : p + 1 - L, fifo, nf);
+    }
+}
+
+// terms of length >= 4 ending at the lanes' positions (`on`: this lane has a candidate); wave-uniform call
+__device__ __forceinline__ void finish_long(const Ctx& c, bool on, const Cand& k, uint4 slot, uint2* fifo, uint32_t& nf) {
+    const Scan2Params& P = c.P;
+    bool have = on && k.go_long && find_bucket(c, k, slot);
+    uint32_t n_ent = 0, more_at = 0, twf = 0;
+    uint4 e = make_uint4(0, 0, 0, 0);
+    if (have) {
+        twf = P.fold ? fold4(k.tw) : k.tw;
+        if (slot.w & kScan2Simple) {
+            n_ent = 1;
+            e = make_uint4(slot.w & 0x7FFFFFu, (slot.w >> 23) & 0xFFu, slot.y, slot.z);
+        } else {
+            more_at = slot.w;
+            n_ent = P.more[more_at].term_id;
+            e = *reinterpret_cast<const uint4*>(&P.more[more_at + 1]);
+        }
+    }
+    for (uint32_t j = 0; __any(j < n_ent); j++) {
+        const bool act = j < n_ent;
+        const bool ok = act && entry_ok(c, k, twf, e);
+        fifo_append(ok, e.x, P.pos_end ? k.p : k.p + 1 - e.y, fifo, nf);
+        if (j + 1 < n_ent) e = *reinterpret_cast<const uint4*>(&P.more[more_at + 2 + j]);
+    }
+}
+
 template <int MODE>
-__device__ __forceinline__ void verify(const Ctx& c, uint32_t p, uint32_t& cnt, uint2* stage, uint64_t out_base,
-                                       uint32_t* fcnt) {
+__device__ __forceinline__ void verify(const Ctx& c, uint32_t p, uint32_t& cnt, uint2* stage, uint64_t out_base) {
     Cand k;
     cand_text(c, p, k);
-    if (k.go_long || k.sid) cand_finish<MODE>(c, k, cand_slot(c, k), cnt, stage, out_base, fcnt);
+    if (k.go_long || k.sid) cand_finish<MODE>(c, k, cand_slot(c, k), cnt, stage, out_base);
 }
 
 template <int MODE>
@@ -226,7 +277,7 @@ __device__ __forceinline__ void verify_masks(const Ctx& c, uint32_t my_lo, uint3
             if (mk) {
                 const uint32_t i = __builtin_ctz(mk);
                 mk &= mk - 1;
-                verify<MODE>(c, my_lo + 32 * k + i, cnt, stage, out_base, nullptr);
+                verify<MODE>(c, my_lo + 32 * k + i, cnt, stage, out_base);
             }
         }
     }
@@ -257,7 +308,6 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
     uint2* fifo = reinterpret_cast<uint2*>(wave_lds);
     uint2* stage = fifo + lane;                                   // ordered path: entry k of this lane is stage[k * 64]
     uint16_t* cand = reinterpret_cast<uint16_t*>(wave_lds + kScan2FifoCap * 8);
-    uint32_t* fcnt = reinterpret_cast<uint32_t*>(wave_lds + kScan2FifoCap * 8 + kScan2CandCap * 2);
     const uint32_t kp = P.kp, kp2 = kp * kp, kp3 = kp2 * kp;
 
     uint64_t slab_next = 0, wave_matches = 0;   // wave-uniform
@@ -341,8 +391,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
             const uint32_t ftotal = __shfl(fincl, 63, 64);
             bool done = ftotal == 0;
             if (ftotal) {
-                if (lane == 0) *fcnt = 0;
-                uint32_t dummy = 0;
+                uint32_t nf = 0;                                   // matches in the fifo (wave-uniform)
                 // passes over lane ranges whose flagged positions fit the LDS list (one pass for a typical unit)
                 for (uint32_t l0 = 0; l0 < 64;) {
                     const uint32_t before = l0 ? __shfl(fincl, (int)l0 - 1, 64) : 0;
@@ -375,10 +424,10 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
                         const uint32_t i = i0 + lane;
                         const bool on = i < ptotal;
                         Cand k;
-                        k.go_long = false; k.sid = 0;
+                        k.go_long = false; k.sid = 0; k.p = 0;
                         uint32_t rel = 0;
                         if (on) { rel = cand[i]; cand_text(c, un.lo + rel, k); }
-                        if (on && k.sid) cand_finish<2, 2>(c, k, make_uint4(0, 0, 0, 0), dummy, fifo, 0, fcnt);
+                        finish_short(c, k.p, k.sid, fifo, nf);
                         const uint64_t sb = __ballot(on && k.go_long);
                         if (on && k.go_long) cand[ns + __popcll(sb & ((1ull << lane) - 1))] = (uint16_t)rel;
                         ns += (uint32_t)__popcll(sb);
@@ -386,21 +435,23 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (P.dbg & 2) { if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(P.dbg_counters + 2), (unsigned long long)ns); }
                     // stage B: the survivors, densely packed over the lanes, go to the L2 bucket table
                     for (uint32_t i0 = 0; i0 < ns; i0 += 64) {
                         const uint32_t i = i0 + lane;
-                        if (i < ns) {
-                            Cand k;
-                            cand_text(c, un.lo + cand[i], k);
-                            if (k.go_long) cand_finish<2, 1>(c, k, cand_slot(c, k), dummy, fifo, 0, fcnt);
-                        }
+                        const bool on = i < ns;
+                        Cand k;
+                        k.go_long = false; k.p = 0; k.x = 0; k.h = 0; k.tw = 0;
+                        uint4 slot = make_uint4(kScan2EmptyKey, 0, 0, 0);
+                        if (on) { cand_text(c, un.lo + cand[i], k); slot = cand_slot(c, k); }
+                        finish_long(c, on, k, slot, fifo, nf);
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     l0 = l1;
                 }
-                const uint32_t nh = *fcnt;
+                const uint32_t nh = nf;
                 if (nh <= kScan2FifoCap) {
                     if (nh > slab_left) {
                         const uint32_t want = nh > P.slab ? nh : P.slab;

@@ -272,8 +272,9 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan3(const Scan2Params P) {
                         context(q, tw, tw2, x, x3);
                         const uint32_t p = round_base + q;
                         const uint32_t sid = on && have_short ? short3[x3] : 0;
-                        const bool go0 = scan2_fpt_pass(fpt[scan2_fpt_cell(x, 0)], x, tw, tw2);
-                        const bool go1 = scan2_fpt_pass(fpt[scan2_fpt_cell(x, 1)], x, tw, tw2);
+                        const uint32_t xm = scan2_fpt_xmix(x);
+                        const bool go0 = scan2_fpt_pass(fpt[scan2_fpt_cell(x, 0)], xm, tw);
+                        const bool go1 = scan2_fpt_pass(fpt[scan2_fpt_cell(x, 1)], xm, tw);
                         bool go_long = on && (go0 || go1);
                         if (P.dbg & 4) go_long = false;
                         if (sid && !(P.dbg & 8)) {   // terms of length <= 3 (record array: tiny, L1 resident)

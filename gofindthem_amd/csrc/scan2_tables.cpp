@@ -135,15 +135,13 @@ void build_scan2_tables(const AcTables& ac, Scan2Tables& t) {
         // needs both of its cells (one fingerprint each); larger buckets pass everything.
         fp_items.push_back(FpItem{key, {0, 0}, (uint32_t)std::min<size_t>(v.size(), 3)});
         for (size_t i = 0; i < v.size() && i < 2; i++) {
-            // front bytes as a text load would see them: f_lo = term[L-8..L-4), f_hi = term[L-12..L-8)
+            // front bytes as a text load would see them: f_lo = term[L-8..L-4)
             const std::string& s = ac.terms[v[i].term_id];
             const int L = (int)s.size();
-            uint32_t f_lo = 0, f_hi = 0;
-            for (int k = 0; k < 4; k++) {
+            uint32_t f_lo = 0;
+            for (int k = 0; k < 4; k++)
                 if (L - 8 + k >= 0) f_lo |= (uint32_t)(uint8_t)s[L - 8 + k] << (8 * k);
-                if (L - 12 + k >= 0) f_hi |= (uint32_t)(uint8_t)s[L - 12 + k] << (8 * k);
-            }
-            fp_items.back().val[i] = (uint8_t)scan2_fpt_byte(scan2_fpt_code((uint32_t)L), key, f_lo, f_hi);
+            fp_items.back().val[i] = (uint8_t)scan2_fpt_byte(scan2_fpt_code((uint32_t)L), scan2_fpt_xmix(key), f_lo);
         }
     }
     {

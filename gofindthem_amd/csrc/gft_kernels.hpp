@@ -131,26 +131,31 @@ constexpr uint32_t kScan2FptAmbiguous = 0xFF;    // several terms share the byte
 #else
 #define GFT_HD
 #endif
-GFT_HD inline uint32_t scan2_mul24(uint32_t a, uint32_t b) {           // low 32 bits of (a mod 2^24) * (b mod 2^24)
+// low 32 bits of (a mod 2^24) * (C mod 2^24).  On the device this must be v_mul_u32_u24 (full rate); the compiler
+// tends to pick the quarter-rate v_mul_lo_u32 for the generic form, hence the explicit instruction.
+template <uint32_t C>
+GFT_HD inline uint32_t scan2_mul24c(uint32_t a) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __umul24(a, b);
+    uint32_t d;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(d) : "n"(C), "v"(a));
+    return d;
 #else
-    return (uint32_t)((uint64_t)(a & 0xFFFFFFu) * (uint64_t)(b & 0xFFFFFFu));
+    return (uint32_t)((uint64_t)(a & 0xFFFFFFu) * (uint64_t)(C & 0xFFFFFFu));
 #endif
 }
-GFT_HD inline uint32_t scan2_fpt_cell(uint32_t x, int which) {
-    return scan2_mul24(x, which ? 0xB2AE35u : 0x3779B1u) >> 18;         // 14 bits
+GFT_HD inline uint32_t scan2_fpt_cell(uint32_t x, int which) {          // 14 bits
+    return (which ? scan2_mul24c<0xB2AE35u>(x) : scan2_mul24c<0x3779B1u>(x)) >> 18;
 }
 GFT_HD inline uint32_t scan2_fpt_code(uint32_t term_len) {            // term_len >= 4
     const uint32_t nf = term_len - 4;
     return nf < 4 ? nf + 1 : 5;
 }
-GFT_HD inline uint32_t scan2_fpt_xmix(uint32_t x) { return scan2_mul24(x, 0xD4EB2Fu); }
+GFT_HD inline uint32_t scan2_fpt_xmix(uint32_t x) { return scan2_mul24c<0xD4EB2Fu>(x); }
 GFT_HD inline uint32_t scan2_fpt_byte(uint32_t code, uint32_t xmix, uint32_t f_lo) {
     // the n = code - 1 bytes next to the window, right-justified; n == 0 covers nothing
     const uint32_t f = f_lo & 0xDFDFDFDFu;
     const uint32_t a = code == 1 ? 0u : f >> ((40u - 8u * code) & 31u);
-    const uint32_t h = scan2_mul24(a ^ (a >> 11), 0xEBCA6Bu) + xmix;
+    const uint32_t h = scan2_mul24c<0xEBCA6Bu>(a ^ (a >> 11)) + xmix;
     return code << 5 | h >> 27;
 }
 GFT_HD inline bool scan2_fpt_pass(uint32_t cell, uint32_t xmix, uint32_t f_lo) {

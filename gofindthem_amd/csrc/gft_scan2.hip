@@ -27,6 +27,16 @@ struct __attribute__((packed, aligned(1))) U128u { uint32_t x, y, z, w; };
 struct __attribute__((packed, aligned(1))) U64u { uint32_t lo, hi; };
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+// a * b + c on 24-bit operands: one full-rate instruction (the compiler's own choice is v_mul_lo_u32 / v_mad_u64_u32)
+__device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t d;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+// LDS tables at fixed addresses (the kernel's only LDS object is the dynamic array, which starts at 0; checked at
+// kernel entry): constant bases fold into the ds_read offset field
+typedef __attribute__((address_space(3))) const uint8_t lds_u8;
+typedef __attribute__((address_space(3))) const uint32_t lds_u32;
 __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p) { return reinterpret_cast<const U32u*>(p)->v; }
 
 // ASCII lower-casing of four packed bytes (finder/finder.go:140-142 for ASCII text)
@@ -62,6 +72,7 @@ struct Ctx {
     const uint8_t* fpt;        // LDS
     const uint8_t* dbase;      // first byte of the document
     uint64_t doc_abs;          // offset of the document inside the text blob
+    uint32_t kp2;              // kp * kp
 };
 
 // class of document position q (may be negative: before the document start)
@@ -97,8 +108,9 @@ __device__ __forceinline__ void cand_text(const Ctx& c, uint32_t p, Cand& k) {
         if (p < 2) c1 = P.pad_class;
         if (p < 1) c2 = P.pad_class;
     }
-    const uint32_t x3 = __umul24(__umul24(c1, kp) + c2, kp) + c.cls[w >> 24];
-    k.x = __umul24(c0, __umul24(__umul24(kp, kp), kp)) + x3;
+    const uint32_t lo = mad24(c2, kp, c.cls[w >> 24]);           // key = (c0 kp + c1) kp^2 + (c2 kp + c3)
+    const uint32_t x3 = mad24(c1, c.kp2, lo);
+    k.x = mad24(mad24(c0, kp, c1), c.kp2, lo);
     k.h = (k.x * kGoldDev) >> P.slot_shift;
     // LDS-only decisions: which short-term record ends here, and whether a term of length >= 4 can end here at all
     // (fingerprint of the bytes in front of the window) -- most flagged positions stop here without touching L2
@@ -308,7 +320,10 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
     uint2* fifo = reinterpret_cast<uint2*>(wave_lds);
     uint2* stage = fifo + lane;                                   // ordered path: entry k of this lane is stage[k * 64]
     uint16_t* cand = reinterpret_cast<uint16_t*>(wave_lds + kScan2FifoCap * 8);
-    const uint32_t kp = P.kp, kp2 = kp * kp, kp3 = kp2 * kp;
+    const uint32_t kp = P.kp, kp2 = kp * kp;
+    lds_u8* lcls = (lds_u8*)0;
+    lds_u32* lfilt = (lds_u32*)256;
+    if ((uint32_t)(uintptr_t)(lds_u8*)smem != 0) __builtin_trap();   // see lds_u8
 
     uint64_t slab_next = 0, wave_matches = 0;   // wave-uniform
     uint32_t slab_left = 0;
@@ -316,7 +331,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
     for (uint64_t u = (uint64_t)blockIdx.x * kWaves + wave; u < P.n_units; u += (uint64_t)gridDim.x * kWaves) {
         const Unit un = P.units[u];
         const uint64_t doc_abs = P.doc_off[un.doc];
-        const Ctx c{P, cls, filt, P.short3_bytes ? short3 : nullptr, fpt, P.text + doc_abs, doc_abs};
+        const Ctx c{P, cls, filt, P.short3_bytes ? short3 : nullptr, fpt, P.text + doc_abs, doc_abs, kp2};
         const uint32_t own = un.hi - un.lo;
         const uint32_t C = ((own + 63) / 64 + 3) & ~3u;            // bytes per lane (multiple of 4, <= 128)
         const uint32_t my_lo = un.lo + lane * C;
@@ -326,40 +341,46 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
         // ---- phase 1: filter ------------------------------------------------------------------------------
         uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
         if (own) {
-            uint32_t a1 = 0, a2 = 0, a3 = 0;
+            // running window key: x(i) = pair(i-2) * kp^2 + pair(i), pair(i) = class(i-1) * kp + class(i)
+            uint32_t cp = 0, pm1 = 0, pm2 = 0;
             if (nvalid) {
-                a1 = class_at(c, (int64_t)my_lo - 1) * kp;
-                a2 = class_at(c, (int64_t)my_lo - 2) * kp2;
-                a3 = class_at(c, (int64_t)my_lo - 3) * kp3;
+                const uint32_t k1 = class_at(c, (int64_t)my_lo - 1), k2 = class_at(c, (int64_t)my_lo - 2),
+                               k3 = class_at(c, (int64_t)my_lo - 3);
+                cp = k1; pm1 = k2 * kp + k1; pm2 = k3 * kp + k2;
             }
             uint32_t acc = 0;
-            const uint32_t npieces = (C + 15) >> 4;
+            const uint32_t ndw = C >> 2;                         // dwords per lane (wave-uniform, <= 32)
+            const uint32_t npieces = (ndw + 3) >> 2;
             const uint8_t* src = c.dbase + my_lo;
+            // the 16-byte piece q+1 is in flight while piece q is filtered
+            U128u nxt{0, 0, 0, 0};
+            if (nvalid) nxt = *reinterpret_cast<const U128u*>(src);
             for (uint32_t q = 0; q < npieces; q++) {
-                uint32_t w[4] = {0, 0, 0, 0};
-                if (q * 16 < nvalid) {
-                    const U128u v = *reinterpret_cast<const U128u*>(src + q * 16);
-                    w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-                }
+                const uint32_t w[4] = {nxt.x, nxt.y, nxt.z, nxt.w};
+                if (q + 1 < npieces && (q + 1) * 16 < nvalid) nxt = *reinterpret_cast<const U128u*>(src + (q + 1) * 16);
+                const uint32_t nd = ndw - 4 * q;                 // dwords of this piece that belong to the lane (>= 1)
 #pragma unroll
                 for (int d = 0; d < 4; d++) {
+                    if ((uint32_t)d < nd) {
 #pragma unroll
-                    for (int b = 0; b < 4; b++) {
-                        const uint32_t cl = cls[(w[d] >> (8 * b)) & 0xFF];
-                        const uint32_t x = a3 + a2 + a1 + cl;
-                        a3 = __umul24(a2, kp); a2 = __umul24(a1, kp); a1 = __umul24(cl, kp);
-                        const uint32_t fi = HASHED ? (x * kGoldDev) >> P.hash_shift : x;
-                        const uint32_t fw = filt[fi >> 5];
-                        acc = __builtin_amdgcn_alignbit(fw >> (fi & 31), acc, 1);
+                        for (int b = 0; b < 4; b++) {
+                            const uint32_t cl = lcls[(w[d] >> (8 * b)) & 0xFF];
+                            const uint32_t pair = mad24(cp, kp, cl);
+                            const uint32_t x = mad24(pm2, kp2, pair);
+                            pm2 = pm1; pm1 = pair; cp = cl;
+                            const uint32_t fi = HASHED ? (x * kGoldDev) >> P.hash_shift : x;
+                            const uint32_t fw = lfilt[fi >> 5];
+                            acc = __builtin_amdgcn_alignbit(fw >> (fi & 31), acc, 1);
+                        }
                     }
                 }
-                if (q & 1) {
+                if ((q & 1) && nd >= 4) {                        // 32 positions complete
                     if ((q >> 1) == 0) m0 = acc; else if ((q >> 1) == 1) m1 = acc; else if ((q >> 1) == 2) m2 = acc; else m3 = acc;
                 }
             }
-            if (npieces & 1) {
-                const uint32_t v = acc >> 16;
-                const uint32_t k = npieces >> 1;
+            if (ndw & 7) {                                       // the last, partial group of 32 positions
+                const uint32_t v = acc >> (32 - 4 * (ndw & 7));
+                const uint32_t k = ndw >> 3;
                 if (k == 0) m0 = v; else if (k == 1) m1 = v; else if (k == 2) m2 = v; else m3 = v;
             }
             // positions past the lane's range carry garbage flags

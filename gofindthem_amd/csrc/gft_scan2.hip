@@ -75,11 +75,6 @@ struct Ctx {
     uint32_t kp2;              // kp * kp
 };
 
-// class of document position q (may be negative: before the document start)
-__device__ __forceinline__ uint32_t class_at(const Ctx& c, int64_t q) {
-    return q >= 0 ? c.cls[c.dbase[q]] : c.P.pad_class;
-}
-
 // ---- verification of one flagged position p, in three separable steps so that several candidates can have their
 // the cheap LDS-only decisions (stage A) and the L2 bucket probes (stage B) can run as separate, dense passes ------------
 
@@ -328,9 +323,17 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
     uint64_t slab_next = 0, wave_matches = 0;   // wave-uniform
     uint32_t slab_left = 0;
 
-    for (uint64_t u = (uint64_t)blockIdx.x * kWaves + wave; u < P.n_units; u += (uint64_t)gridDim.x * kWaves) {
-        const Unit un = P.units[u];
-        const uint64_t doc_abs = P.doc_off[un.doc];
+    // the next unit's record and document offset are fetched while the current unit is processed
+    const uint64_t stride = (uint64_t)gridDim.x * kWaves;
+    uint64_t u = (uint64_t)blockIdx.x * kWaves + wave;
+    Unit un_n{0, 0, 0};
+    uint64_t abs_n = 0;
+    if (u < P.n_units) { un_n = P.units[u]; abs_n = P.doc_off[un_n.doc]; }
+    for (; u < P.n_units; u += stride) {
+        const Unit un = un_n;
+        const uint64_t doc_abs = abs_n;
+        const bool more_units = u + stride < P.n_units;
+        if (more_units) un_n = P.units[u + stride];
         const Ctx c{P, cls, filt, P.short3_bytes ? short3 : nullptr, fpt, P.text + doc_abs, doc_abs, kp2};
         const uint32_t own = un.hi - un.lo;
         const uint32_t C = ((own + 63) / 64 + 3) & ~3u;            // bytes per lane (multiple of 4, <= 128)
@@ -343,18 +346,22 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
         if (own) {
             // running window key: x(i) = pair(i-2) * kp^2 + pair(i), pair(i) = class(i-1) * kp + class(i)
             uint32_t cp = 0, pm1 = 0, pm2 = 0;
+            const uint8_t* src = c.dbase + my_lo;
+            U128u nxt{0, 0, 0, 0};
             if (nvalid) {
-                const uint32_t k1 = class_at(c, (int64_t)my_lo - 1), k2 = class_at(c, (int64_t)my_lo - 2),
-                               k3 = class_at(c, (int64_t)my_lo - 3);
-                cp = k1; pm1 = k2 * kp + k1; pm2 = k3 * kp + k2;
+                // the three bytes in front of the lane's range (one unaligned dword) and the first piece, together
+                uint32_t hist = 0;
+                if (doc_abs + my_lo >= 4) hist = load_u32_unaligned(src - 4);
+                else for (uint32_t i = 1; i <= 3 && i <= doc_abs + my_lo; i++) hist |= (uint32_t)src[-(int)i] << (32 - 8 * i);
+                nxt = *reinterpret_cast<const U128u*>(src);
+                const uint32_t k1 = my_lo >= 1 ? lcls[hist >> 24] : P.pad_class, k2 = my_lo >= 2 ? lcls[(hist >> 16) & 0xFF] : P.pad_class,
+                               k3 = my_lo >= 3 ? lcls[(hist >> 8) & 0xFF] : P.pad_class;
+                cp = k1; pm1 = mad24(k2, kp, k1); pm2 = mad24(k3, kp, k2);
             }
             uint32_t acc = 0;
             const uint32_t ndw = C >> 2;                         // dwords per lane (wave-uniform, <= 32)
             const uint32_t npieces = (ndw + 3) >> 2;
-            const uint8_t* src = c.dbase + my_lo;
             // the 16-byte piece q+1 is in flight while piece q is filtered
-            U128u nxt{0, 0, 0, 0};
-            if (nvalid) nxt = *reinterpret_cast<const U128u*>(src);
             for (uint32_t q = 0; q < npieces; q++) {
                 const uint32_t w[4] = {nxt.x, nxt.y, nxt.z, nxt.w};
                 if (q + 1 < npieces && (q + 1) * 16 < nvalid) nxt = *reinterpret_cast<const U128u*>(src + (q + 1) * 16);
@@ -389,6 +396,8 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
             m2 = nvalid >= 96 ? m2 : (nvalid > 64 ? m2 & ((1u << (nvalid - 64)) - 1) : 0);
             m3 = nvalid >= 128 ? m3 : (nvalid > 96 ? m3 & ((1u << (nvalid - 96)) - 1) : 0);
         }
+
+        if (more_units) abs_n = P.doc_off[un_n.doc];
 
         // ---- phase 2: verify flagged positions, stage matches in LDS ----------------------------------------
         uint32_t cnt = 0;

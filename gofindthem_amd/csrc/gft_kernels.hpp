@@ -83,8 +83,9 @@ struct SolveParams {
 constexpr uint32_t kScan2Threads = 1024;         // 16 waves per workgroup share one LDS copy of the filter
 constexpr uint32_t kScan2StageCap = 6;           // matches a lane can stage in LDS before the direct-write path
 constexpr uint32_t kScan2FifoCap = 256;          // unordered path: matches of one unit buffered in LDS (>= 64 * kScan2StageCap)
-constexpr uint32_t kScan2CandCap = 856;          // unordered path: flagged positions of one unit listed in LDS
-constexpr uint32_t kScan2WaveLds = kScan2FifoCap * 8 + kScan2CandCap * 2 + 16;   // 3776 bytes per wave
+constexpr uint32_t kScan2CandCapMin = 512;       // unordered path: flagged positions of one unit listed in LDS (the actual
+                                                 // capacity is whatever LDS is left, Scan2Params::cand_cap)
+constexpr uint32_t kScan2WaveLds = kScan2FifoCap * 8 + 856 * 2 + 16;   // gft_scan3: 3776 bytes per wave
 constexpr uint32_t kScan3TextBytes = 1040;        // gft_scan3: one round of text in LDS (8 bytes of history + 1 KiB)
 constexpr uint32_t kScan3ListCap = 320;           // gft_scan3: flagged positions of a round listed in LDS             // unordered path: flagged positions a lane verifies per trip
 constexpr uint32_t kScan2Slab = 4096;            // pool entries a wave reserves per global atomic
@@ -173,7 +174,10 @@ struct Scan2Params {
     uint32_t filter_words, hashed, hash_shift;
     const uint8_t* short3;       // [short3_bytes] record id per 3-window, copied to LDS (short3_bytes == 0: no short terms)
     uint32_t short3_bytes;
-    const Scan2Short* shorts;    // tiny, L1 resident
+    const Scan2Short* shorts;    // gft_scan3: tiny, L1 resident
+    const uint32_t* shorts_packed;   // gft_scan2: 3 words per record (term_id | len << 28, longest first, 0 = none), copied to LDS
+    uint32_t shorts_words;
+    uint32_t cand_cap;           // gft_scan2: entries of a wave's LDS candidate list (scan2_plan)
     const uint8_t* fpt;          // [kScan2FptSize], copied to LDS
     const Scan2Slot* slots;
     uint32_t slot_shift, slot_mask;
@@ -198,6 +202,9 @@ struct Scan2Params {
 size_t scan2_lds_bytes(uint32_t filter_words, uint32_t short3_bytes, uint32_t waves);
 // picks the largest workgroup (16, 12, 8 or 4 waves) whose LDS footprint fits lds_max; 0 if none does
 uint32_t scan2_pick_waves(uint32_t filter_words, uint32_t short3_bytes, size_t lds_max);
+// gft_scan2: waves per workgroup and candidate-list capacity that fit lds_max; false if nothing fits
+bool scan2_plan(uint32_t filter_words, uint32_t short3_bytes, uint32_t shorts_words, size_t lds_max, uint32_t* waves,
+                uint32_t* cand_cap);
 hipError_t launch_scan2(const Scan2Params& P, uint32_t waves, unsigned n_cus, hipStream_t st);
 hipError_t launch_scan3(const Scan2Params& P, uint32_t waves, unsigned n_cus, hipStream_t st);
 

@@ -59,17 +59,13 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
     return v;
 }
 
-// max over the wave of a value in 0..3
-__device__ __forceinline__ uint32_t wave_max3(uint32_t v) {
-    return __any(v >= 3) ? 3u : __any(v == 2) ? 2u : __any(v == 1) ? 1u : 0u;
-}
-
 struct Ctx {
     const Scan2Params& P;
     const uint8_t* cls;        // LDS
     const uint32_t* filt;      // LDS
     const uint8_t* short3;     // LDS (nullptr: the dictionary has no term shorter than the window)
     const uint8_t* fpt;        // LDS
+    const uint32_t* lrec;      // LDS: short-term records, 3 words each
     const uint8_t* dbase;      // first byte of the document
     uint64_t doc_abs;          // offset of the document inside the text blob
     uint32_t kp2;              // kp * kp
@@ -209,10 +205,11 @@ __device__ __forceinline__ void cand_finish(const Ctx& c, const Cand& k, uint4 s
     }
     // ---- terms of length <= 3 (record from the LDS 3-window table; the record array is tiny and L1 resident) -----------
     if (k.sid) {
-        const Scan2Short r = P.shorts[k.sid];
 #pragma unroll
-        for (uint32_t j = 0; j < 3; j++)
-            if (j < r.n && r.len[j] <= p + 1) emit(r.term[j], r.len[j]);
+        for (uint32_t j = 0; j < 3; j++) {
+            const uint32_t e = c.lrec[3 * k.sid + j];
+            if (e && (e >> 28) <= p + 1) emit(e & 0x0FFFFFFFu, e >> 28);
+        }
     }
 }
 
@@ -229,16 +226,14 @@ __device__ __forceinline__ void fifo_append(bool em, uint32_t term, uint32_t pos
 
 // terms of length <= 3 ending at the lanes' positions (sid = 0: none); wave-uniform call
 __device__ __forceinline__ void finish_short(const Ctx& c, uint32_t p, uint32_t sid, uint2* fifo, uint32_t& nf) {
-    const Scan2Params& P = c.P;
     if (!__any(sid != 0)) return;
-    Scan2Short r;
-    r.n = 0;
-    if (sid) r = P.shorts[sid];
-    const uint32_t nmax = (uint32_t)__builtin_amdgcn_readfirstlane(wave_max3(r.n));
-    for (uint32_t j = 0; j < nmax; j++) {
-        const uint32_t L = j == 0 ? r.len[0] : j == 1 ? r.len[1] : r.len[2];
-        const uint32_t t = j == 0 ? r.term[0] : j == 1 ? r.term[1] : r.term[2];
-        fifo_append(j < r.n && L <= p + 1, t, P.pos_end ? p : p + 1 - L, fifo, nf);
+    uint32_t r[3] = {0, 0, 0};
+    if (sid) { r[0] = c.lrec[3 * sid]; r[1] = c.lrec[3 * sid + 1]; r[2] = c.lrec[3 * sid + 2]; }
+#pragma unroll
+    for (uint32_t j = 0; j < 3; j++) {
+        if (j && !__any(r[j] != 0)) break;
+        const uint32_t L = r[j] >> 28;
+        fifo_append(r[j] != 0 && L <= p + 1, r[j] & 0x0FFFFFFFu, c.P.pos_end ? p : p + 1 - L, fifo, nf);
     }
 }
 
@@ -298,7 +293,8 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
     uint32_t* filt = reinterpret_cast<uint32_t*>(smem + 256);
     uint8_t* short3 = smem + 256 + (size_t)P.filter_words * 4;
     uint8_t* fpt = short3 + P.short3_bytes;
-    uint8_t* wave_lds_all = fpt + kScan2FptSize;
+    uint32_t* lrec = reinterpret_cast<uint32_t*>(fpt + kScan2FptSize);
+    uint8_t* wave_lds_all = reinterpret_cast<uint8_t*>(lrec) + ((P.shorts_words * 4 + 15) & ~15u);
 
     for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) cls[i] = P.cls[i];
     for (uint32_t i = threadIdx.x; i < P.filter_words; i += blockDim.x) filt[i] = P.filter[i];
@@ -306,12 +302,13 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
         reinterpret_cast<uint32_t*>(short3)[i] = reinterpret_cast<const uint32_t*>(P.short3)[i];
     for (uint32_t i = threadIdx.x; i < kScan2FptSize / 4; i += blockDim.x)
         reinterpret_cast<uint32_t*>(fpt)[i] = reinterpret_cast<const uint32_t*>(P.fpt)[i];
+    for (uint32_t i = threadIdx.x; i < P.shorts_words; i += blockDim.x) lrec[i] = P.shorts_packed[i];
     __syncthreads();
 
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     const uint32_t kWaves = blockDim.x >> 6;
-    // per-wave LDS region: [fifo / ordered staging: kScan2FifoCap x 8 B][candidate list: kScan2CandCap x 2 B][counter]
-    uint8_t* wave_lds = wave_lds_all + (size_t)wave * kScan2WaveLds;
+    // per-wave LDS region: [fifo / ordered staging: kScan2FifoCap x 8 B][candidate list: cand_cap x 2 B]
+    uint8_t* wave_lds = wave_lds_all + (size_t)wave * (kScan2FifoCap * 8 + P.cand_cap * 2);
     uint2* fifo = reinterpret_cast<uint2*>(wave_lds);
     uint2* stage = fifo + lane;                                   // ordered path: entry k of this lane is stage[k * 64]
     uint16_t* cand = reinterpret_cast<uint16_t*>(wave_lds + kScan2FifoCap * 8);
@@ -334,7 +331,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
         const uint64_t doc_abs = abs_n;
         const bool more_units = u + stride < P.n_units;
         if (more_units) un_n = P.units[u + stride];
-        const Ctx c{P, cls, filt, P.short3_bytes ? short3 : nullptr, fpt, P.text + doc_abs, doc_abs, kp2};
+        const Ctx c{P, cls, filt, P.short3_bytes ? short3 : nullptr, fpt, lrec, P.text + doc_abs, doc_abs, kp2};
         const uint32_t own = un.hi - un.lo;
         const uint32_t C = ((own + 63) / 64 + 3) & ~3u;            // bytes per lane (multiple of 4, <= 128)
         const uint32_t my_lo = un.lo + lane * C;
@@ -425,7 +422,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
                 // passes over lane ranges whose flagged positions fit the LDS list (one pass for a typical unit)
                 for (uint32_t l0 = 0; l0 < 64;) {
                     const uint32_t before = l0 ? __shfl(fincl, (int)l0 - 1, 64) : 0;
-                    const bool fits = lane >= l0 && fincl - before <= kScan2CandCap;
+                    const bool fits = lane >= l0 && fincl - before <= P.cand_cap;
                     const uint64_t fm = __ballot(fits) >> l0;
                     const uint32_t nl = fm == ~0ull >> l0 ? 64 - l0 : (uint32_t)__builtin_ctzll(~fm);   // lanes in this pass (>= 1)
                     const uint32_t l1 = l0 + nl;
@@ -552,7 +549,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
 
 }  // namespace
 
-size_t scan2_lds_bytes(uint32_t filter_words, uint32_t short3_bytes, uint32_t waves) {
+size_t scan2_lds_bytes(uint32_t filter_words, uint32_t short3_bytes, uint32_t waves) {      // gft_scan3 layout
     return 256 + (size_t)filter_words * 4 + short3_bytes + kScan2FptSize + (size_t)waves * kScan2WaveLds;
 }
 
@@ -562,9 +559,28 @@ uint32_t scan2_pick_waves(uint32_t filter_words, uint32_t short3_bytes, size_t l
     return 0;
 }
 
+static size_t scan2_fixed_lds(uint32_t filter_words, uint32_t short3_bytes, uint32_t shorts_words) {
+    return 256 + (size_t)filter_words * 4 + short3_bytes + kScan2FptSize + (((size_t)shorts_words * 4 + 15) & ~(size_t)15);
+}
+
+bool scan2_plan(uint32_t filter_words, uint32_t short3_bytes, uint32_t shorts_words, size_t lds_max, uint32_t* waves,
+                uint32_t* cand_cap) {
+    const size_t fixed = scan2_fixed_lds(filter_words, short3_bytes, shorts_words);
+    for (uint32_t w : {16u, 12u, 8u, 4u}) {
+        if (fixed + (size_t)w * (kScan2FifoCap * 8 + kScan2CandCapMin * 2) > lds_max) continue;
+        size_t per = ((lds_max - fixed) / w) & ~(size_t)15;
+        size_t cap = (per - kScan2FifoCap * 8) / 2;
+        *waves = w;
+        *cand_cap = (uint32_t)(cap > 4096 ? 4096 : cap);
+        return true;
+    }
+    return false;
+}
+
 hipError_t launch_scan2(const Scan2Params& P, uint32_t waves, unsigned n_cus, hipStream_t st) {
     if (!P.n_units) return hipSuccess;
-    const size_t lds = scan2_lds_bytes(P.filter_words, P.short3_bytes, waves);
+    const size_t lds = scan2_fixed_lds(P.filter_words, P.short3_bytes, P.shorts_words) +
+                       (size_t)waves * (kScan2FifoCap * 8 + P.cand_cap * 2);
     using Kern = void (*)(const Scan2Params);
     const Kern fn = P.hashed ? (P.ordered ? k_scan2<true, true> : k_scan2<true, false>)
                              : (P.ordered ? k_scan2<false, true> : k_scan2<false, false>);

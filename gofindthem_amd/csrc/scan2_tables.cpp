@@ -102,6 +102,12 @@ void build_scan2_tables(const AcTables& ac, Scan2Tables& t) {
         }
     }
 
+    for (const Scan2Short& r : t.shorts)
+        for (uint32_t j = 0; j < 3; j++) {
+            if (j < r.n && r.term[j] >= (1u << 28)) { t.why_not = "term id too large for a short-term record"; return; }
+            t.shorts_packed.push_back(j < r.n ? r.term[j] | r.len[j] << 28 : 0u);
+        }
+
     // ---- slots (16 bytes) + fingerprint table ---------------------------------------------------------------------------------
     uint32_t lg = 10;
     while ((1ull << lg) < 4 * t.n_keys) lg++;   // load <= 0.25: a miss ends at the first probe most of the time

@@ -69,50 +69,63 @@ struct Ctx {
     const uint8_t* dbase;      // first byte of the document
     uint64_t doc_abs;          // offset of the document inside the text blob
     uint32_t kp2;              // kp * kp
+    bool near0;                // wave-uniform: the document starts within 7 bytes of the blob start
 };
 
 // ---- verification of one flagged position p, in three separable steps so that several candidates can have their
 // the cheap LDS-only decisions (stage A) and the L2 bucket probes (stage B) can run as separate, dense passes ------------
 
-// step 1: one 8-byte load brings the window (bytes p-3..p) and the 4 bytes in front of it (p-7..p-4)
+// step 1: one 8-byte load brings the window (bytes p-3..p) and the 4 bytes in front of it (p-7..p-4).
+// Positions before the document start need no special casing here: the bytes there (the previous document's, or
+// zeros in front of the blob) can only change keys of windows that reach across the start, and every term such a
+// window may name is longer than p + 1 and is dropped by the length check at emission.
 struct Cand { uint32_t p, x, tw, h, sid; bool go_long; };
-__device__ __forceinline__ void cand_text(const Ctx& c, uint32_t p, Cand& k) {
-    const Scan2Params& P = c.P;
-    const uint32_t kp = P.kp;
-    k.p = p;
-    uint32_t tw, w;
+struct Text8 { uint32_t tw, w; };
+__device__ __forceinline__ Text8 cand_load_slow(const Ctx& c, uint32_t p) {   // within 7 bytes of the blob start
+    Text8 t{0, 0};
     const uint64_t ab = c.doc_abs + p;
-    if (__builtin_expect(ab >= 7, 1)) {
+    if (ab >= 7) {
         const U64u v = *reinterpret_cast<const U64u*>(c.dbase + (int64_t)p - 7);
-        tw = v.lo; w = v.hi;
-    } else {    // within 7 bytes of the blob start: bytes in front of the blob read as 0 (no term reaches them)
-        tw = 0; w = 0;
+        t.tw = v.lo; t.w = v.hi;
+    } else {
         for (uint32_t i = 0; i <= (uint32_t)ab; i++) {        // oldest byte first; byte p ends up on top of w
-            tw = tw >> 8 | w << 24;
-            w = w >> 8 | (uint32_t)c.dbase[(int64_t)p - (int64_t)ab + i] << 24;
+            t.tw = t.tw >> 8 | t.w << 24;
+            t.w = t.w >> 8 | (uint32_t)c.dbase[(int64_t)p - (int64_t)ab + i] << 24;
         }
     }
-    k.tw = tw;          // raw: the fingerprint ignores the case bit, the bucket compare folds when asked to
-    uint32_t c0 = c.cls[w & 0xFF], c1 = c.cls[(w >> 8) & 0xFF], c2 = c.cls[(w >> 16) & 0xFF];
-    if (__builtin_expect(p < 3, 0)) {                         // positions before the document start
-        c0 = P.pad_class;
-        if (p < 2) c1 = P.pad_class;
-        if (p < 1) c2 = P.pad_class;
-    }
+    return t;
+}
+__device__ __forceinline__ Text8 cand_load(const Ctx& c, uint32_t p) {
+    if (__builtin_expect(c.near0, 0)) return cand_load_slow(c, p);        // wave-uniform: first document of the blob
+    const U64u v = *reinterpret_cast<const U64u*>(c.dbase + (int64_t)p - 7);
+    return Text8{v.lo, v.hi};
+}
+// window key, bucket hash and the short-term record id
+__device__ __forceinline__ void cand_keys(const Ctx& c, uint32_t p, const Text8 t, Cand& k) {
+    const uint32_t kp = c.P.kp, w = t.w;
+    k.p = p;
+    k.tw = t.tw;        // raw: the fingerprint ignores the case bit, the bucket compare folds when asked to
+    const uint32_t c0 = c.cls[w & 0xFF], c1 = c.cls[(w >> 8) & 0xFF], c2 = c.cls[(w >> 16) & 0xFF];
     const uint32_t lo = mad24(c2, kp, c.cls[w >> 24]);           // key = (c0 kp + c1) kp^2 + (c2 kp + c3)
     const uint32_t x3 = mad24(c1, c.kp2, lo);
     k.x = mad24(mad24(c0, kp, c1), c.kp2, lo);
-    k.h = (k.x * kGoldDev) >> P.slot_shift;
-    // LDS-only decisions: which short-term record ends here, and whether a term of length >= 4 can end here at all
-    // (fingerprint of the bytes in front of the window) -- most flagged positions stop here without touching L2
+    k.h = (k.x * kGoldDev) >> c.P.slot_shift;
     k.sid = c.short3 ? c.short3[x3] : 0;
+}
+// LDS-only decision: can a term of length >= 4 end here at all (fingerprint of the bytes in front of the window)?
+// Most flagged positions stop here without touching L2.
+__device__ __forceinline__ void cand_decide(const Ctx& c, Cand& k) {
     const uint32_t f0 = c.fpt[scan2_fpt_cell(k.x, 0)], f1 = c.fpt[scan2_fpt_cell(k.x, 1)];
     const uint32_t xm = scan2_fpt_xmix(k.x);
-    k.go_long = scan2_fpt_pass(f0, xm, tw) || scan2_fpt_pass(f1, xm, tw);
-    if (P.dbg & 12) {           // timing studies (wrong results): 4 = no bucket-table access, 8 = no short-term records
-        if (P.dbg & 4) k.go_long = false;
-        if (P.dbg & 8) k.sid = 0;
+    k.go_long = scan2_fpt_pass(f0, xm, k.tw) || scan2_fpt_pass(f1, xm, k.tw);
+    if (c.P.dbg & 12) {         // timing studies (wrong results): 4 = no bucket-table access, 8 = no short-term records
+        if (c.P.dbg & 4) k.go_long = false;
+        if (c.P.dbg & 8) k.sid = 0;
     }
+}
+__device__ __forceinline__ void cand_text(const Ctx& c, uint32_t p, Cand& k) {
+    cand_keys(c, p, cand_load(c, p), k);
+    cand_decide(c, k);
 }
 
 // step 2: the first probe of the bucket table
@@ -331,7 +344,8 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
         const uint64_t doc_abs = abs_n;
         const bool more_units = u + stride < P.n_units;
         if (more_units) un_n = P.units[u + stride];
-        const Ctx c{P, cls, filt, P.short3_bytes ? short3 : nullptr, fpt, lrec, P.text + doc_abs, doc_abs, kp2};
+        const Ctx c{P, cls, filt, P.short3_bytes ? short3 : nullptr, fpt, lrec, P.text + doc_abs, doc_abs, kp2,
+                    __builtin_amdgcn_readfirstlane((uint32_t)(doc_abs < 7)) != 0};
         const uint32_t own = un.hi - un.lo;
         const uint32_t C = ((own + 63) / 64 + 3) & ~3u;            // bytes per lane (multiple of 4, <= 128)
         const uint32_t my_lo = un.lo + lane * C;
@@ -446,17 +460,26 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     // stage A: every flagged position -> LDS-only decisions; short terms are emitted here, positions that may
                     // end a term of length >= 4 are compacted in place to the front of the list (write index <= read index)
+                    // (two candidates per lane and trip: their loads and table lookups are in flight together; lanes
+                    // past the end of the list work on a copy of entry 0 and stay silent)
                     uint32_t ns = 0;
-                    for (uint32_t i0 = 0; i0 < ptotal; i0 += 64) {
-                        const uint32_t i = i0 + lane;
-                        const bool on = i < ptotal;
-                        Cand k;
-                        k.go_long = false; k.sid = 0; k.p = 0;
-                        uint32_t rel = 0;
-                        if (on) { rel = cand[i]; cand_text(c, un.lo + rel, k); }
-                        finish_short(c, k.p, k.sid, fifo, nf);
-                        const uint64_t sb = __ballot(on && k.go_long);
-                        if (on && k.go_long) cand[ns + __popcll(sb & ((1ull << lane) - 1))] = (uint16_t)rel;
+                    for (uint32_t i0 = 0; i0 < ptotal; i0 += 128) {
+                        const uint32_t ia = i0 + lane, ib = ia + 64;
+                        const bool on_a = ia < ptotal, on_b = ib < ptotal;
+                        const uint32_t rel_a = cand[on_a ? ia : 0], rel_b = cand[on_b ? ib : 0];
+                        const uint32_t pa = un.lo + rel_a, pb = un.lo + rel_b;
+                        const Text8 ta = cand_load(c, pa), tb = cand_load(c, pb);
+                        Cand ka, kb;
+                        cand_keys(c, pa, ta, ka); cand_keys(c, pb, tb, kb);
+                        cand_decide(c, ka); cand_decide(c, kb);
+                        finish_short(c, pa, on_a ? ka.sid : 0, fifo, nf);
+                        finish_short(c, pb, on_b ? kb.sid : 0, fifo, nf);
+                        // all reads of this trip are done (ia, ib >= every write index below)
+                        const uint64_t sa = __ballot(on_a && ka.go_long), sb = __ballot(on_b && kb.go_long);
+                        const uint64_t below = (1ull << lane) - 1;
+                        if (on_a && ka.go_long) cand[ns + __popcll(sa & below)] = (uint16_t)rel_a;
+                        ns += (uint32_t)__popcll(sa);
+                        if (on_b && kb.go_long) cand[ns + __popcll(sb & below)] = (uint16_t)rel_b;
                         ns += (uint32_t)__popcll(sb);
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -464,14 +487,18 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     if (P.dbg & 2) { if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(P.dbg_counters + 2), (unsigned long long)ns); }
                     // stage B: the survivors, densely packed over the lanes, go to the L2 bucket table
-                    for (uint32_t i0 = 0; i0 < ns; i0 += 64) {
-                        const uint32_t i = i0 + lane;
-                        const bool on = i < ns;
-                        Cand k;
-                        k.go_long = false; k.p = 0; k.x = 0; k.h = 0; k.tw = 0;
-                        uint4 slot = make_uint4(kScan2EmptyKey, 0, 0, 0);
-                        if (on) { cand_text(c, un.lo + cand[i], k); slot = cand_slot(c, k); }
-                        finish_long(c, on, k, slot, fifo, nf);
+                    for (uint32_t i0 = 0; i0 < ns; i0 += 128) {
+                        const uint32_t ia = i0 + lane, ib = ia + 64;
+                        const bool on_a = ia < ns, on_b = ib < ns;
+                        const uint32_t pa = un.lo + cand[on_a ? ia : 0], pb = un.lo + cand[on_b ? ib : 0];
+                        const Text8 ta = cand_load(c, pa), tb = cand_load(c, pb);
+                        Cand ka, kb;
+                        cand_keys(c, pa, ta, ka); cand_keys(c, pb, tb, kb);
+                        ka.go_long = kb.go_long = true;
+                        const uint4 sla = *reinterpret_cast<const uint4*>(&P.slots[ka.h]);
+                        const uint4 slb = *reinterpret_cast<const uint4*>(&P.slots[kb.h]);
+                        finish_long(c, on_a, ka, sla, fifo, nf);
+                        if (i0 + 64 < ns) finish_long(c, on_b, kb, slb, fifo, nf);
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();

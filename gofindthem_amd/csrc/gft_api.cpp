@@ -61,9 +61,9 @@ struct gft_engine {
     Scan2Tables s2;
     bool use_scan2 = false;
     DevBuf d_s2_filter, d_s2_slots, d_s2_more, d_s2_cls, d_s2_cls_fold, d_s2_term_blob, d_s2_term_off, d_nmatches, d_dbg;
-    DevBuf d_s2_short3, d_s2_shorts, d_s2_shorts_packed, d_s2_fpt;
-    uint32_t scan2_waves = 0, scan2_short3_bytes = 0;   // scan2_waves: gft_scan3's workgroup size
-    uint32_t scan2_k2_waves = 0, scan2_cand_cap = 0;    // gft_scan2's (scan2_plan)
+    DevBuf d_s2_short3, d_s2_shorts_packed, d_s2_fpt;
+    uint32_t scan2_short3_bytes = 0;
+    uint32_t scan2_k2_waves = 0, scan2_cand_cap = 0;    // scan2_plan
 
     // programs
     bool have_programs = false;
@@ -297,11 +297,11 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         P.filter = e->d_s2_filter.as<uint32_t>(); P.filter_words = (uint32_t)e->s2.filter.size();
         P.hashed = e->s2.hashed ? 1 : 0; P.hash_shift = e->s2.hash_shift;
         P.short3 = e->d_s2_short3.as<uint8_t>(); P.short3_bytes = e->scan2_short3_bytes;
-        P.shorts = e->d_s2_shorts.as<Scan2Short>(); P.fpt = e->d_s2_fpt.as<uint8_t>();
+        P.fpt = e->d_s2_fpt.as<uint8_t>();
         P.shorts_packed = e->d_s2_shorts_packed.as<uint32_t>(); P.shorts_words = (uint32_t)e->s2.shorts_packed.size();
         P.cand_cap = e->scan2_cand_cap;
         P.slots = e->d_s2_slots.as<Scan2Slot>(); P.slot_shift = e->s2.slot_shift;
-        P.slot_mask = (uint32_t)e->s2.slots.size() - 1; P.more = e->d_s2_more.as<Scan2Entry>();
+        P.more = e->d_s2_more.as<Scan2Slot>();
         P.fold = (flags & GFT_FOLD_ASCII) ? 1 : 0;
         P.cls = P.fold ? e->d_s2_cls_fold.as<uint8_t>() : e->d_s2_cls.as<uint8_t>();
         P.term_blob = e->d_s2_term_blob.as<uint8_t>(); P.term_off = e->d_s2_term_off.as<uint32_t>();
@@ -312,7 +312,7 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         P.unit_start = e->d_unit_start.as<uint64_t>(); P.unit_count = e->d_unit_count.as<uint32_t>();
         P.n_matches = e->d_nmatches.as<uint64_t>();
         // slab slack is at most one slab per resident wave: keep it below half the pool
-        const uint64_t n_waves = (uint64_t)e->n_cus * std::max(e->scan2_waves, e->scan2_k2_waves);
+        const uint64_t n_waves = (uint64_t)e->n_cus * e->scan2_k2_waves;
         P.slab = (uint32_t)std::min<uint64_t>(kScan2Slab, std::max<uint64_t>(64, e->pool_cap / (2 * n_waves)));
         P.ordered = need_csr ? 1 : 0;   // the solver reads presence / successor positions: any order will do
         const char* dbg = getenv("GFT_SCAN_DEBUG");
@@ -325,18 +325,8 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         }
         {
             ProfScope ps(e, "scan");
-            // gft_scan2 serves both paths (ordered for CSR results, unordered + balanced for the solver).
-            // GFT_SCAN_KERNEL=rounds selects gft_scan3 for the process path (coalesced 1 KiB rounds, text in LDS: 2.8x
-            // fewer L2 requests but more instructions -- measured 15 % slower on MI355X, kept as a tested alternative)
-            const int pad = P.fold ? e->s2.pad_byte_fold : e->s2.pad_byte;
-            const char* k3 = getenv("GFT_SCAN_KERNEL");
-            if (!need_csr && pad >= 0 && e->scan2_waves && k3 && std::string(k3) == "rounds") {
-                P.pad_byte = (uint32_t)pad;
-                HIP_TRY(launch_scan3(P, e->scan2_waves, e->n_cus, st), "scan kernel launch");
-            } else {
-                P.pad_byte = 0;
-                HIP_TRY(launch_scan2(P, e->scan2_k2_waves, e->n_cus, st), "scan kernel launch");
-            }
+            // gft_scan2 serves both paths (ordered for CSR results, unordered + balanced for the solver)
+            HIP_TRY(launch_scan2(P, e->scan2_k2_waves, e->n_cus, st), "scan kernel launch");
         }
         uint64_t cursor = 0;
         HIP_TRY(hipMemcpyAsync(&cursor, e->d_cursor.p, 8, hipMemcpyDeviceToHost, st), "readback");
@@ -477,7 +467,7 @@ void gft_engine_destroy(gft_engine* e) {
         DevBuf* all[] = {&e->d_byte_class, &e->d_delta, &e->d_out_term, &e->d_out_link, &e->d_term_len, &e->d_prog,
                          &e->d_prog_off, &e->d_fprog, &e->d_fprog_off, &e->d_groups, &e->d_pscratch, &e->d_s2_filter,
                          &e->d_s2_slots, &e->d_s2_more, &e->d_s2_cls, &e->d_s2_cls_fold, &e->d_s2_term_blob,
-                         &e->d_s2_term_off, &e->d_nmatches, &e->d_dbg, &e->d_s2_short3, &e->d_s2_shorts, &e->d_s2_shorts_packed, &e->d_s2_fpt,
+                         &e->d_s2_term_off, &e->d_nmatches, &e->d_dbg, &e->d_s2_short3, &e->d_s2_shorts_packed, &e->d_s2_fpt,
 &e->d_unit_cnt, &e->d_unit_base, &e->d_units, &e->d_partial, &e->d_cursor,
                          &e->d_pool_term, &e->d_pool_pos, &e->d_unit_start, &e->d_unit_count, &e->d_unit_out,
                          &e->d_term, &e->d_pos, &e->d_match_off, &e->d_text, &e->d_doc_off, &e->d_bitmap, &e->d_xoff,
@@ -537,8 +527,6 @@ int gft_build(gft_engine* e, const uint8_t* terms_blob, const uint64_t* term_off
     // suffix-window tables (the fast path); GFT_SCAN_KERNEL=dfa forces the general two-tier DFA kernel
     build_scan2_tables(e->tab, e->s2);
     const char* force = getenv("GFT_SCAN_KERNEL");
-    e->scan2_waves = e->s2.supported ? scan2_pick_waves((uint32_t)e->s2.filter.size(), (uint32_t)e->s2.short3.size(),
-                                                         e->lds_max - 512) : 0;
     const bool k2_fits = e->s2.supported && scan2_plan((uint32_t)e->s2.filter.size(), (uint32_t)e->s2.short3.size(),
                                                         (uint32_t)e->s2.shorts_packed.size(), e->lds_max - 512,
                                                         &e->scan2_k2_waves, &e->scan2_cand_cap);
@@ -546,7 +534,7 @@ int gft_build(gft_engine* e, const uint8_t* terms_blob, const uint64_t* term_off
     if (e->use_scan2 && getenv("GFT_SCAN_DEBUG")) {
         size_t n_ff = 0, n_used = 0, n_simple = 0, n_slots = 0;
         for (uint8_t b : e->s2.fpt) { n_ff += b == 0xFF; n_used += b != 0; }
-        for (const auto& s : e->s2.slots) { n_slots += s.key != kScan2EmptyKey; n_simple += s.key != kScan2EmptyKey && (s.info & kScan2Simple); }
+        for (const auto& s : e->s2.slots) { n_slots += s.key != kScan2EmptyKey; n_simple += s.key != kScan2EmptyKey && !(s.info & kScan2Multi); }
         fprintf(stderr, "[gft build debug] kp=%u keys=%zu (simple %zu) slots=%zu fpt: used=%zu always-pass=%zu of %u; shorts=%zu filter=%s %u bits waves=%u\n",
                 e->s2.kp, n_slots, n_simple, e->s2.slots.size(), n_used, n_ff, kScan2FptSize, e->s2.shorts.size() - 1,
                 e->s2.hashed ? "hashed" : "direct", e->s2.filter_bits, e->scan2_k2_waves);
@@ -556,7 +544,6 @@ int gft_build(gft_engine* e, const uint8_t* terms_blob, const uint64_t* term_off
         e->scan2_short3_bytes = (uint32_t)e->s2.short3.size();
         if (e->s2.short3.empty()) e->s2.short3.assign(16, 0);   // placeholder upload; short3_bytes stays 0
         if ((rc = upload(e, e->d_s2_short3, e->s2.short3, "table upload"))) return rc;
-        if ((rc = upload(e, e->d_s2_shorts, e->s2.shorts, "table upload"))) return rc;
         if ((rc = upload(e, e->d_s2_shorts_packed, e->s2.shorts_packed, "table upload"))) return rc;
         if ((rc = upload(e, e->d_s2_fpt, e->s2.fpt, "table upload"))) return rc;
         std::vector<uint8_t> c1(e->s2.cls, e->s2.cls + 256), c2(e->s2.cls_fold, e->s2.cls_fold + 256);

@@ -79,38 +79,38 @@ struct SolveParams {
     uint32_t* bitmap;
 };
 
+#if defined(__HIPCC__)
+#define GFT_HD __host__ __device__
+#else
+#define GFT_HD
+#endif
+
 // ---- suffix-window scan (gft_scan2.hip; tables built by scan2_tables.cpp) ---------------------------------------
 constexpr uint32_t kScan2Threads = 1024;         // 16 waves per workgroup share one LDS copy of the filter
 constexpr uint32_t kScan2StageCap = 6;           // matches a lane can stage in LDS before the direct-write path
 constexpr uint32_t kScan2FifoCap = 256;          // unordered path: matches of one unit buffered in LDS (>= 64 * kScan2StageCap)
 constexpr uint32_t kScan2CandCapMin = 512;       // unordered path: flagged positions of one unit listed in LDS (the actual
                                                  // capacity is whatever LDS is left, Scan2Params::cand_cap)
-constexpr uint32_t kScan2WaveLds = kScan2FifoCap * 8 + 856 * 2 + 16;   // gft_scan3: 3776 bytes per wave
-constexpr uint32_t kScan3TextBytes = 1040;        // gft_scan3: one round of text in LDS (8 bytes of history + 1 KiB)
-constexpr uint32_t kScan3ListCap = 320;           // gft_scan3: flagged positions of a round listed in LDS             // unordered path: flagged positions a lane verifies per trip
 constexpr uint32_t kScan2Slab = 4096;            // pool entries a wave reserves per global atomic
 constexpr uint32_t kScan2UnitMax = 8192;         // bytes per work unit (128 per lane)
 constexpr uint32_t kGoldDev = 0x9E3779B1u;
 
-// one term of a bucket
-struct Scan2Entry {
-    uint32_t term_id;
-    uint32_t len;
-    uint32_t cmp_val;    // the (up to) 4 bytes in front of the window, as a little-endian load of text[p-7..p-4]
-    uint32_t cmp_mask;   // 0xFF per byte that exists (len >= 8: 0xFFFFFFFF; len <= 4: 0)
-};
-// hash-table slot, 16 bytes.  A bucket holding ONE entry (len <= 255, term id < 2^23) is fully described by the
-// slot (info = kScan2Simple | len << 23 | term_id, cmp_* = that entry's); otherwise info indexes `more`, where a
-// header {count} is followed by the bucket's entries, longest first.
-constexpr uint32_t kScan2EmptyKey = 0xFFFFFFFFu;   // never a window: the newest class of a window is never PAD
-constexpr uint32_t kScan2Simple = 0x80000000u;
-struct Scan2Slot {
+// Bucket table: window key -> the terms of length >= 4 that end with that window.  32-byte slots, two-choice (cuckoo)
+// placement: a key lives in slot h0(key) or h1(key), the kernel loads both at once, so a lookup is never a chain of
+// dependent probes.  A slot describes ONE term completely for lengths <= kScan2InlineLen: the bytes in front of the
+// window are stored the way the text loads see them, front[k] = text[p-7-4k .. p-4-4k] as a little-endian dword
+// (zero where the term has no byte); longer terms compare the rest against term_blob.  A bucket with several terms
+// has kScan2Multi set in `info`: the slot is then only a header, info & ~kScan2Multi indexes `more` (entries in the
+// same 32-byte format, longest first == the reference's emission order) and `len` is their count.
+constexpr uint32_t kScan2EmptyKey = 0xFFFFFFFFu;   // never a window key of a term (checked at build time)
+constexpr uint32_t kScan2Multi = 0x80000000u;
+constexpr uint32_t kScan2InlineLen = 24;           // 4 window bytes + 20 front bytes
+struct __attribute__((aligned(32))) Scan2Slot {
     uint32_t key;
-    uint32_t cmp_val;
-    uint32_t cmp_mask;
-    uint32_t info;
+    uint32_t info;       // one term: term_id (< 2^31); several: kScan2Multi | index into `more`
+    uint32_t len;        // one term: its length in bytes; several: number of entries
+    uint32_t front[5];
 };
-
 // short3 record: the (up to three) terms of length <= 3 that end at a 3-window, longest first
 struct Scan2Short {
     uint32_t n;
@@ -127,11 +127,6 @@ constexpr uint32_t kScan2FptAmbiguous = 0xFF;    // several terms share the byte
 // Front bytes as loaded from the text: `f_lo` = text[p-7..p-4] (little endian), case bit cleared on both sides so the
 // same table serves exact and ASCII-folded scans (the bucket table does the exact compare).  A position passes if
 // either of its two cells passes.  All hashing is 24-bit multiplies (v_mul_u32_u24 / v_mad_u32_u24: full rate).
-#if defined(__HIPCC__)
-#define GFT_HD __host__ __device__
-#else
-#define GFT_HD
-#endif
 // low 32 bits of (a mod 2^24) * (C mod 2^24).  On the device this must be v_mul_u32_u24 (full rate); the compiler
 // tends to pick the quarter-rate v_mul_lo_u32 for the generic form, hence the explicit instruction.
 template <uint32_t C>
@@ -143,6 +138,11 @@ GFT_HD inline uint32_t scan2_mul24c(uint32_t a) {
 #else
     return (uint32_t)((uint64_t)(a & 0xFFFFFFu) * (uint64_t)(C & 0xFFFFFFu));
 #endif
+}
+// the two candidate slots of a window key (table of 2^lg slots, shift = 32 - lg)
+GFT_HD inline uint32_t scan2_slot_hash(uint32_t x, int which, uint32_t shift) {
+    const uint32_t xf = x ^ (x >> 20);             // keys beyond 24 bits (hashed alphabets) keep their top bits in play
+    return (which ? scan2_mul24c<0x85EBCBu>(xf) : scan2_mul24c<0x9E3779u>(xf)) >> shift;
 }
 GFT_HD inline uint32_t scan2_fpt_cell(uint32_t x, int which) {          // 14 bits
     return (which ? scan2_mul24c<0xB2AE35u>(x) : scan2_mul24c<0x3779B1u>(x)) >> 18;
@@ -174,19 +174,17 @@ struct Scan2Params {
     uint32_t filter_words, hashed, hash_shift;
     const uint8_t* short3;       // [short3_bytes] record id per 3-window, copied to LDS (short3_bytes == 0: no short terms)
     uint32_t short3_bytes;
-    const Scan2Short* shorts;    // gft_scan3: tiny, L1 resident
-    const uint32_t* shorts_packed;   // gft_scan2: 3 words per record (term_id | len << 28, longest first, 0 = none), copied to LDS
+    const uint32_t* shorts_packed;   // 3 words per record (term_id | len << 28, longest first, 0 = none), copied to LDS
     uint32_t shorts_words;
-    uint32_t cand_cap;           // gft_scan2: entries of a wave's LDS candidate list (scan2_plan)
+    uint32_t cand_cap;           // entries of a wave's LDS candidate list (scan2_plan)
     const uint8_t* fpt;          // [kScan2FptSize], copied to LDS
-    const Scan2Slot* slots;
-    uint32_t slot_shift, slot_mask;
-    const Scan2Entry* more;
+    const Scan2Slot* slots;      // 2^lg slots, slot_shift = 32 - lg
+    uint32_t slot_shift;
+    const Scan2Slot* more;
     const uint8_t* cls;          // [256] byte -> class (the folded table when GFT_FOLD_ASCII)
     const uint8_t* term_blob;
     const uint32_t* term_off;
     uint32_t kp, pad_class, fold, pos_end;
-    uint32_t pad_byte;           // gft_scan3: a byte value of class 0 (stands in for positions before the document start)
     uint64_t* cursor;            // pool allocation cursor (entries, slab granular)
     uint64_t pool_cap;
     uint32_t* pool_term;
@@ -199,14 +197,10 @@ struct Scan2Params {
     uint32_t dbg;                // GFT_SCAN_DEBUG bits (timing studies only): 1 = skip verification, 2 = count flags
     uint64_t* dbg_counters;      // [4] when dbg & 2: flagged positions, table probes, entries compared, -
 };
-size_t scan2_lds_bytes(uint32_t filter_words, uint32_t short3_bytes, uint32_t waves);
-// picks the largest workgroup (16, 12, 8 or 4 waves) whose LDS footprint fits lds_max; 0 if none does
-uint32_t scan2_pick_waves(uint32_t filter_words, uint32_t short3_bytes, size_t lds_max);
-// gft_scan2: waves per workgroup and candidate-list capacity that fit lds_max; false if nothing fits
+// waves per workgroup (16, 12, 8 or 4) and candidate-list capacity that fit lds_max; false if nothing fits
 bool scan2_plan(uint32_t filter_words, uint32_t short3_bytes, uint32_t shorts_words, size_t lds_max, uint32_t* waves,
                 uint32_t* cand_cap);
 hipError_t launch_scan2(const Scan2Params& P, uint32_t waves, unsigned n_cus, hipStream_t st);
-hipError_t launch_scan3(const Scan2Params& P, uint32_t waves, unsigned n_cus, hipStream_t st);
 
 hipError_t launch_unit_count(const uint64_t* d_doc_off, uint64_t n_docs, uint32_t unit_max, uint32_t* d_cnt,
                              hipStream_t st);

@@ -6,10 +6,11 @@
 //            256-byte LDS table and probes the LDS-resident 4-window filter once per byte.  Neighbouring bytes are
 //            independent (the depth-4 automaton is 4-local), so there is no dependent lookup chain; the per-byte flag
 //            is shifted into a lane-private bit mask with v_alignbit.
-//   phase 2  VERIFY  only flagged positions (a few % of the text) touch the L2-resident bucket table: one 32-byte
-//            slot holds the window's longest term inline; terms longer than the window are confirmed by a masked
-//            dword compare of the 4 bytes in front of it (and a byte loop past 8).  Matches come out per lane in text
-//            order, longest first, i.e. in the reference's emission order.
+//   phase 2  VERIFY  flagged positions (~12 % of the text) first pass LDS-only checks (short-term records, fingerprint
+//            table); the survivors (~3 %) go to the L2-resident bucket table: both candidate 32-byte slots of the
+//            window key are loaded at once, a slot holds a whole term up to 24 bytes, so a lookup is two loads deep
+//            (text, slot).  Ordered path: matches come out per lane in text order, longest first, i.e. in the
+//            reference's emission order; unordered path (solver input): positions are balanced over the lanes.
 //   output   matches are staged per lane in LDS, a wave prefix sum (shuffles) gives every lane its offset, the wave
 //            takes its room from a private slab (one global atomic per ~4 K matches) and writes the unit's matches
 //            contiguously.  Nothing is ever truncated: the host re-runs with a larger pool if the cursor overran.
@@ -70,6 +71,7 @@ struct Ctx {
     uint64_t doc_abs;          // offset of the document inside the text blob
     uint32_t kp2;              // kp * kp
     bool near0;                // wave-uniform: the document starts within 7 bytes of the blob start
+    bool near24;               // ... within 23 bytes
 };
 
 // ---- verification of one flagged position p, in three separable steps so that several candidates can have their
@@ -79,7 +81,7 @@ struct Ctx {
 // Positions before the document start need no special casing here: the bytes there (the previous document's, or
 // zeros in front of the blob) can only change keys of windows that reach across the start, and every term such a
 // window may name is longer than p + 1 and is dropped by the length check at emission.
-struct Cand { uint32_t p, x, tw, h, sid; bool go_long; };
+struct Cand { uint32_t p, x, tw, sid; bool go_long; };
 struct Text8 { uint32_t tw, w; };
 __device__ __forceinline__ Text8 cand_load_slow(const Ctx& c, uint32_t p) {   // within 7 bytes of the blob start
     Text8 t{0, 0};
@@ -109,7 +111,6 @@ __device__ __forceinline__ void cand_keys(const Ctx& c, uint32_t p, const Text8 
     const uint32_t lo = mad24(c2, kp, c.cls[w >> 24]);           // key = (c0 kp + c1) kp^2 + (c2 kp + c3)
     const uint32_t x3 = mad24(c1, c.kp2, lo);
     k.x = mad24(mad24(c0, kp, c1), c.kp2, lo);
-    k.h = (k.x * kGoldDev) >> c.P.slot_shift;
     k.sid = c.short3 ? c.short3[x3] : 0;
 }
 // LDS-only decision: can a term of length >= 4 end here at all (fingerprint of the bytes in front of the window)?
@@ -128,35 +129,78 @@ __device__ __forceinline__ void cand_text(const Ctx& c, uint32_t p, Cand& k) {
     cand_decide(c, k);
 }
 
-// step 2: the first probe of the bucket table
-__device__ __forceinline__ uint4 cand_slot(const Ctx& c, const Cand& k) {
-    if (!k.go_long) return make_uint4(kScan2EmptyKey, 0, 0, 0);
-    return *reinterpret_cast<const uint4*>(&c.P.slots[k.h]);
+// step 2 (bucket table): the 20 bytes in front of the window as the slots store them, f[k] = text[p-7-4k .. p-4-4k]
+struct Front { uint32_t f[5]; };
+__device__ __forceinline__ Front front_load(const Ctx& c, uint32_t p, uint32_t tw) {
+    Front t;
+    t.f[0] = tw;
+    if (__builtin_expect(c.near24, 0)) {                      // wave-uniform: first document of the blob
+        const uint64_t ab = c.doc_abs + p;
+#pragma unroll
+        for (int k = 1; k < 5; k++) {
+            uint32_t v = 0;
+            for (int b = 0; b < 4; b++)
+                if (ab >= (uint64_t)(7 + 4 * k - b)) v |= (uint32_t)c.dbase[(int64_t)p - 7 - 4 * k + b] << (8 * b);
+            t.f[k] = v;
+        }
+    } else {
+        const U128u v = *reinterpret_cast<const U128u*>(c.dbase + (int64_t)p - 23);
+        t.f[4] = v.x; t.f[3] = v.y; t.f[2] = v.z; t.f[1] = v.w;
+    }
+    return t;
+}
+__device__ __forceinline__ void front_fold(Front& t) {
+#pragma unroll
+    for (int k = 0; k < 5; k++) t.f[k] = fold4(t.f[k]);
 }
 
-// does bucket entry e = {term_id, len, cmp_val, cmp_mask} end at k.p?  twf = the (folded) bytes p-7..p-4
-__device__ __forceinline__ bool entry_ok(const Ctx& c, const Cand& k, uint32_t twf, const uint4 e) {
+struct Slot { uint4 a, b; };      // a = {key, info, len, front[0]}, b = front[1..4]
+__device__ __forceinline__ Slot slot_load(const Scan2Slot* s) {
+    const uint4* q = reinterpret_cast<const uint4*>(s);
+    return Slot{q[0], q[1]};
+}
+// both candidate slots of key x -> the one that holds it; false: no term ends with this window
+__device__ __forceinline__ bool slot_pick(uint32_t x, const Slot& s0, const Slot& s1, Slot& out) {
+    const bool use1 = s1.a.x == x;
+    out.a = use1 ? s1.a : s0.a;
+    out.b = use1 ? s1.b : s0.b;
+    return use1 || s0.a.x == x;
+}
+
+// does the term described by e end at p?  t = the (folded) bytes in front of the window.  kmax: dwords of `front` to
+// look at (wave-uniform bound, or 5)
+__device__ __forceinline__ bool entry_ok(const Ctx& c, uint32_t p, const Front& t, const Slot& e, uint32_t kmax) {
     const Scan2Params& P = c.P;
-    const uint32_t p = k.p, L = e.y;
-    bool ok = L <= p + 1 && ((twf ^ e.z) & e.w) == 0;          // len <= 4: mask 0
-    if (ok && L > 8) {
-        // the first L-8 bytes of the term against text[p+1-L .. p-8], four bytes at a time from the end;
-        // all loads are independent (no early exit), so they are in flight together.  term_blob carries 4
-        // bytes of slack in front of every term, the text side needs 3 bytes of slack before the match.
-        const uint8_t* tb = P.term_blob + P.term_off[e.x];
+    const uint32_t L = e.a.z;
+    const int32_t nfront = (int32_t)L - 4;
+    uint32_t diff = 0;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        if ((uint32_t)k < kmax) {
+            const int32_t nb = min(max(nfront - 4 * k, 0), 4);                     // bytes of this dword the term owns
+            const uint32_t mask = (uint32_t)(0xFFFFFFFF00000000ull >> (8 * nb));   // ... the ones next to the window
+            const uint32_t fk = k == 0 ? e.a.w : k == 1 ? e.b.x : k == 2 ? e.b.y : k == 3 ? e.b.z : e.b.w;
+            diff |= (t.f[k] ^ fk) & mask;
+        }
+    }
+    bool ok = L <= p + 1 && diff == 0;
+    if (ok && L > kScan2InlineLen) {
+        // the first L-24 bytes of the term against text[p+1-L .. p-24], four bytes at a time from the end; term_blob
+        // carries 4 bytes of slack in front of every term, the text side needs 3 bytes of slack before the match
+        const uint8_t* tb = P.term_blob + P.term_off[e.a.y];
         const uint8_t* tp = c.dbase + (int64_t)p + 1 - L;
-        const uint32_t n = L - 8;
+        const uint32_t n = L - kScan2InlineLen;
         if (c.doc_abs + p + 1 - L >= 3) {
-            uint32_t diff = 0;
+            uint32_t d2 = 0;
             for (uint32_t j = 0; j * 4 < n; j++) {
                 const int32_t at = (int32_t)n - 4 - (int32_t)(j * 4);       // may be -1..-3 for the last chunk
                 uint32_t tv = load_u32_unaligned(tp + at);
                 const uint32_t wv = load_u32_unaligned(tb + at);
                 if (P.fold) tv = fold4(tv);
                 const uint32_t mask = at >= 0 ? 0xFFFFFFFFu : 0xFFFFFFFFu << (8 * (uint32_t)(-at));
-                diff |= (tv ^ wv) & mask;
+                d2 |= (tv ^ wv) & mask;
             }
-            ok = diff == 0;
+            ok = d2 == 0;
         } else {
             for (uint32_t i = 0; i < n && ok; i++) {
                 uint32_t b = tp[i];
@@ -168,22 +212,10 @@ __device__ __forceinline__ bool entry_ok(const Ctx& c, const Cand& k, uint32_t t
     return ok;
 }
 
-// first probe result -> the slot holding key k.x (or "no such bucket"); returns false when the bucket does not exist
-__device__ __forceinline__ bool find_bucket(const Ctx& c, const Cand& k, uint4& slot) {
-    uint32_t h = k.h;
-    while (slot.x != k.x) {
-        if (slot.x == kScan2EmptyKey) return false;             // fingerprint / hashed-filter false positive
-        h = (h + 1) & c.P.slot_mask;
-        slot = *reinterpret_cast<const uint4*>(&c.P.slots[h]);
-    }
-    return true;
-}
-
 // step 3 (ordered path): all terms that end at p, longest first.  MODE 0: count and stage per lane in LDS;
 // MODE 1: write to the pool at out_base.
 template <int MODE>
-__device__ __forceinline__ void cand_finish(const Ctx& c, const Cand& k, uint4 slot, uint32_t& cnt, uint2* stage,
-                                            uint64_t out_base) {
+__device__ __forceinline__ void cand_finish(const Ctx& c, const Cand& k, uint32_t& cnt, uint2* stage, uint64_t out_base) {
     const Scan2Params& P = c.P;
     const uint32_t p = k.p;
     auto emit = [&](uint32_t term, uint32_t L) {
@@ -197,26 +229,27 @@ __device__ __forceinline__ void cand_finish(const Ctx& c, const Cand& k, uint4 s
         cnt++;
     };
     // ---- terms of length >= 4, longest first ---------------------------------------------------------------------
-    if (k.go_long && find_bucket(c, k, slot)) {
-        // bucket entries as {term_id, len, cmp_val, cmp_mask}; the common one-entry bucket is the slot itself
-        const uint32_t twf = P.fold ? fold4(k.tw) : k.tw;
-        const bool simple = (slot.w & kScan2Simple) != 0;
-        uint32_t n_ent = 1, more_at = 0;
-        uint4 e;
-        if (simple) {
-            e = make_uint4(slot.w & 0x7FFFFFu, (slot.w >> 23) & 0xFFu, slot.y, slot.z);
-        } else {
-            more_at = slot.w;
-            n_ent = P.more[more_at].term_id;
-            e = *reinterpret_cast<const uint4*>(&P.more[more_at + 1]);
-        }
-        for (uint32_t j = 0;;) {
-            if (entry_ok(c, k, twf, e)) emit(e.x, e.y);
-            if (++j >= n_ent) break;
-            e = *reinterpret_cast<const uint4*>(&P.more[more_at + 1 + j]);
+    if (k.go_long) {
+        const Slot s0 = slot_load(&P.slots[scan2_slot_hash(k.x, 0, P.slot_shift)]);
+        const Slot s1 = slot_load(&P.slots[scan2_slot_hash(k.x, 1, P.slot_shift)]);
+        Front t = front_load(c, p, k.tw);
+        if (P.fold) front_fold(t);
+        Slot e;
+        if (slot_pick(k.x, s0, s1, e)) {
+            uint32_t n_ent = 1, more_at = 0;
+            if (e.a.y & kScan2Multi) {
+                more_at = e.a.y & ~kScan2Multi;
+                n_ent = e.a.z;
+                e = slot_load(&P.more[more_at]);
+            }
+            for (uint32_t j = 0;;) {
+                if (entry_ok(c, p, t, e, 5)) emit(e.a.y, e.a.z);
+                if (++j >= n_ent) break;
+                e = slot_load(&P.more[more_at + j]);
+            }
         }
     }
-    // ---- terms of length <= 3 (record from the LDS 3-window table; the record array is tiny and L1 resident) -----------
+    // ---- terms of length <= 3 (records from the LDS 3-window table) -------------------------------------------------------
     if (k.sid) {
 #pragma unroll
         for (uint32_t j = 0; j < 3; j++) {
@@ -250,36 +283,99 @@ __device__ __forceinline__ void finish_short(const Ctx& c, uint32_t p, uint32_t 
     }
 }
 
-// terms of length >= 4 ending at the lanes' positions (`on`: this lane has a candidate); wave-uniform call
-__device__ __forceinline__ void finish_long(const Ctx& c, bool on, const Cand& k, uint4 slot, uint2* fifo, uint32_t& nf) {
+// dwords of front bytes a term of length L owns (0 for lanes that are not active)
+__device__ __forceinline__ uint32_t wave_kmax(uint32_t L) {
+    return __any(L > 20) ? 5 : __any(L > 16) ? 4 : __any(L > 12) ? 3 : __any(L > 8) ? 2 : 1;
+}
+// fold the first kmax dwords of t that are not folded yet (`done` = how many are; wave-uniform)
+__device__ __forceinline__ void front_fold_upto(Front& t, uint32_t& done, uint32_t kmax) {
+#pragma unroll
+    for (int k = 0; k < 5; k++)
+        if ((uint32_t)k >= done && (uint32_t)k < kmax) t.f[k] = fold4(t.f[k]);
+    done = kmax > done ? kmax : done;
+}
+
+// A wave's deferred bucket entries: {candidate position, index into `more`} pairs parked in LDS so that the entries
+// of multi-term buckets are verified densely (64 distinct entries per trip) instead of one round per bucket depth.
+struct Deferred { uint2* list; uint32_t cap, n; };
+
+// terms of length >= 4 ending at the lanes' positions (`on`: this lane has a candidate); wave-uniform call.
+// s0, s1: the key's two candidate slots; t: the bytes in front of the window, not yet folded.  One-term buckets are
+// verified here; the entries of multi-term buckets are deferred (or, if the list is full, verified in place).
+__device__ __forceinline__ void finish_long(const Ctx& c, bool on, uint32_t rel, const Cand& k, const Slot& s0, const Slot& s1,
+                                            Front t, uint2* fifo, uint32_t& nf, Deferred& d) {
     const Scan2Params& P = c.P;
-    bool have = on && k.go_long && find_bucket(c, k, slot);
-    uint32_t n_ent = 0, more_at = 0, twf = 0;
-    uint4 e = make_uint4(0, 0, 0, 0);
-    if (have) {
-        twf = P.fold ? fold4(k.tw) : k.tw;
-        if (slot.w & kScan2Simple) {
-            n_ent = 1;
-            e = make_uint4(slot.w & 0x7FFFFFu, (slot.w >> 23) & 0xFFu, slot.y, slot.z);
-        } else {
-            more_at = slot.w;
-            n_ent = P.more[more_at].term_id;
-            e = *reinterpret_cast<const uint4*>(&P.more[more_at + 1]);
-        }
+    Slot e;
+    const bool have = slot_pick(k.x, s0, s1, e) && on;
+    if (!__any(have)) return;
+    const bool multi = have && (e.a.y & kScan2Multi);
+    uint32_t folded = 0;
+    {   // one-term buckets
+        const bool act = have && !multi;
+        const uint32_t kmax = wave_kmax(act ? e.a.z : 0);
+        if (P.fold) front_fold_upto(t, folded, kmax);
+        const bool ok = act && entry_ok(c, k.p, t, e, kmax);
+        fifo_append(ok, e.a.y, P.pos_end ? k.p : k.p + 1 - e.a.z, fifo, nf);
     }
+    if (!__any(multi)) return;
+    const uint32_t n_ent = multi ? e.a.z : 0, more_at = e.a.y & ~kScan2Multi;
+    uint32_t tot = n_ent;
+    for (int sh = 32; sh; sh >>= 1) tot += __shfl_xor(tot, sh, 64);
+    if (tot <= d.cap - d.n) {
+        // park every entry: lanes take consecutive cells, entry after entry
+        for (uint32_t j = 0; __any(j < n_ent); j++) {
+            const uint64_t m = __ballot(j < n_ent);
+            if (j < n_ent)
+                d.list[d.n + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] =
+                    make_uint2(rel, more_at + j);
+            d.n += (uint32_t)__popcll(m);
+        }
+        return;
+    }
+    // no room (a very deep bucket): verify in place, one round per entry
+    Slot cur = e;
+    if (multi) cur = slot_load(&P.more[more_at]);
     for (uint32_t j = 0; __any(j < n_ent); j++) {
         const bool act = j < n_ent;
-        const bool ok = act && entry_ok(c, k, twf, e);
-        fifo_append(ok, e.x, P.pos_end ? k.p : k.p + 1 - e.y, fifo, nf);
-        if (j + 1 < n_ent) e = *reinterpret_cast<const uint4*>(&P.more[more_at + 2 + j]);
+        Slot nxt = cur;
+        if (j + 1 < n_ent) nxt = slot_load(&P.more[more_at + j + 1]);      // in flight during the compare
+        const uint32_t kmax = wave_kmax(act ? cur.a.z : 0);
+        if (P.fold) front_fold_upto(t, folded, kmax);
+        const bool ok = act && entry_ok(c, k.p, t, cur, kmax);
+        fifo_append(ok, cur.a.y, P.pos_end ? k.p : k.p + 1 - cur.a.z, fifo, nf);
+        cur = nxt;
     }
+}
+
+// verify the parked entries, 64 per trip
+__device__ __forceinline__ void drain_deferred(const Ctx& c, uint32_t unit_lo, uint2* fifo, uint32_t& nf, Deferred& d) {
+    const Scan2Params& P = c.P;
+    const uint32_t lane = lane_id();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (uint32_t i0 = 0; i0 < d.n; i0 += 64) {
+        const bool on = i0 + lane < d.n;
+        const uint2 it = d.list[on ? i0 + lane : 0];
+        const uint32_t p = unit_lo + it.x;
+        const Slot e = slot_load(&P.more[it.y]);
+        const Text8 t8 = cand_load(c, p);
+        Front t = front_load(c, p, t8.tw);
+        const uint32_t kmax = wave_kmax(on ? e.a.z : 0);
+        uint32_t folded = 0;
+        if (P.fold) front_fold_upto(t, folded, kmax);
+        const bool ok = on && entry_ok(c, p, t, e, kmax);
+        fifo_append(ok, e.a.y, P.pos_end ? p : p + 1 - e.a.z, fifo, nf);
+    }
+    d.n = 0;
+    __builtin_amdgcn_wave_barrier();
 }
 
 template <int MODE>
 __device__ __forceinline__ void verify(const Ctx& c, uint32_t p, uint32_t& cnt, uint2* stage, uint64_t out_base) {
     Cand k;
     cand_text(c, p, k);
-    if (k.go_long || k.sid) cand_finish<MODE>(c, k, cand_slot(c, k), cnt, stage, out_base);
+    if (k.go_long || k.sid) cand_finish<MODE>(c, k, cnt, stage, out_base);
 }
 
 template <int MODE>
@@ -345,7 +441,8 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
         const bool more_units = u + stride < P.n_units;
         if (more_units) un_n = P.units[u + stride];
         const Ctx c{P, cls, filt, P.short3_bytes ? short3 : nullptr, fpt, lrec, P.text + doc_abs, doc_abs, kp2,
-                    __builtin_amdgcn_readfirstlane((uint32_t)(doc_abs < 7)) != 0};
+                    __builtin_amdgcn_readfirstlane((uint32_t)(doc_abs < 7)) != 0,
+                    __builtin_amdgcn_readfirstlane((uint32_t)(doc_abs < 23)) != 0};
         const uint32_t own = un.hi - un.lo;
         const uint32_t C = ((own + 63) / 64 + 3) & ~3u;            // bytes per lane (multiple of 4, <= 128)
         const uint32_t my_lo = un.lo + lane * C;
@@ -486,20 +583,25 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     if (P.dbg & 2) { if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(P.dbg_counters + 2), (unsigned long long)ns); }
-                    // stage B: the survivors, densely packed over the lanes, go to the L2 bucket table
-                    for (uint32_t i0 = 0; i0 < ns; i0 += 128) {
-                        const uint32_t ia = i0 + lane, ib = ia + 64;
-                        const bool on_a = ia < ns, on_b = ib < ns;
-                        const uint32_t pa = un.lo + cand[on_a ? ia : 0], pb = un.lo + cand[on_b ? ib : 0];
-                        const Text8 ta = cand_load(c, pa), tb = cand_load(c, pb);
-                        Cand ka, kb;
-                        cand_keys(c, pa, ta, ka); cand_keys(c, pb, tb, kb);
-                        ka.go_long = kb.go_long = true;
-                        const uint4 sla = *reinterpret_cast<const uint4*>(&P.slots[ka.h]);
-                        const uint4 slb = *reinterpret_cast<const uint4*>(&P.slots[kb.h]);
-                        finish_long(c, on_a, ka, sla, fifo, nf);
-                        if (i0 + 64 < ns) finish_long(c, on_b, kb, slb, fifo, nf);
+                    // stage B: the survivors, densely packed over the lanes, go to the L2 bucket table; the room behind
+                    // them in the candidate list parks the entries of multi-term buckets
+                    Deferred dfr;
+                    dfr.list = reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(cand) + ((ns * 2 + 7) & ~7u));
+                    dfr.cap = (P.cand_cap * 2 - ((ns * 2 + 7) & ~7u)) / 8;
+                    dfr.n = 0;
+                    for (uint32_t i0 = 0; i0 < ns; i0 += 64) {
+                        const bool on = i0 + lane < ns;
+                        const uint32_t rel = cand[on ? i0 + lane : 0];
+                        const uint32_t p = un.lo + rel;
+                        const Text8 t8 = cand_load(c, p);
+                        const Front fr = front_load(c, p, t8.tw);
+                        Cand k;
+                        cand_keys(c, p, t8, k);
+                        const Slot s0 = slot_load(&P.slots[scan2_slot_hash(k.x, 0, P.slot_shift)]);
+                        const Slot s1 = slot_load(&P.slots[scan2_slot_hash(k.x, 1, P.slot_shift)]);
+                        finish_long(c, on, rel, k, s0, s1, fr, fifo, nf, dfr);
                     }
+                    if (dfr.n) drain_deferred(c, un.lo, fifo, nf, dfr);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -575,16 +677,6 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
 }
 
 }  // namespace
-
-size_t scan2_lds_bytes(uint32_t filter_words, uint32_t short3_bytes, uint32_t waves) {      // gft_scan3 layout
-    return 256 + (size_t)filter_words * 4 + short3_bytes + kScan2FptSize + (size_t)waves * kScan2WaveLds;
-}
-
-uint32_t scan2_pick_waves(uint32_t filter_words, uint32_t short3_bytes, size_t lds_max) {
-    for (uint32_t w : {16u, 12u, 8u, 4u})
-        if (scan2_lds_bytes(filter_words, short3_bytes, w) <= lds_max) return w;
-    return 0;
-}
 
 static size_t scan2_fixed_lds(uint32_t filter_words, uint32_t short3_bytes, uint32_t shorts_words) {
     return 256 + (size_t)filter_words * 4 + short3_bytes + kScan2FptSize + (((size_t)shorts_words * 4 + 15) & ~(size_t)15);

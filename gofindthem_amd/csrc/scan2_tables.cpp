@@ -20,18 +20,14 @@ void build_scan2_tables(const AcTables& ac, Scan2Tables& t) {
     memcpy(t.cls, ac.byte_class, 256);
     for (int b = 0; b < 256; b++) t.cls_fold[b] = ac.byte_class[(b >= 'A' && b <= 'Z') ? b + 32 : b];
 
-    for (int b = 255; b >= 0; b--) {
-        if (t.cls[b] == 0) t.pad_byte = b;
-        if (t.cls_fold[b] == 0) t.pad_byte_fold = b;
-    }
-
     const uint64_t kp3 = (uint64_t)kp * kp * kp;
     bool any_short = false;
     for (const auto& s : ac.terms) any_short |= !s.empty() && s.size() < kWin;
     if (any_short && kp3 > kScan2Short3Max) { t.why_not = "terms shorter than 4 bytes over a large alphabet"; return; }
 
     // ---- terms of length >= 4: buckets keyed by their last four classes ------------------------------------------
-    std::unordered_map<uint32_t, std::vector<Scan2Entry>> buckets;
+    struct Ent { uint32_t term_id, len; };
+    std::unordered_map<uint32_t, std::vector<Ent>> buckets;
     buckets.reserve(ac.terms.size() * 2);
     std::vector<std::vector<uint32_t>> content;   // per 3-window: short terms ending there
     if (any_short) content.resize((size_t)kp3);
@@ -49,15 +45,7 @@ void build_scan2_tables(const AcTables& ac, Scan2Tables& t) {
         const uint32_t m = std::min(L, kWin);
         for (uint32_t i = L - m; i < L; i++) tail = tail * kp + ac.byte_class[(uint8_t)s[i]];
         if (L >= kWin) {
-            Scan2Entry e{(uint32_t)id, L, 0, 0};
-            for (int k = 0; k < 4; k++) {
-                const int idx = (int)L - 8 + k;
-                if (idx >= 0 && idx < (int)L - 4) {
-                    e.cmp_val |= (uint32_t)(uint8_t)s[idx] << (8 * k);
-                    e.cmp_mask |= 0xFFu << (8 * k);
-                }
-            }
-            buckets[tail].push_back(e);
+            buckets[tail].push_back(Ent{(uint32_t)id, L});
         } else {
             // a short term ends every 3-window whose last L classes are the term
             uint32_t scale = 1, combos = 1;
@@ -108,34 +96,34 @@ void build_scan2_tables(const AcTables& ac, Scan2Tables& t) {
             t.shorts_packed.push_back(j < r.n ? r.term[j] | r.len[j] << 28 : 0u);
         }
 
-    // ---- slots (16 bytes) + fingerprint table ---------------------------------------------------------------------------------
-    uint32_t lg = 10;
-    while ((1ull << lg) < 4 * t.n_keys) lg++;   // load <= 0.25: a miss ends at the first probe most of the time
-    t.slot_shift = 32 - lg;
-    t.slots.assign((size_t)1 << lg, Scan2Slot{kScan2EmptyKey, 0, 0, 0});
+    // ---- bucket table (32-byte slots, two-choice placement) + fingerprint items ------------------------------------
+    auto make_slot = [&](uint32_t key, const Ent& e) {
+        const std::string& s = ac.terms[e.term_id];
+        const int L = (int)s.size();
+        Scan2Slot r{key, e.term_id, e.len, {0, 0, 0, 0, 0}};
+        for (int k = 0; k < 5; k++)
+            for (int b = 0; b < 4; b++) {
+                const int idx = L - 8 - 4 * k + b;             // term byte under text[p-7-4k+b]
+                if (idx >= 0) r.front[k] |= (uint32_t)(uint8_t)s[idx] << (8 * b);
+            }
+        return r;
+    };
     t.fpt.assign(kScan2FptSize, 0);
     struct FpItem { uint32_t key; uint8_t val[2]; uint32_t n; };
     std::vector<FpItem> fp_items;
     std::vector<uint32_t> homeless;
-    const uint32_t smask = (1u << lg) - 1;
+    std::vector<Scan2Slot> items;        // one per key: the term itself, or the header of a multi-term bucket
     for (auto& kv : buckets) {
         auto& v = kv.second;
-        std::stable_sort(v.begin(), v.end(), [](const Scan2Entry& a, const Scan2Entry& b) { return a.len > b.len; });
+        std::stable_sort(v.begin(), v.end(), [](const Ent& a, const Ent& b) { return a.len > b.len; });
         const uint32_t key = kv.first;
+        if (key == kScan2EmptyKey) { t.why_not = "window key collides with the empty marker"; return; }
         set_filter(key);
-        uint32_t h = (key * kGold) >> t.slot_shift;
-        while (t.slots[h].key != kScan2EmptyKey) h = (h + 1) & smask;
-        Scan2Slot& s = t.slots[h];
-        s.key = key;
-        const bool simple = v.size() == 1 && v[0].len <= 255 && v[0].term_id < (1u << 23);
-        if (simple) {
-            s.cmp_val = v[0].cmp_val; s.cmp_mask = v[0].cmp_mask;
-            s.info = kScan2Simple | v[0].len << 23 | v[0].term_id;
+        if (v.size() == 1) {
+            items.push_back(make_slot(key, v[0]));
         } else {
-            s.cmp_val = 0; s.cmp_mask = 0;
-            s.info = (uint32_t)t.more.size();                       // header {count} then the entries, longest first
-            t.more.push_back(Scan2Entry{(uint32_t)v.size(), 0, 0, 0});
-            t.more.insert(t.more.end(), v.begin(), v.end());
+            items.push_back(Scan2Slot{key, kScan2Multi | (uint32_t)t.more.size(), (uint32_t)v.size(), {0, 0, 0, 0, 0}});
+            for (const Ent& e : v) t.more.push_back(make_slot(key, e));
         }
         // fingerprint cells (cuckoo: two candidate cells per key).  A one-term bucket owns one cell; a two-term bucket
         // needs both of its cells (one fingerprint each); larger buckets pass everything.
@@ -148,6 +136,30 @@ void build_scan2_tables(const AcTables& ac, Scan2Tables& t) {
             for (int k = 0; k < 4; k++)
                 if (L - 8 + k >= 0) f_lo |= (uint32_t)(uint8_t)s[L - 8 + k] << (8 * k);
             fp_items.back().val[i] = (uint8_t)scan2_fpt_byte(scan2_fpt_code((uint32_t)L), scan2_fpt_xmix(key), f_lo);
+        }
+    }
+    {
+        uint32_t lg = 10;
+        while ((1ull << lg) < 4 * items.size()) lg++;        // load <= 0.25
+        for (;; lg++) {
+            if (lg > 28) { t.why_not = "bucket table too large"; return; }
+            t.slot_shift = 32 - lg;
+            t.slots.assign((size_t)1 << lg, Scan2Slot{kScan2EmptyKey, 0, 0, {0, 0, 0, 0, 0}});
+            uint32_t rng = 0x2545F491u;
+            bool ok = true;
+            for (const Scan2Slot& it : items) {
+                Scan2Slot cur = it;
+                bool placed = false;
+                for (int kick = 0; kick < 1000 && !placed; kick++) {
+                    const uint32_t h0 = scan2_slot_hash(cur.key, 0, t.slot_shift), h1 = scan2_slot_hash(cur.key, 1, t.slot_shift);
+                    if (t.slots[h0].key == kScan2EmptyKey) { t.slots[h0] = cur; placed = true; break; }
+                    if (t.slots[h1].key == kScan2EmptyKey) { t.slots[h1] = cur; placed = true; break; }
+                    rng = rng * 1664525u + 1013904223u;
+                    std::swap(cur, t.slots[(rng >> 16) & 1 ? h1 : h0]);
+                }
+                if (!placed) { ok = false; break; }
+            }
+            if (ok) break;       // else: a larger table (two keys sharing both slots with a third cannot happen twice)
         }
     }
     {
@@ -189,7 +201,7 @@ void build_scan2_tables(const AcTables& ac, Scan2Tables& t) {
     for (uint32_t k : homeless) t.fpt[scan2_fpt_cell(k, 0)] = kScan2FptAmbiguous;
     t.term_blob.insert(t.term_blob.end(), 8, 0);
     t.term_off.push_back((uint32_t)t.term_blob.size());
-    if (t.more.empty()) t.more.push_back(Scan2Entry{0, 0, 0, 0});
+    if (t.more.empty()) t.more.push_back(Scan2Slot{kScan2EmptyKey, 0, 0, {0, 0, 0, 0, 0}});
     t.supported = t.more.size() < (1u << 31);
     if (!t.supported) t.why_not = "bucket table too large";
 }

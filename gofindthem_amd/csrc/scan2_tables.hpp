@@ -41,16 +41,14 @@ struct Scan2Tables {
     std::vector<Scan2Short> shorts;  // record 0 unused
     std::vector<uint32_t> shorts_packed;   // 3 words per record: term_id | len << 28, longest first, 0 = none
     std::vector<uint8_t> fpt;        // [kScan2FptSize]
-    uint32_t slot_shift = 0;         // slot index = (key * kGold) >> slot_shift, linear probing
+    uint32_t slot_shift = 0;         // slot index = scan2_slot_hash(key, 0 or 1, slot_shift)
     std::vector<Scan2Slot> slots;    // power-of-two table, terms of length >= 4 only
-    std::vector<Scan2Entry> more;    // entry lists of multi-term buckets
+    std::vector<Scan2Slot> more;     // entry lists of multi-term buckets
     uint8_t cls[256];                // byte -> class
     uint8_t cls_fold[256];           // byte -> class of its ASCII lower-case form
     std::vector<uint8_t> term_blob;  // raw term bytes (for terms longer than 8)
     std::vector<uint32_t> term_off;  // n_terms + 1
     uint64_t n_keys = 0;
-    int pad_byte = -1;               // a byte of class 0 in cls[] (gft_scan3 history at a document start), -1: none
-    int pad_byte_fold = -1;          // same for cls_fold[]
 };
 
 constexpr uint32_t kGold = kGoldDev;

@@ -9,7 +9,7 @@ from oracle.pyoracle import Oracle, POS_END, POS_START
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["window", "rounds", "dfa"], autouse=True)
+@pytest.fixture(params=["window", "dfa"], autouse=True)
 def scan_kernel(request, monkeypatch):
     """every test runs against both scan kernels: the suffix-window kernel (default) and the general two-tier
     DFA kernel (forced with GFT_SCAN_KERNEL=dfa, read by gft_build)"""

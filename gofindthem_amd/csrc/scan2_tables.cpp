@@ -140,7 +140,7 @@ void build_scan2_tables(const AcTables& ac, Scan2Tables& t) {
     }
     {
         uint32_t lg = 10;
-        while ((1ull << lg) < 4 * items.size()) lg++;        // load <= 0.25
+        while ((1ull << lg) < 2 * items.size()) lg++;        // load <= 0.5 (two choices place that easily)
         for (;; lg++) {
             if (lg > 28) { t.why_not = "bucket table too large"; return; }
             t.slot_shift = 32 - lg;

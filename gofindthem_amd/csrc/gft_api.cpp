@@ -70,6 +70,8 @@ struct gft_engine {
     uint32_t n_exprs = 0, n_extra = 0;
     DevBuf d_prog, d_prog_off;            // public postfix words (INORD group subtrees are read from these)
     DevBuf d_fprog, d_fprog_off, d_groups; // fused internal form + INORD group table
+    DevBuf d_order, d_blk_deep;            // evaluation order of the programs (gft_set_programs)
+    uint32_t fprog_words = 0;
     DevBuf d_pscratch;                    // HBM presence matrices when n_slots * 8 B does not fit LDS
 
     // workspace
@@ -185,46 +187,96 @@ int check_program(const gft_engine* e, const uint32_t* w, uint64_t len, uint32_t
 
 // public postfix words -> fused internal form (gft_kernels.hpp FusedOp) + INORD group table.
 // `gbase` = offset of this program inside the uploaded public word array.
-void fuse_program(const uint32_t* w, uint64_t len, uint64_t gbase, std::vector<uint32_t>& out,
-                  std::vector<uint32_t>& groups) {
-    std::vector<uint64_t> starts;   // start index (in w) of every operand on the stack
-    auto is_bin = [&](uint64_t i) { return i < len && ((w[i] >> 28) == GFT_OP_AND || (w[i] >> 28) == GFT_OP_OR); };
+// public postfix words -> fused words (gft_kernels.hpp FusedOp); returns the deepest the accumulator stack gets
+uint32_t fuse_program(const uint32_t* w, uint64_t len, uint64_t gbase, std::vector<uint32_t>& out,
+                      std::vector<uint32_t>& groups) {
+    // postfix -> tree (node = operator or leaf, with the range of public words it covers)
+    struct Node { uint32_t op, slot; int64_t l, r; uint64_t s, e; };
+    std::vector<Node> nodes;
+    std::vector<int64_t> st;
     for (uint64_t i = 0; i < len; i++) {
         const uint32_t op = w[i] >> 28;
         switch (op) {
-        case GFT_OP_UNIT: {
-            const uint32_t slot = w[i] & GFT_SLOT_MASK;
-            // a UNIT directly followed by a binary operator is that operator's right operand
-            if (!starts.empty() && is_bin(i + 1)) {
-                out.push_back(((w[i + 1] >> 28) == GFT_OP_AND ? kFopAndS : kFopOrS) << 28 | slot);
-                i += 1;   // the operator is consumed: left operand stays on the stack, merged
-                break;
-            }
-            if (!starts.empty() && i + 1 < len && (w[i + 1] >> 28) == GFT_OP_NOT && is_bin(i + 2)) {
-                out.push_back(((w[i + 2] >> 28) == GFT_OP_AND ? kFopAndNS : kFopOrNS) << 28 | slot);
-                i += 2;
-                break;
-            }
-            out.push_back(kFopLoad << 28 | slot);
-            starts.push_back(i);
+        case GFT_OP_UNIT:
+            nodes.push_back(Node{op, w[i] & GFT_SLOT_MASK, -1, -1, i, i});
+            st.push_back((int64_t)nodes.size() - 1);
+            break;
+        case GFT_OP_AND:
+        case GFT_OP_OR: {
+            const int64_t r = st.back(); st.pop_back();
+            const int64_t l = st.back(); st.pop_back();
+            nodes.push_back(Node{op, 0, l, r, nodes[l].s, i});
+            st.push_back((int64_t)nodes.size() - 1);
             break;
         }
-        case GFT_OP_AND:
-        case GFT_OP_OR:
-            out.push_back((op == GFT_OP_AND ? kFopAndPop : kFopOrPop) << 28);
-            starts.pop_back();
-            break;
         case GFT_OP_NOT:
-            out.push_back(kFopNot << 28);
-            break;
         case GFT_OP_INORD: {
-            const uint64_t s = starts.back();
-            // a group with a single leaf has a non-empty position list exactly when the leaf is present
-            // (every reported key carries >= 1 position), so no position check is needed
-            if (i - s > 1) {
-                out.push_back(kFopInord << 28 | (uint32_t)(groups.size() / 2));
-                groups.push_back((uint32_t)(gbase + s));
-                groups.push_back((uint32_t)(i - s));
+            const int64_t c = st.back(); st.pop_back();
+            nodes.push_back(Node{op, 0, c, -1, nodes[c].s, i});
+            st.push_back((int64_t)nodes.size() - 1);
+            break;
+        }
+        default:
+            break;
+        }
+    }
+    if (st.empty()) return 0;
+    // Code generation with an explicit job stack (left-deep chains of 10 000 leaves must not recurse).
+    //  * NOT is pushed down to the leaves (De Morgan; every node is evaluated anyway, the reference does not
+    //    short-circuit), so it only survives on top of an INORD group;
+    //  * AND / OR commute: the operand that is a leaf goes second and folds into the operator word;
+    //  * the accumulator is pushed only between two operands that are both subtrees.
+    auto strip = [&](int64_t n, bool& neg) {        // skip NOT chains
+        while (nodes[n].op == GFT_OP_NOT) { neg = !neg; n = nodes[n].l; }
+        return n;
+    };
+    struct Job { int64_t n; int phase; bool neg; };
+    std::vector<Job> jobs{{st.back(), 0, false}};
+    uint32_t depth = 0, max_depth = 0;
+    while (!jobs.empty()) {
+        Job j = jobs.back(); jobs.pop_back();
+        bool neg = j.neg;
+        const int64_t n = j.phase == 0 ? strip(j.n, neg) : j.n;
+        const Node& nd = nodes[n];
+        switch (nd.op) {
+        case GFT_OP_UNIT:
+            out.push_back((neg ? kFopSetN : kFopSet) << 28 | nd.slot);
+            break;
+        case GFT_OP_INORD:
+            if (j.phase == 0) { jobs.push_back({n, 1, neg}); jobs.push_back({nd.l, 0, false}); }
+            else {
+                // (a group with a single leaf has a non-empty position list exactly when the leaf is present: every
+                // reported key carries >= 1 position, so no position check is needed)
+                if (nodes[nd.l].op != GFT_OP_UNIT) {
+                    out.push_back(kFopInord << 28 | (uint32_t)(groups.size() / 2));
+                    groups.push_back((uint32_t)(gbase + nodes[nd.l].s));
+                    groups.push_back((uint32_t)(nodes[nd.l].e - nodes[nd.l].s + 1));
+                }
+                if (neg) out.push_back(kFopNot << 28);
+            }
+            break;
+        case GFT_OP_AND:
+        case GFT_OP_OR: {
+            const bool is_and = (nd.op == GFT_OP_AND) != neg;        // not (a and b) == not a or not b
+            if (j.phase == 0) {
+                bool ln = neg, rn = neg;
+                const int64_t l = strip(nd.l, ln), r = strip(nd.r, rn);
+                if (nodes[r].op == GFT_OP_UNIT) { jobs.push_back({n, 1, neg}); jobs.push_back({nd.l, 0, neg}); }
+                else if (nodes[l].op == GFT_OP_UNIT) { jobs.push_back({n, 2, neg}); jobs.push_back({nd.r, 0, neg}); }
+                else {
+                    jobs.push_back({n, 4, neg}); jobs.push_back({nd.r, 0, neg});
+                    jobs.push_back({n, 3, neg}); jobs.push_back({nd.l, 0, neg});
+                }
+            } else if (j.phase == 1 || j.phase == 2) {
+                bool ln = neg;
+                const int64_t leaf = strip(j.phase == 1 ? nd.r : nd.l, ln);
+                out.push_back((is_and ? (ln ? kFopAndNS : kFopAndS) : (ln ? kFopOrNS : kFopOrS)) << 28 | nodes[leaf].slot);
+            } else if (j.phase == 3) {
+                out.push_back(kFopPush << 28);
+                max_depth = std::max(max_depth, ++depth);
+            } else {
+                out.push_back((is_and ? kFopAndPop : kFopOrPop) << 28);
+                depth--;
             }
             break;
         }
@@ -232,6 +284,7 @@ void fuse_program(const uint32_t* w, uint64_t len, uint64_t gbase, std::vector<u
             break;
         }
     }
+    return max_depth;
 }
 
 int ensure_pool(gft_engine* e, uint64_t entries) {
@@ -402,6 +455,7 @@ int solve_pipeline(gft_engine* e, uint64_t n_docs, const gft_extra_matches* d_ex
     S.n_docs = n_docs;
     S.fprog = e->d_fprog.as<uint32_t>(); S.fprog_off = e->d_fprog_off.as<uint64_t>();
     S.gprog = e->d_prog.as<uint32_t>(); S.groups = e->d_groups.as<uint32_t>();
+    S.order = e->d_order.as<uint32_t>(); S.blk_deep = e->d_blk_deep.as<uint32_t>();
     S.n_exprs = e->n_exprs;
     S.n_slots = (uint32_t)e->tab.terms.size() + e->n_extra + 1;
     S.tile_words = std::min<uint32_t>(kSolveTileWords, (e->n_exprs + 31) / 32);
@@ -409,9 +463,12 @@ int solve_pipeline(gft_engine* e, uint64_t n_docs, const gft_extra_matches* d_ex
     S.p_scratch = nullptr;
     { const char* dbg = getenv("GFT_SOLVE_DEBUG"); S.dbg = dbg ? (uint32_t)atoi(dbg) : 0; }
     // presence matrix (8 B per slot) in LDS when it fits next to the output tile, else in HBM (served by L2)
-    const bool p_in_lds = solve_lds_bytes(S.n_slots, S.tile_words, true) + 1024 <= e->lds_max;
+    S.fprog_words = e->fprog_words;
+    const bool p_in_lds = solve_lds_bytes(S.n_slots, S.tile_words, true, 0, 0, false) + 1024 <= e->lds_max;
+    // ... and the fused programs too, if there is room left (the interpreter fetches them word after word)
+    const bool prog_in_lds = solve_lds_bytes(S.n_slots, S.tile_words, p_in_lds, S.fprog_words, S.n_exprs, true) + 1024 <= e->lds_max;
     const uint64_t n_groups = (n_docs + 63) / 64;
-    const size_t lds_need = solve_lds_bytes(S.n_slots, S.tile_words, p_in_lds) + 512;
+    const size_t lds_need = solve_lds_bytes(S.n_slots, S.tile_words, p_in_lds, S.fprog_words, S.n_exprs, prog_in_lds) + 512;
     const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, e->lds_max / lds_need));
     unsigned grid = (unsigned)std::min<uint64_t>(n_groups, (uint64_t)e->n_cus * per_cu);
     if (!p_in_lds) {
@@ -419,7 +476,7 @@ int solve_pipeline(gft_engine* e, uint64_t n_docs, const gft_extra_matches* d_ex
         S.p_scratch = e->d_pscratch.as<uint64_t>();
     }
     ProfScope ps(e, "solve");
-    HIP_TRY(launch_solve(S, p_in_lds, grid, e->stream), "solve kernel launch");
+    HIP_TRY(launch_solve(S, p_in_lds, prog_in_lds, grid, e->stream), "solve kernel launch");
     return GFT_OK;
 }
 
@@ -465,7 +522,7 @@ void gft_engine_destroy(gft_engine* e) {
         for (auto& kv : e->prof)
             for (auto& p : kv.second.ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
         DevBuf* all[] = {&e->d_byte_class, &e->d_delta, &e->d_out_term, &e->d_out_link, &e->d_term_len, &e->d_prog,
-                         &e->d_prog_off, &e->d_fprog, &e->d_fprog_off, &e->d_groups, &e->d_pscratch, &e->d_s2_filter,
+                         &e->d_prog_off, &e->d_fprog, &e->d_fprog_off, &e->d_groups, &e->d_order, &e->d_blk_deep, &e->d_pscratch, &e->d_s2_filter,
                          &e->d_s2_slots, &e->d_s2_more, &e->d_s2_cls, &e->d_s2_cls_fold, &e->d_s2_term_blob,
                          &e->d_s2_term_off, &e->d_nmatches, &e->d_dbg, &e->d_s2_short3, &e->d_s2_shorts_packed, &e->d_s2_fpt,
 &e->d_unit_cnt, &e->d_unit_base, &e->d_units, &e->d_partial, &e->d_cursor,
@@ -653,19 +710,57 @@ int gft_set_programs(gft_engine* e, const uint32_t* prog_words, const uint64_t* 
     int rc;
     if ((rc = upload(e, e->d_prog, w, "program upload"))) return rc;
     if ((rc = upload(e, e->d_prog_off, o, "program upload"))) return rc;
-    std::vector<uint32_t> fw, groups;
+    std::vector<uint32_t> fw, groups, fdepth;
     std::vector<uint64_t> fo(1, 0);
     for (uint32_t i = 0; i < n_exprs; i++) {
-        fuse_program(prog_words + prog_off[i], prog_off[i + 1] - prog_off[i], prog_off[i], fw, groups);
+        fdepth.push_back(fuse_program(prog_words + prog_off[i], prog_off[i + 1] - prog_off[i], prog_off[i], fw, groups));
         fo.push_back(fw.size());
+    }
+    // Evaluation order: inside every output tile (kSolveTileWords * 32 expressions) the programs are sorted by
+    // length, longest first, and handed to the waves 64 at a time, so the lanes of a wave run loops of similar
+    // length; programs that nest deeper than the interpreter's register stack come first (their blocks take the
+    // general interpreter).  order[i] = expression evaluated at sorted position i; blk_deep[b] = block b needs it.
+    std::vector<uint32_t> order(n_exprs), blk_deep;
+    for (uint32_t i = 0; i < n_exprs; i++) order[i] = i;
+    const uint32_t tile_exprs = kSolveTileWords * 32;
+    for (uint32_t t0 = 0; t0 < n_exprs; t0 += tile_exprs) {
+        const uint32_t t1 = std::min(n_exprs, t0 + tile_exprs);
+        std::stable_sort(order.begin() + t0, order.begin() + t1, [&](uint32_t a, uint32_t b) {
+            const bool da = fdepth[a] > kSolveRegStack, db = fdepth[b] > kSolveRegStack;
+            if (da != db) return da;
+            return fo[a + 1] - fo[a] > fo[b + 1] - fo[b];
+        });
+        for (uint32_t b0 = t0; b0 < t1; b0 += 64) {
+            uint32_t deep = 0;
+            for (uint32_t i = b0; i < std::min(t1, b0 + 64); i++) deep |= fdepth[order[i]] > kSolveRegStack;
+            blk_deep.push_back(deep);
+        }
+    }
+    if (order.empty()) order.push_back(0);
+    if (blk_deep.empty()) blk_deep.push_back(0);
+    if (getenv("GFT_SOLVE_DEBUG")) {
+        uint64_t hist[16] = {0}, with_rare = 0, maxlen = 0;
+        for (uint32_t i = 0; i < n_exprs; i++) {
+            bool rare = false;
+            for (uint64_t k = fo[i]; k < fo[i + 1]; k++) { hist[fw[k] >> 28]++; rare |= (fw[k] >> 28) >= kFopAndPop; }
+            with_rare += rare;
+            maxlen = std::max<uint64_t>(maxlen, fo[i + 1] - fo[i]);
+        }
+        fprintf(stderr, "[gft solve debug] %u programs, %zu fused words (max %llu); programs with stack/not/inord ops: %llu; ops:",
+                n_exprs, fw.size(), (unsigned long long)maxlen, (unsigned long long)with_rare);
+        for (int k = 1; k <= 12; k++) fprintf(stderr, " %d:%llu", k, (unsigned long long)hist[k]);
+        fprintf(stderr, "\n");
     }
     if (fw.empty()) fw.push_back(0);
     if (groups.empty()) groups.assign(2, 0);
     if ((rc = upload(e, e->d_fprog, fw, "program upload"))) return rc;
     if ((rc = upload(e, e->d_fprog_off, fo, "program upload"))) return rc;
     if ((rc = upload(e, e->d_groups, groups, "program upload"))) return rc;
+    if ((rc = upload(e, e->d_order, order, "program upload"))) return rc;
+    if ((rc = upload(e, e->d_blk_deep, blk_deep, "program upload"))) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream), "program upload");
     e->n_exprs = n_exprs; e->n_extra = n_extra; e->have_programs = true;
+    e->fprog_words = (uint32_t)fw.size();
     return GFT_OK;
 }
 

@@ -41,20 +41,24 @@ struct ScanParams {
 };
 
 // internal ("fused") form of an expression program, produced from the public postfix words at
-// gft_set_programs time: a right operand that is a plain UNIT folds into the operator, so left-deep chains
-// (the common shape: the parser is precedence-free and left-associative) never touch the operand stack.
+// gft_set_programs time.  An operand that is a plain (or negated) UNIT folds into its operator -- AND / OR commute, so
+// this works on either side -- and the accumulator is pushed only between two operands that are both subtrees.  The
+// common shapes (the parser is precedence-free and left-associative) are straight runs of ops 1..5.
 //   word = op << 28 | operand
-enum FusedOp : uint32_t {
-    kFopLoad = 1,     // push acc; acc = P[slot]
+enum FusedOp : uint32_t {     // ops < 8 read one presence row: bit 2 = negate it, low two bits = set / and / or
+    kFopSet = 1,      // acc = P[slot]
     kFopAndS = 2,     // acc &= P[slot]
     kFopOrS = 3,      // acc |= P[slot]
-    kFopAndNS = 4,    // acc &= ~P[slot]
-    kFopOrNS = 5,     // acc |= ~P[slot]
-    kFopAndPop = 6,   // acc = pop & acc
-    kFopOrPop = 7,    // acc = pop | acc
-    kFopNot = 8,      // acc = ~acc
-    kFopInord = 9     // acc = documents of acc whose INORD group `operand` has a non-empty position list
+    kFopSetN = 5,     // acc = ~P[slot]
+    kFopAndNS = 6,    // acc &= ~P[slot]
+    kFopOrNS = 7,     // acc |= ~P[slot]
+    kFopAndPop = 8,   // acc = pop & acc
+    kFopOrPop = 9,    // acc = pop | acc
+    kFopNot = 10,     // acc = ~acc (only on top of an INORD group: NOT is pushed down to the leaves otherwise)
+    kFopInord = 11,   // acc = documents of acc whose INORD group `operand` has a non-empty position list
+    kFopPush = 12     // push acc
 };
+constexpr uint32_t kSolveRegStack = 2;           // accumulator-stack entries the fast interpreter keeps in registers
 constexpr uint32_t kSolveTileWords = 64;         // bitmap words (x32 expressions) evaluated per LDS output tile
 
 struct SolveParams {
@@ -73,7 +77,10 @@ struct SolveParams {
     const uint64_t* fprog_off;
     const uint32_t* gprog;       // public postfix words (INORD group subtrees are interpreted from these)
     const uint32_t* groups;      // [n_groups][2] = offset, length into gprog
+    const uint32_t* order;       // [n_exprs] evaluation order inside every output tile (gft_set_programs)
+    const uint32_t* blk_deep;    // per 64 sorted programs: 1 = some program nests deeper than kSolveRegStack
     uint32_t n_exprs, n_slots, tile_words;
+    uint32_t fprog_words;        // total words of fprog (staged in LDS when they fit)
     uint32_t dbg;                // GFT_SOLVE_DEBUG bits (timing studies): 1 skip presence build, 2 skip evaluation, 4 skip transpose/output
     uint64_t* p_scratch;         // presence matrix in HBM when it does not fit LDS: [grid][n_slots]
     uint32_t* bitmap;
@@ -216,7 +223,8 @@ hipError_t launch_gather(const uint64_t* d_unit_start, const uint32_t* d_unit_co
                          uint64_t n_units, const uint32_t* d_pool_term, const uint32_t* d_pool_pos, uint32_t* d_term,
                          uint32_t* d_pos, const uint64_t* d_unit_base, uint64_t n_docs, uint64_t* d_match_off,
                          unsigned n_cus, hipStream_t st);
-size_t solve_lds_bytes(uint32_t n_slots, uint32_t tile_words, bool p_in_lds);
-hipError_t launch_solve(const SolveParams& S, bool p_in_lds, unsigned grid, hipStream_t st);
+size_t solve_lds_bytes(uint32_t n_slots, uint32_t tile_words, bool p_in_lds, uint32_t prog_words, uint32_t n_exprs,
+                       bool prog_in_lds);
+hipError_t launch_solve(const SolveParams& S, bool p_in_lds, bool prog_in_lds, unsigned grid, hipStream_t st);
 
 }  // namespace gft

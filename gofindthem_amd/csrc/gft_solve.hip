@@ -109,7 +109,83 @@ __device__ bool inord_group_nonempty(const uint32_t* __restrict__ prog, uint32_t
     return false;
 }
 
-template <bool P_LDS>
+// documents of `cand` (bit j = document d0 + j) whose INORD group `grp` has a non-empty position list
+__device__ uint64_t inord_docs(const SolveParams& S, uint32_t grp, uint64_t cand, uint64_t d0) {
+    uint64_t res = 0;
+    const uint32_t goff = S.groups[grp * 2], glen = S.groups[grp * 2 + 1];
+    while (cand) {
+        const uint32_t j = (uint32_t)__builtin_ctzll(cand);
+        cand &= cand - 1;
+        const uint64_t d = d0 + j;
+        DocHits M;
+        M.unit_start = S.unit_start; M.unit_count = S.unit_count;
+        M.term = S.term; M.pos = S.pos;
+        M.u0 = S.doc_unit_base[d]; M.u1 = S.doc_unit_base[d + 1];
+        M.nx = 0; M.xslot = nullptr; M.xpos = nullptr;
+        if (S.x_off) {
+            const uint64_t x0 = S.x_off[d];
+            M.xslot = S.x_slot + x0; M.xpos = S.x_pos + x0; M.nx = (uint32_t)(S.x_off[d + 1] - x0);
+        }
+        if (inord_group_nonempty(S.gprog + goff, glen, M)) res |= 1ull << j;
+    }
+    return res;
+}
+
+// One fused program over 64 documents (bit j of every mask = document d0 + j).  Lanes of a wave run different
+// programs, so the interpreter is predicated rather than branched: every word costs one presence read and a handful of
+// selects.  DEEP = false keeps the accumulator stack in two registers (programs that nest deeper are sorted into
+// blocks of their own and take DEEP = true: four registers backed by scratch).
+template <bool P_LDS, bool DEEP>
+__device__ __forceinline__ uint64_t run_program(const SolveParams& S, const uint64_t* P, const uint32_t* prog, uint32_t len,
+                                                uint64_t valid, uint64_t d0) {
+    // HBM-resident P was written with L2 atomics by other waves: read it past this CU's L1
+    auto ld = [&](uint32_t slot) -> uint64_t {
+        return P_LDS ? P[slot] : __hip_atomic_load(&P[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    uint64_t acc = 0, s0 = 0, s1 = 0, s2 = 0, s3 = 0, deep[DEEP ? kMaxBoolDepth : 1];
+    uint32_t sp = 0;
+    uint32_t w = len ? prog[0] : 0;
+    for (uint32_t pc = 0; pc < len; pc++) {
+        const uint32_t op = w >> 28, a = w & 0x0FFFFFFFu;
+        if (pc + 1 < len) w = prog[pc + 1];                     // next word in flight
+        const bool is_s = op < kFopAndPop;
+        uint64_t v = ld(is_s ? a : 0);
+        v ^= 0ull - (uint64_t)((op >> 2) & 1);                  // SetN / AndNS / OrNS
+        const uint32_t k = op & 3;
+        const uint64_t t = k == 3 ? (acc | v) : (acc & v);
+        const uint64_t sacc = k == 1 ? v : t;
+        const bool is_pop = (op & 14) == kFopAndPop, is_push = op == kFopPush;
+        const uint64_t pacc = (op & 1) ? (acc | s0) : (acc & s0);
+        const uint64_t before = acc;
+        acc = is_s ? sacc : is_pop ? pacc : acc;
+        if (!DEEP) {
+            const uint64_t n0 = is_push ? before : is_pop ? s1 : s0;
+            s1 = is_push ? s0 : s1;
+            s0 = n0;
+        } else {
+            if (is_push) {
+                if (sp >= 4) deep[sp - 4] = s3;
+                s3 = s2; s2 = s1; s1 = s0; s0 = before;
+                sp++;
+            }
+            if (is_pop) {
+                s0 = s1; s1 = s2; s2 = s3;
+                sp--;
+                if (sp >= 4) s3 = deep[sp - 4];
+            }
+        }
+        if (__any(op == kFopNot || op == kFopInord)) {          // only around INORD groups
+            if (op == kFopNot) acc = ~acc;
+            // candidates: documents where the group's boolean value is true (rval, expression.go:137)
+            if (op == kFopInord) acc = inord_docs(S, a, acc & valid, d0);
+        }
+    }
+    return acc;
+}
+
+// PROG_LDS: the fused programs (and their offsets) are staged in LDS once per workgroup, so the interpreter's
+// dependent word-after-word fetches cost an LDS round trip instead of an L2 one
+template <bool P_LDS, bool PROG_LDS>
 __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const SolveParams S) {
     extern __shared__ __align__(16) uint8_t smem[];
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
@@ -119,6 +195,15 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
     uint64_t* P = P_LDS ? reinterpret_cast<uint64_t*>(smem) : S.p_scratch + (size_t)blockIdx.x * S.n_slots;
     uint32_t* O = reinterpret_cast<uint32_t*>(smem + (P_LDS ? (((size_t)S.n_slots * 8 + 15) & ~(size_t)15) : 0));   // [64][tile_words]
     uint32_t* Pw = reinterpret_cast<uint32_t*>(P);
+    uint64_t* R = reinterpret_cast<uint64_t*>(O + 64 * tile_words);   // [tile_words * 32] results by expression
+    uint32_t* lprog = reinterpret_cast<uint32_t*>(R + tile_words * 32);  // [fprog_words] when PROG_LDS
+    uint32_t* loff = lprog + S.fprog_words;                     // [n_exprs + 1]
+    uint32_t* lorder = loff + S.n_exprs + 1;                    // [n_exprs]
+    if (PROG_LDS) {
+        for (uint32_t i = threadIdx.x; i < S.fprog_words; i += kSolveBlockThreads) lprog[i] = S.fprog[i];
+        for (uint32_t i = threadIdx.x; i <= S.n_exprs; i += kSolveBlockThreads) loff[i] = (uint32_t)S.fprog_off[i];
+        for (uint32_t i = threadIdx.x; i < S.n_exprs; i += kSolveBlockThreads) lorder[i] = S.order[i];
+    }
 
     for (uint32_t i = threadIdx.x; i < S.n_slots; i += kSolveBlockThreads) {
         if (P_LDS) P[i] = 0;
@@ -159,63 +244,35 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
         if (!P_LDS) __threadfence_block();
         __syncthreads();
 
-        // ---- 2. expressions, 64 per wave round, tile by tile over the bitmap words -----------------------------------
+        // ---- 2. expressions, tile by tile over the bitmap words ------------------------------------------------------
+        const uint64_t valid = nd == 64 ? ~0ull : ((1ull << nd) - 1);
         for (uint32_t w0 = 0; w0 < bm_words; w0 += tile_words) {
             const uint32_t tw = bm_words - w0 < tile_words ? bm_words - w0 : tile_words;
+            const uint32_t e0 = w0 << 5;                                          // first expression of the tile
+            const uint32_t ne = S.n_exprs - e0 < (tw << 5) ? S.n_exprs - e0 : (tw << 5);
+            // 2a. evaluation in sorted order (gft_set_programs): 64 programs of similar length per wave.  Sixteen blocks
+            // at a time, longest first, dealt to the waves in a snake over the four SIMDs so that the SIMDs get similar sums
+            const uint32_t nblk = (ne + 63) / 64;
+            for (uint32_t b16 = 0; b16 < nblk && !(S.dbg & 2); b16 += kWaves) {
+                const uint32_t row = wave >> 2, c4 = wave & 3;
+                const uint32_t b = b16 + row * 4 + ((row & 1) ? 3 - c4 : c4);
+                const uint32_t i = b * 64 + lane;
+                if (b < nblk && i < ne) {
+                    const uint32_t e = PROG_LDS ? lorder[e0 + i] : S.order[e0 + i];
+                    const uint64_t po = PROG_LDS ? loff[e] : S.fprog_off[e];
+                    const uint32_t len = (uint32_t)((PROG_LDS ? loff[e + 1] : S.fprog_off[e + 1]) - po);
+                    const uint32_t* prog = (PROG_LDS ? lprog : S.fprog) + po;
+                    const bool deep = S.blk_deep[(e0 >> 6) + b] != 0;              // wave-uniform
+                    R[e - e0] = deep ? run_program<P_LDS, true>(S, P, prog, len, valid, d0)
+                                     : run_program<P_LDS, false>(S, P, prog, len, valid, d0);
+                }
+            }
+            __syncthreads();
+            // 2b. transpose in natural order: lane j ends up with the two bitmap words of document j for 64 expressions
             const uint32_t rounds = (tw + 1) / 2;
             for (uint32_t r = wave; r < rounds; r += kWaves) {
-                const uint32_t e = (w0 << 5) + r * 64 + lane;
-                uint64_t acc = 0;
-                if (e < S.n_exprs && !(S.dbg & 2)) {
-                    uint64_t stk[kMaxBoolDepth];
-                    uint32_t sp = 0;
-                    const uint64_t po = S.fprog_off[e];
-                    const uint32_t len = (uint32_t)(S.fprog_off[e + 1] - po);
-                    const uint32_t* prog = S.fprog + po;
-                    for (uint32_t pc = 0; pc < len; pc++) {
-                        const uint32_t w = prog[pc];
-                        const uint32_t a = w & 0x0FFFFFFFu;
-                        // HBM-resident P was written with L2 atomics by other waves: read it past this CU's L1
-                        auto ld = [&](uint32_t slot) -> uint64_t {
-                            return P_LDS ? P[slot]
-                                         : __hip_atomic_load(&P[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        };
-                        switch (w >> 28) {
-                        case kFopLoad: stk[sp++] = acc; acc = ld(a); break;
-                        case kFopAndS: acc &= ld(a); break;
-                        case kFopOrS: acc |= ld(a); break;
-                        case kFopAndNS: acc &= ~ld(a); break;
-                        case kFopOrNS: acc |= ~ld(a); break;
-                        case kFopAndPop: acc &= stk[--sp]; break;
-                        case kFopOrPop: acc |= stk[--sp]; break;
-                        case kFopNot: acc = ~acc; break;
-                        case kFopInord: {
-                            // candidates: documents where the group's boolean value is true (rval, expression.go:137)
-                            uint64_t m = acc & (nd == 64 ? ~0ull : ((1ull << nd) - 1)), res = 0;
-                            const uint32_t goff = S.groups[a * 2], glen = S.groups[a * 2 + 1];
-                            while (m) {
-                                const uint32_t j = (uint32_t)__builtin_ctzll(m);
-                                m &= m - 1;
-                                const uint64_t d = d0 + j;
-                                DocHits M;
-                                M.unit_start = S.unit_start; M.unit_count = S.unit_count;
-                                M.term = S.term; M.pos = S.pos;
-                                M.u0 = S.doc_unit_base[d]; M.u1 = S.doc_unit_base[d + 1];
-                                M.nx = 0; M.xslot = nullptr; M.xpos = nullptr;
-                                if (S.x_off) {
-                                    const uint64_t x0 = S.x_off[d];
-                                    M.xslot = S.x_slot + x0; M.xpos = S.x_pos + x0; M.nx = (uint32_t)(S.x_off[d + 1] - x0);
-                                }
-                                if (inord_group_nonempty(S.gprog + goff, glen, M)) res |= 1ull << j;
-                            }
-                            acc = res;
-                            break;
-                        }
-                        default: break;
-                        }
-                    }
-                }
-                // transpose: lane j ends up with the two bitmap words of document j for these 64 expressions
+                const uint32_t el = r * 64 + lane;
+                const uint64_t acc = (el < ne && !(S.dbg & 2)) ? R[el] : 0;
                 uint64_t mine = 0;
 #pragma unroll 8
                 for (uint32_t j = 0; j < 64 && !(S.dbg & 4); j++) {
@@ -264,19 +321,21 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
 
 }  // namespace
 
-size_t solve_lds_bytes(uint32_t n_slots, uint32_t tile_words, bool p_in_lds) {
-    return (p_in_lds ? (((size_t)n_slots * 8 + 15) & ~(size_t)15) : 0) + (size_t)64 * tile_words * 4;
+size_t solve_lds_bytes(uint32_t n_slots, uint32_t tile_words, bool p_in_lds, uint32_t prog_words, uint32_t n_exprs,
+                       bool prog_in_lds) {
+    return (p_in_lds ? (((size_t)n_slots * 8 + 15) & ~(size_t)15) : 0) + (size_t)64 * tile_words * 4 +
+           (size_t)tile_words * 32 * 8 + (prog_in_lds ? ((size_t)prog_words + 2 * (size_t)n_exprs + 1) * 4 : 0);
 }
 
-hipError_t launch_solve(const SolveParams& S, bool p_in_lds, unsigned grid, hipStream_t st) {
+hipError_t launch_solve(const SolveParams& S, bool p_in_lds, bool prog_in_lds, unsigned grid, hipStream_t st) {
     if (!S.n_docs || !S.n_exprs) return hipSuccess;
-    const size_t lds = solve_lds_bytes(S.n_slots, S.tile_words, p_in_lds);
-    const void* fn = p_in_lds ? reinterpret_cast<const void*>(k_solve_groups<true>)
-                              : reinterpret_cast<const void*>(k_solve_groups<false>);
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds = solve_lds_bytes(S.n_slots, S.tile_words, p_in_lds, S.fprog_words, S.n_exprs, prog_in_lds);
+    using Kern = void (*)(const SolveParams);
+    const Kern fn = p_in_lds ? (prog_in_lds ? k_solve_groups<true, true> : k_solve_groups<true, false>)
+                             : (prog_in_lds ? k_solve_groups<false, true> : k_solve_groups<false, false>);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    if (p_in_lds) k_solve_groups<true><<<dim3(grid), dim3(kSolveBlockThreads), lds, st>>>(S);
-    else k_solve_groups<false><<<dim3(grid), dim3(kSolveBlockThreads), lds, st>>>(S);
+    fn<<<dim3(grid), dim3(kSolveBlockThreads), lds, st>>>(S);
     return hipGetLastError();
 }
 

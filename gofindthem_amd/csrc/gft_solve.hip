@@ -6,10 +6,12 @@
 //      scan kernel's match slabs with ds_or (UNIT truth == key presence, dsl/expression.go:68-72);
 //   2. every lane interprets ONE expression over 64-bit masks, so each AND/OR/NOT evaluates 64 documents at once
 //      (the reference evaluates every node, no short-circuit, so this is the same function, expression.go:74-127);
+//      programs are fused at gft_set_programs time (gft_api.cpp fuse_program), staged in LDS and handed to the waves
+//      sorted by length;
 //   3. INORD(...) groups: the boolean value of the group's subtree gives the candidate documents; only for those
 //      the position algebra runs, per document, on (slot, theta) pairs with successor queries;
-//   4. the 64 x 64 result tile of a wave is transposed with __ballot so that lane d holds the two bitmap words of
-//      document d, staged in LDS and written out as full rows.
+//   4. the 64 x 64 result tile of a wave is transposed (six masked exchange steps) so that lane d holds the two
+//      bitmap words of document d, staged in LDS and written out as full rows.
 // No MFMA: boolean algebra on bit masks; LDS- and latency-bound.
 #include <hip/hip_runtime.h>
 
@@ -107,6 +109,24 @@ __device__ bool inord_group_nonempty(const uint32_t* __restrict__ prog, uint32_t
     for (uint32_t i = 0; i < c; i++)
         if (succ_query(M, pairs[b + i].slot, pairs[b + i].theta) != INT64_MAX) return true;
     return false;
+}
+
+// 64 x 64 bit-matrix transpose across a wave: lane i holds row i; afterwards lane j holds column j (bit i = old row
+// i's bit j).  Six exchange steps with the partner lane i ^ s, swapping the off-diagonal s x s blocks.
+template <int SH>
+__device__ __forceinline__ uint64_t transpose_step(uint64_t x, uint32_t lane, uint64_t m) {
+    const uint64_t t = __shfl_xor(x, SH, 64);
+    return (lane & SH) ? ((t >> SH) & m) | (x & ~m) : (x & m) | ((t & m) << SH);
+}
+__device__ __forceinline__ uint64_t wave_transpose64(uint64_t x) {
+    const uint32_t lane = lane_id();
+    x = transpose_step<32>(x, lane, 0x00000000FFFFFFFFull);
+    x = transpose_step<16>(x, lane, 0x0000FFFF0000FFFFull);
+    x = transpose_step<8>(x, lane, 0x00FF00FF00FF00FFull);
+    x = transpose_step<4>(x, lane, 0x0F0F0F0F0F0F0F0Full);
+    x = transpose_step<2>(x, lane, 0x3333333333333333ull);
+    x = transpose_step<1>(x, lane, 0x5555555555555555ull);
+    return x;
 }
 
 // documents of `cand` (bit j = document d0 + j) whose INORD group `grp` has a non-empty position list
@@ -212,24 +232,45 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
     __syncthreads();
 
     const uint64_t n_groups = (S.n_docs + 63) / 64;
+    // unit range + first slab of this thread's document in the NEXT group (consumed by step 1 of that group)
+    uint64_t pf_u0 = 0, pf_u1 = 0, pf_s = 0;
+    uint32_t pf_n = 0;
+    auto prefetch = [&](uint64_t g) {
+        const uint64_t d = g * 64 + threadIdx.x / kTeam;
+        pf_u0 = pf_u1 = 0; pf_n = 0;
+        if (g < n_groups && d < S.n_docs) {
+            pf_u0 = S.doc_unit_base[d]; pf_u1 = S.doc_unit_base[d + 1];
+            if (pf_u1 > pf_u0) { pf_s = S.unit_start[pf_u0]; pf_n = S.unit_count[pf_u0]; }
+        }
+    };
+    prefetch(blockIdx.x);
     for (uint64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
         const uint64_t d0 = g * 64;
         const uint32_t nd = (uint32_t)(S.n_docs - d0 < 64 ? S.n_docs - d0 : 64);
 
         // ---- 1. presence matrix ------------------------------------------------------------------------------
-        // a team of kTeam lanes per document, all documents of the group at once (short dependent-load chains)
+        // a team of kTeam lanes per document, all documents of the group at once.  The document's unit range and its
+        // first unit's slab were fetched while the previous group was evaluated (pf_*); four slab entries per lane are
+        // in flight at a time
         for (uint32_t j = threadIdx.x / kTeam; j < nd && !(S.dbg & 1); j += kSolveBlockThreads / kTeam) {
             const uint32_t member = threadIdx.x % kTeam;
             const uint64_t d = d0 + j;
             const uint32_t bit = 1u << (j & 31), half = j >> 5;
-            const uint64_t u0 = S.doc_unit_base[d], u1 = S.doc_unit_base[d + 1];
+            const bool pf = j == threadIdx.x / kTeam;              // first (normally only) document of this team
+            const uint64_t u0 = pf ? pf_u0 : S.doc_unit_base[d], u1 = pf ? pf_u1 : S.doc_unit_base[d + 1];
             for (uint64_t u = u0; u < u1; u++) {
-                const uint64_t s = S.unit_start[u];
-                const uint32_t n = S.unit_count[u];
-                for (uint32_t i = member; i < n; i += kTeam) {
-                    const uint32_t t = S.term[s + i];
-                    if (P_LDS) __hip_atomic_fetch_or(&Pw[t * 2 + half], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    else atomicOr(&Pw[(size_t)t * 2 + half], bit);
+                const uint64_t s = (pf && u == u0) ? pf_s : S.unit_start[u];
+                const uint32_t n = (pf && u == u0) ? pf_n : S.unit_count[u];
+                for (uint32_t i = member; i < n; i += 4 * kTeam) {
+                    uint32_t t[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) t[q] = i + q * kTeam < n ? S.term[s + i + q * kTeam] : 0xFFFFFFFFu;
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        if (t[q] != 0xFFFFFFFFu) {
+                            if (P_LDS) __hip_atomic_fetch_or(&Pw[t[q] * 2 + half], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            else atomicOr(&Pw[(size_t)t[q] * 2 + half], bit);
+                        }
                 }
             }
             if (S.x_off) {
@@ -243,6 +284,8 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
         }
         if (!P_LDS) __threadfence_block();
         __syncthreads();
+
+        prefetch(g + gridDim.x);
 
         // ---- 2. expressions, tile by tile over the bitmap words ------------------------------------------------------
         const uint64_t valid = nd == 64 ? ~0ull : ((1ull << nd) - 1);
@@ -273,12 +316,7 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
             for (uint32_t r = wave; r < rounds; r += kWaves) {
                 const uint32_t el = r * 64 + lane;
                 const uint64_t acc = (el < ne && !(S.dbg & 2)) ? R[el] : 0;
-                uint64_t mine = 0;
-#pragma unroll 8
-                for (uint32_t j = 0; j < 64 && !(S.dbg & 4); j++) {
-                    const uint64_t b = __ballot((acc >> j) & 1);
-                    if (lane == j) mine = b;
-                }
+                const uint64_t mine = (S.dbg & 4) ? 0 : wave_transpose64(acc);
                 O[lane * tile_words + r * 2] = (uint32_t)mine;
                 if (r * 2 + 1 < tw) O[lane * tile_words + r * 2 + 1] = (uint32_t)(mine >> 32);
             }

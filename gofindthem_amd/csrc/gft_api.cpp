@@ -61,9 +61,10 @@ struct gft_engine {
     Scan2Tables s2;
     bool use_scan2 = false;
     DevBuf d_s2_filter, d_s2_slots, d_s2_more, d_s2_cls, d_s2_cls_fold, d_s2_term_blob, d_s2_term_off, d_nmatches, d_dbg;
-    DevBuf d_s2_short3, d_s2_shorts_packed, d_s2_fpt;
+    DevBuf d_s2_short3, d_s2_shorts_packed, d_s2_short3_big, d_s2_fpt;
     uint32_t scan2_short3_bytes = 0;
     uint32_t scan2_k2_waves = 0, scan2_cand_cap = 0;    // scan2_plan
+    uint32_t scan2_unit_max = kScan2UnitMax;            // bytes per work unit (adapts to the match density)
 
     // programs
     bool have_programs = false;
@@ -308,7 +309,9 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         return GFT_OK;
     }
     const uint32_t warm = e->tab.max_term_len ? e->tab.max_term_len - 1 : 0;
-    const uint32_t unit_max = e->use_scan2 ? kScan2UnitMax : kTextBuf - warm;
+    // gft_scan2: a unit's matches should fit the wave's LDS fifo (kScan2FifoCap), so the unit size follows the match
+    // density the previous call saw (dense dictionaries -> smaller units); results do not depend on it
+    const uint32_t unit_max = e->use_scan2 ? e->scan2_unit_max : kTextBuf - warm;
 
     // 1. work units
     HIP_TRY(e->d_unit_cnt.ensure(n_docs * 4), "unit alloc");
@@ -351,7 +354,8 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         P.hashed = e->s2.hashed ? 1 : 0; P.hash_shift = e->s2.hash_shift;
         P.short3 = e->d_s2_short3.as<uint8_t>(); P.short3_bytes = e->scan2_short3_bytes;
         P.fpt = e->d_s2_fpt.as<uint8_t>();
-        P.shorts_packed = e->d_s2_shorts_packed.as<uint32_t>(); P.shorts_words = (uint32_t)e->s2.shorts_packed.size();
+        P.shorts_packed = e->d_s2_shorts_packed.as<uint32_t>(); P.shorts_words = (uint32_t)std::min<size_t>(e->s2.shorts_packed.size(), 255 * 3);
+        P.short3_big = e->s2.short3_big.empty() ? nullptr : e->d_s2_short3_big.as<uint32_t>();
         P.cand_cap = e->scan2_cand_cap;
         P.slots = e->d_s2_slots.as<Scan2Slot>(); P.slot_shift = e->s2.slot_shift;
         P.more = e->d_s2_more.as<Scan2Slot>();
@@ -392,7 +396,16 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
                     (unsigned long long)n_units, (unsigned long long)c4[0], (unsigned long long)c4[1],
                     (unsigned long long)c4[2], (unsigned long long)total);
         }
-        if (cursor <= e->pool_cap) break;
+        if (cursor <= e->pool_cap) {
+            if (!need_csr && text_hi > text_lo) {
+                // a unit of maximal size should fill ~75 % of the fifo
+                const double per_byte = (double)total / (double)(text_hi - text_lo);
+                const double want = per_byte > 0 ? 0.75 * kScan2FifoCap / per_byte : (double)kScan2UnitMax;
+                uint32_t um = want >= kScan2UnitMax ? kScan2UnitMax : (uint32_t)want & ~255u;
+                e->scan2_unit_max = std::max<uint32_t>(512, um);
+            }
+            break;
+        }
         if (attempt == 2) return fail(e, GFT_E_HIP, "match pool overflow persisted");
         rc = ensure_pool(e, cursor + cursor / 16);
         if (rc) return rc;
@@ -524,7 +537,7 @@ void gft_engine_destroy(gft_engine* e) {
         DevBuf* all[] = {&e->d_byte_class, &e->d_delta, &e->d_out_term, &e->d_out_link, &e->d_term_len, &e->d_prog,
                          &e->d_prog_off, &e->d_fprog, &e->d_fprog_off, &e->d_groups, &e->d_order, &e->d_blk_deep, &e->d_pscratch, &e->d_s2_filter,
                          &e->d_s2_slots, &e->d_s2_more, &e->d_s2_cls, &e->d_s2_cls_fold, &e->d_s2_term_blob,
-                         &e->d_s2_term_off, &e->d_nmatches, &e->d_dbg, &e->d_s2_short3, &e->d_s2_shorts_packed, &e->d_s2_fpt,
+                         &e->d_s2_term_off, &e->d_nmatches, &e->d_dbg, &e->d_s2_short3, &e->d_s2_shorts_packed, &e->d_s2_short3_big, &e->d_s2_fpt,
 &e->d_unit_cnt, &e->d_unit_base, &e->d_units, &e->d_partial, &e->d_cursor,
                          &e->d_pool_term, &e->d_pool_pos, &e->d_unit_start, &e->d_unit_count, &e->d_unit_out,
                          &e->d_term, &e->d_pos, &e->d_match_off, &e->d_text, &e->d_doc_off, &e->d_bitmap, &e->d_xoff,
@@ -585,7 +598,7 @@ int gft_build(gft_engine* e, const uint8_t* terms_blob, const uint64_t* term_off
     build_scan2_tables(e->tab, e->s2);
     const char* force = getenv("GFT_SCAN_KERNEL");
     const bool k2_fits = e->s2.supported && scan2_plan((uint32_t)e->s2.filter.size(), (uint32_t)e->s2.short3.size(),
-                                                        (uint32_t)e->s2.shorts_packed.size(), e->lds_max - 512,
+                                                        (uint32_t)std::min<size_t>(e->s2.shorts_packed.size(), 255 * 3), e->lds_max - 512,
                                                         &e->scan2_k2_waves, &e->scan2_cand_cap);
     e->use_scan2 = k2_fits && !(force && std::string(force) == "dfa");
     if (e->use_scan2 && getenv("GFT_SCAN_DEBUG")) {
@@ -602,6 +615,7 @@ int gft_build(gft_engine* e, const uint8_t* terms_blob, const uint64_t* term_off
         if (e->s2.short3.empty()) e->s2.short3.assign(16, 0);   // placeholder upload; short3_bytes stays 0
         if ((rc = upload(e, e->d_s2_short3, e->s2.short3, "table upload"))) return rc;
         if ((rc = upload(e, e->d_s2_shorts_packed, e->s2.shorts_packed, "table upload"))) return rc;
+        if (!e->s2.short3_big.empty() && (rc = upload(e, e->d_s2_short3_big, e->s2.short3_big, "table upload"))) return rc;
         if ((rc = upload(e, e->d_s2_fpt, e->s2.fpt, "table upload"))) return rc;
         std::vector<uint8_t> c1(e->s2.cls, e->s2.cls + 256), c2(e->s2.cls_fold, e->s2.cls_fold + 256);
         if ((rc = upload(e, e->d_s2_cls, c1, "table upload"))) return rc;
@@ -615,6 +629,7 @@ int gft_build(gft_engine* e, const uint8_t* terms_blob, const uint64_t* term_off
     HIP_TRY(e->d_nmatches.ensure(8), "table upload");
     HIP_TRY(hipStreamSynchronize(e->stream), "table upload");
     e->built = true;
+    e->scan2_unit_max = kScan2UnitMax;
     e->have_programs = false;   // slots refer to the dictionary: programs must be set again
     e->n_exprs = 0;
     return GFT_OK;

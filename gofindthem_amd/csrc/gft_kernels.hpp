@@ -182,7 +182,8 @@ struct Scan2Params {
     const uint8_t* short3;       // [short3_bytes] record id per 3-window, copied to LDS (short3_bytes == 0: no short terms)
     uint32_t short3_bytes;
     const uint32_t* shorts_packed;   // 3 words per record (term_id | len << 28, longest first, 0 = none), copied to LDS
-    uint32_t shorts_words;
+    uint32_t shorts_words;       // words staged in LDS (at most 255 records)
+    const uint32_t* short3_big;  // full record id per 3-window for LDS byte 255 (nullptr: every record has an LDS id)
     uint32_t cand_cap;           // entries of a wave's LDS candidate list (scan2_plan)
     const uint8_t* fpt;          // [kScan2FptSize], copied to LDS
     const Scan2Slot* slots;      // 2^lg slots, slot_shift = 32 - lg

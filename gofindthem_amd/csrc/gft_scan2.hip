@@ -81,7 +81,7 @@ struct Ctx {
 // Positions before the document start need no special casing here: the bytes there (the previous document's, or
 // zeros in front of the blob) can only change keys of windows that reach across the start, and every term such a
 // window may name is longer than p + 1 and is dropped by the length check at emission.
-struct Cand { uint32_t p, x, tw, sid; bool go_long; };
+struct Cand { uint32_t p, x, x3, tw, sid; bool go_long; };
 struct Text8 { uint32_t tw, w; };
 __device__ __forceinline__ Text8 cand_load_slow(const Ctx& c, uint32_t p) {   // within 7 bytes of the blob start
     Text8 t{0, 0};
@@ -111,6 +111,7 @@ __device__ __forceinline__ void cand_keys(const Ctx& c, uint32_t p, const Text8 
     const uint32_t lo = mad24(c2, kp, c.cls[w >> 24]);           // key = (c0 kp + c1) kp^2 + (c2 kp + c3)
     const uint32_t x3 = mad24(c1, c.kp2, lo);
     k.x = mad24(mad24(c0, kp, c1), c.kp2, lo);
+    k.x3 = x3;
     k.sid = c.short3 ? c.short3[x3] : 0;
 }
 // LDS-only decision: can a term of length >= 4 end here at all (fingerprint of the bytes in front of the window)?
@@ -212,6 +213,13 @@ __device__ __forceinline__ bool entry_ok(const Ctx& c, uint32_t p, const Front& 
     return ok;
 }
 
+// the three words of short-term record `sid` of 3-window x3 (LDS; ids beyond 254 live in global memory)
+__device__ __forceinline__ void short_record(const Ctx& c, uint32_t sid, uint32_t x3, uint32_t (&r)[3]) {
+    const uint32_t* src = c.lrec + 3 * sid;
+    if (__builtin_expect(sid == 255 && c.P.short3_big != nullptr, 0)) src = c.P.shorts_packed + 3 * (size_t)c.P.short3_big[x3];
+    r[0] = src[0]; r[1] = src[1]; r[2] = src[2];
+}
+
 // step 3 (ordered path): all terms that end at p, longest first.  MODE 0: count and stage per lane in LDS;
 // MODE 1: write to the pool at out_base.
 template <int MODE>
@@ -251,11 +259,11 @@ __device__ __forceinline__ void cand_finish(const Ctx& c, const Cand& k, uint32_
     }
     // ---- terms of length <= 3 (records from the LDS 3-window table) -------------------------------------------------------
     if (k.sid) {
+        uint32_t r[3];
+        short_record(c, k.sid, k.x3, r);
 #pragma unroll
-        for (uint32_t j = 0; j < 3; j++) {
-            const uint32_t e = c.lrec[3 * k.sid + j];
-            if (e && (e >> 28) <= p + 1) emit(e & 0x0FFFFFFFu, e >> 28);
-        }
+        for (uint32_t j = 0; j < 3; j++)
+            if (r[j] && (r[j] >> 28) <= p + 1) emit(r[j] & 0x0FFFFFFFu, r[j] >> 28);
     }
 }
 
@@ -271,10 +279,10 @@ __device__ __forceinline__ void fifo_append(bool em, uint32_t term, uint32_t pos
 }
 
 // terms of length <= 3 ending at the lanes' positions (sid = 0: none); wave-uniform call
-__device__ __forceinline__ void finish_short(const Ctx& c, uint32_t p, uint32_t sid, uint2* fifo, uint32_t& nf) {
+__device__ __forceinline__ void finish_short(const Ctx& c, uint32_t p, uint32_t sid, uint32_t x3, uint2* fifo, uint32_t& nf) {
     if (!__any(sid != 0)) return;
     uint32_t r[3] = {0, 0, 0};
-    if (sid) { r[0] = c.lrec[3 * sid]; r[1] = c.lrec[3 * sid + 1]; r[2] = c.lrec[3 * sid + 2]; }
+    if (sid) short_record(c, sid, x3, r);
 #pragma unroll
     for (uint32_t j = 0; j < 3; j++) {
         if (j && !__any(r[j] != 0)) break;
@@ -569,8 +577,8 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
                         Cand ka, kb;
                         cand_keys(c, pa, ta, ka); cand_keys(c, pb, tb, kb);
                         cand_decide(c, ka); cand_decide(c, kb);
-                        finish_short(c, pa, on_a ? ka.sid : 0, fifo, nf);
-                        finish_short(c, pb, on_b ? kb.sid : 0, fifo, nf);
+                        finish_short(c, pa, on_a ? ka.sid : 0, ka.x3, fifo, nf);
+                        finish_short(c, pb, on_b ? kb.sid : 0, kb.x3, fifo, nf);
                         // all reads of this trip are done (ia, ib >= every write index below)
                         const uint64_t sa = __ballot(on_a && ka.go_long), sb = __ballot(on_b && kb.go_long);
                         const uint64_t below = (1ull << lane) - 1;

@@ -79,13 +79,17 @@ void build_scan2_tables(const AcTables& ac, Scan2Tables& t) {
             std::sort(v.begin(), v.end(), [&](uint32_t a, uint32_t b) { return ac.terms[a].size() > ac.terms[b].size(); });
             auto it = ids.find(v);
             if (it == ids.end()) {
-                if (t.shorts.size() > 255) { t.why_not = "too many distinct short-term combinations"; return; }
                 Scan2Short r{(uint32_t)v.size(), {0, 0, 0}, {0, 0, 0}, 0};
                 for (size_t i = 0; i < v.size() && i < 3; i++) { r.term[i] = v[i]; r.len[i] = (uint32_t)ac.terms[v[i]].size(); }
                 it = ids.emplace(v, (uint32_t)t.shorts.size()).first;
                 t.shorts.push_back(r);
             }
-            t.short3[w] = (uint8_t)it->second;
+            // the LDS byte table names the first 254 records; 255 = "look the id up in short3_big" (global memory)
+            t.short3[w] = (uint8_t)std::min<uint32_t>(it->second, 255);
+            if (it->second >= 255) {
+                if (t.short3_big.empty()) t.short3_big.assign(t.short3.size(), 0);
+                t.short3_big[w] = it->second;
+            }
             for (uint32_t c0 = 0; c0 < kp; c0++) set_filter((uint32_t)(c0 * kp3 + w));   // any class may precede
         }
     }

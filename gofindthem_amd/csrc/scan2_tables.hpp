@@ -39,6 +39,7 @@ struct Scan2Tables {
     std::vector<uint32_t> filter;    // filter_bits / 32 words
     std::vector<uint8_t> short3;     // [kp^3 rounded up to 16] record id (0 = none) per 3-window
     std::vector<Scan2Short> shorts;  // record 0 unused
+    std::vector<uint32_t> short3_big;      // [short3.size()] full record id per 3-window; empty unless > 254 records exist
     std::vector<uint32_t> shorts_packed;   // 3 words per record: term_id | len << 28, longest first, 0 = none
     std::vector<uint8_t> fpt;        // [kScan2FptSize]
     uint32_t slot_shift = 0;         // slot index = scan2_slot_hash(key, 0 or 1, slot_shift)

@@ -59,6 +59,17 @@ SYMBOLS = {
     "gft_finder_debug_add_literal": (_i, [_vp, _i, C.c_char_p, _u32]),
     "gft_finder_debug_set_updated": (_i, [_vp, _i, _i]),
     "gft_finder_debug_get_updated": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    "gft_group_create": (_i, [C.POINTER(_vp), _vp]),
+    "gft_group_destroy": (None, [_vp]),
+    "gft_group_last_error": (C.c_char_p, [_vp]),
+    "gft_group_add_rule": (_i, [_vp, C.c_char_p, _u64, C.c_char_p, _u64]),
+    "gft_group_state": (_i, [_vp, _vp, _u64, C.POINTER(_u64)]),
+    "gft_group_process_jsons": (_i, [_vp, _vp, _vp, _u64, C.c_char_p, _u64, C.c_char_p, _u64, _i, _vp, _u64, C.POINTER(_u64)]),
+    "gft_group_last_result": (_i, [_vp, _vp, _u64, C.POINTER(_u64)]),
+    "gft_group_evaluate": (_i, [_vp, C.c_char_p, _u64, _vp, _u64, C.POINTER(_u64)]),
+    "gft_group_last_batch": (_i, [_vp, C.POINTER(_u64), C.POINTER(_u64)]),
+    "gft_group_dsl_parse": (_i, [C.c_char_p, _u64, _vp, _u64, C.POINTER(_u64)]),
+    "gft_group_dsl_tokens": (_i, [C.c_char_p, _u64, _vp, _u64, C.POINTER(_u64)]),
     "gft_dsl_parse": (_i, [C.c_char_p, _u64, _i, _vp, _u64, C.POINTER(_u64)]),
     "gft_dsl_tokens": (_i, [C.c_char_p, _u64, _vp, _u64, C.POINTER(_u64)]),
     "gft_to_lower": (_i, [C.c_char_p, _u64, _vp, _u64, C.POINTER(_u64)]),

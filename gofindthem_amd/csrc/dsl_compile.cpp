@@ -72,6 +72,9 @@ int32_t lower_rune(int32_t cp) {
 std::string rune_str(int32_t cp) { std::string s; encode_rune(cp, s); return s; }
 }  // namespace
 
+int32_t DecodeRune(const std::string& s, size_t i, size_t* adv) { return decode_rune(s, i, adv); }
+void EncodeRune(int32_t cp, std::string& out) { encode_rune(cp, out); }
+
 bool IsAscii(const std::string& s) {
     for (unsigned char c : s) if (c >= 0x80) return false;
     return true;

@@ -50,6 +50,10 @@ struct ParseResult {
 
 ParseResult Parse(const std::string& src, bool case_sensitive);
 
+// UTF-8 as Go reads it: an invalid byte decodes to U+FFFD (advance 1) and is re-encoded as such
+int32_t DecodeRune(const std::string& s, size_t i, size_t* adv);
+void EncodeRune(int32_t cp, std::string& out);
+
 // strings.ToLower for the parser's literals and for document text (Unicode simple case mapping)
 std::string ToLower(const std::string& s);
 bool IsAscii(const std::string& s);

@@ -324,6 +324,9 @@ struct gft_finder {
     std::string err, json;
 };
 
+// for group_host.cpp: the C++ object behind the handle
+gft::Finder* gft_finder_impl(gft_finder* f) { return f ? f->finder.get() : nullptr; }
+
 extern "C" {
 
 int gft_finder_create(gft_finder** out, int case_sensitive, int device) {

@@ -172,6 +172,34 @@ int gft_finder_debug_add_literal(gft_finder* f, int which, const uint8_t* lit, u
 int gft_finder_debug_set_updated(gft_finder* f, int updated_sub, int updated_rgx);
 int gft_finder_debug_get_updated(const gft_finder* f, int* updated_sub, int* updated_rgx);
 
+/* ---- Group finder: group/finder/finder.go + group/dsl on top of a finder --------------------
+ * The tag-rule DSL and the object walk run on the host; every string leaf of every JSON document of a call becomes one
+ * document of ONE batch through the finder (the reference runs one ProcessText per leaf, group/finder/internal.go:28-31).
+ * Results are JSON documents written like the gft_dsl_* calls below (out/cap/needed). */
+typedef struct gft_group gft_group;
+int gft_group_create(gft_group** out, gft_finder* finder);      /* NewFinder(findthem) (finder.go:28-35); finder is borrowed */
+void gft_group_destroy(gft_group* g);
+const char* gft_group_last_error(const gft_group* g);
+/* AddRule(ruleName, []string{expr}) (finder.go:45-66): GFT_E_PARSE + the reference's error text on malformed input */
+int gft_group_add_rule(gft_group* g, const uint8_t* name, uint64_t name_len, const uint8_t* expr, uint64_t expr_len);
+/* {"rules":{name:[{"ExpressionString":..,"Expression":{tree}}]},"fields":[..],"tags":[..]} (the struct finder_test.go compares) */
+int gft_group_state(const gft_group* g, char* out, uint64_t cap, uint64_t* needed);
+/* ProcessJson (what = 0, finder.go:160-172) / TagJson (what = 1, finder.go:80-92) over a batch of raw JSON documents
+ * (blob + offsets).  include/exclude: JSON arrays of path prefixes, or NULL.  Output: one element per document,
+ * {"rules":{rule:[expressions]}} / {"tags":{tag:{field:[expressions]}}} or {"error":"..."} */
+int gft_group_process_jsons(gft_group* g, const uint8_t* json_blob, const uint64_t* doc_off, uint64_t n_docs,
+                            const uint8_t* include_json, uint64_t include_len, const uint8_t* exclude_json,
+                            uint64_t exclude_len, int what, char* out, uint64_t cap, uint64_t* needed);
+/* the document of the last gft_group_process_jsons call again (it is kept, so a too-small buffer costs no second run) */
+int gft_group_last_result(const gft_group* g, char* out, uint64_t cap, uint64_t* needed);
+/* EvaluateRules (finder.go:118-137) on a caller-supplied {tag:{field:[expressions]}} map -> {rule:[expressions]} */
+int gft_group_evaluate(gft_group* g, const uint8_t* tagmap_json, uint64_t len, char* out, uint64_t cap, uint64_t* needed);
+/* string leaves and text bytes the last gft_group_process_jsons call sent through the finder (measurement) */
+int gft_group_last_batch(const gft_group* g, uint64_t* leaves, uint64_t* bytes);
+/* group DSL alone (host only): {"tree":..,"tags":[..],"fields":[..]} or {"error":..}; token list as gft_dsl_tokens */
+int gft_group_dsl_parse(const uint8_t* expr, uint64_t len, char* out, uint64_t cap, uint64_t* needed);
+int gft_group_dsl_tokens(const uint8_t* expr, uint64_t len, char* out, uint64_t cap, uint64_t* needed);
+
 /* ---- DSL front-end alone (host only, no device needed) ------------------------------------------------------
  * Each writes a NUL-terminated JSON document into out (cap bytes) and the size it needs into *needed; returns
  * GFT_OK, or GFT_E_INVALID when cap is too small (call again with *needed bytes).

@@ -16,6 +16,10 @@ Sources (relative to /root/reference):
     finder/finder_test.go:463-578      -> solve_expressions.json
     finder/finder_test.go:178-405      -> process_text.json  (mocked-engine orchestration + error propagation)
     group/finder/finder_test.go:332-447-> engine_truth.json  (the only cases that run a real AC engine)
+    group/dsl/parser_test.go:11-398    -> group_parser.json  (18 Parse cases of the tag-rule DSL)
+    group/dsl/scanner_test.go:17-131   -> group_scanner.json (6 token-stream cases)
+    group/dsl/expression_test.go:21-265-> group_solver.json  (28 Solve cases)
+    group/finder/finder_test.go, internal_test.go, examples/group/finder/main.go -> group_finder.json
     examples/finder/main.go, README.md:159-170 -> examples.json (inputs from the reference; expected
                                           results HAND-DERIVED from finder.go/expression.go, labelled so)
 """
@@ -378,7 +382,143 @@ def main():
                          "map": {"foo": [0, 2, 5], "bar": [3], "dolor": [1, 7]}, "expected": True}})
 
 
+def gexpr_obj(e):
+    """group/dsl Expression literal -> canonical fixture object."""
+    if e is None:
+        return None
+    if isinstance(e, list):
+        return {"Type": "UNSET"}
+    d = {"Type": str(e.get("Type", "UNSET_EXPR")).split(".")[-1].replace("_EXPR", "")}
+    if d["Type"] == "UNIT":
+        t = e.get("Tag") or {}
+        t = t if isinstance(t, dict) else {}
+        d["Tag"] = {"Name": t.get("Name", ""), "FieldPath": t.get("FieldPath", "")}
+    for side in ("LExpr", "RExpr"):
+        if e.get(side) is not None:
+            d[side] = gexpr_obj(e[side])
+    return d
+
+
+def errtext(e):
+    return e["error"] if isinstance(e, dict) else None
+
+
+def group_main():
+    # ---- tag-rule DSL: parser ---------------------------------------------------------------------------
+    src = read("group/dsl/parser_test.go")
+    cases = []
+    for c in table_after(src, "tests := []struct"):
+        cases.append({"expStr": c["expStr"], "message": c["message"], "error": errtext(c.get("expectedErr")),
+                      "exp": gexpr_obj(c["expectedExp"]) if errtext(c.get("expectedErr")) is None else None,
+                      "tags": keyset(c.get("expectedTags")), "fields": keyset(c.get("expectedPaths"))})
+    dump("group_parser.json", {"source": "group/dsl/parser_test.go:11-398", "cases": cases})
+
+    # ---- tag-rule DSL: scanner --------------------------------------------------------------------------
+    src = read("group/dsl/scanner_test.go")
+    cases = []
+    for c in table_after(src, "tests := []struct"):
+        exp = [{"Tok": str(e["Tok"]), "Lit": e["Lit"], "Err": errtext(e.get("Err"))} for e in c["expected"]]
+        cases.append({"expStr": c["expStr"], "message": c["message"], "expected": exp})
+    dump("group_scanner.json", {"source": "group/dsl/scanner_test.go:17-131", "cases": cases})
+
+    # ---- tag-rule DSL: Solve ----------------------------------------------------------------------------
+    src = read("group/dsl/expression_test.go")
+
+    def tagmap(m):
+        out = {}
+        for tag, fields in (m if isinstance(m, dict) else {}).items():
+            out[tag] = None if not isinstance(fields, dict) else {f: sorted(v) if isinstance(v, dict) else [] for f, v in fields.items()}
+        return out
+    cases = [{"expStr": c["expStr"], "message": c["message"], "expected": c["expectedResp"],
+              "map": tagmap(c["matchedExpByFieldByTag"])} for c in table_after(src, "var solverTestCases")]
+    dump("group_solver.json", {"source": "group/dsl/expression_test.go:21-265", "cases": cases})
+
+    # ---- GroupFinder ------------------------------------------------------------------------------------------------
+    src = read("group/finder/finder_test.go")
+
+    def finder_state(g):
+        rules = {}
+        wr = g.get("expressionWrapperByExprName")
+        for name, ws in (wr if isinstance(wr, dict) else {}).items():
+            rules[name] = [{"ExpressionString": w["ExpressionString"], "Expression": gexpr_obj(w["Expression"])} for w in ws]
+        return {"rules": rules, "fields": keyset(g.get("fields")), "tags": keyset(g.get("tags"))}
+    add_rules = []
+    for fn_name, nxt in (("func TestNewFinderWithRules", "func TestAddRule("), ("func TestAddRule(", "func TestAddRules"),
+                         ("func TestAddRules", "func TestTagJson")):
+        fn = src[src.index(fn_name):src.index(nxt)]
+        for c in table_after(fn, "tests := []struct"):
+            rules = c["rulesByName"] if "rulesByName" in c else {c["ruleName"]: c["expressions"]}
+            add_rules.append({"test": fn_name.split()[1].rstrip("("), "message": c["message"], "rules": rules,
+                              "error": errtext(c.get("expectedErr")), "state": finder_state(c["groupFinder"])})
+    fn = src[src.index("func TestEvaluateRules"):]
+    evaluate = [{"message": c["message"], "rules": c["rulesByName"], "map": tagmap(c["matchedExpByFieldByTag"]),
+                 "expected": c["expectedExpressionsByRule"]} for c in table_after(fn, "tests := []struct")]
+    src_i = read("group/finder/internal_test.go")
+    valid = [{"message": c["message"], "fieldPath": c["args"]["fieldPath"], "includePaths": list(c["args"]["includePaths"]),
+              "excludePaths": list(c["args"]["excludePaths"]), "expected": c["expected"]}
+             for c in table_after(src_i, "tests := []struct")]
+    # TestTagObject / TestTagText / TestTagJson (finder_test.go:269-447): the inputs are Go values (a string, a
+    # []string, an anonymous struct with unexported fields); transcribed by hand as data.  Unexported (lower-case)
+    # struct fields are kept in the data so that the walk's "exported fields only" rule is exercised.
+    tag_object = {
+        "finder_expressions": [{"expression": '"string"', "tag": "strTag"}], "case_sensitive": False,
+        "rules": {"test": ['"strTag"']},
+        "cases": [
+            {"message": "tag object raw string", "object": "some random string",
+             "expected": {"strTag": {"": ['"string"']}}},
+            {"message": "tag object array of string", "object": ["some random string", "some random string"],
+             "expected": {"strTag": {"index(0)": ['"string"'], "index(1)": ['"string"']}}},
+            {"message": "tag object struct with internal fields", "struct": True,
+             "object": {"StrField": "some random string",
+                        "StrArray": ["some random string 1", "some random string 2"],
+                        "AnotherObj": {"Field1": 42, "Field2": 42.42, "internalField": 0},
+                        "internalStr": "some internal value", "internalArr": ["some internal value 0"],
+                        "internalObj": {"Field3": 0.0}},
+             "expected": {"strTag": {"StrField": ['"string"'], "StrArray.index(0)": ['"string"'],
+                                     "StrArray.index(1)": ['"string"']}}},
+        ],
+        "tag_text": {"text": "some random string", "expected": {"strTag": ['"string"']}},
+        "tag_json_no_expressions": {"raw": '{"strField": "some string", "intField": 42, "floatField": 42.42}', "expected": {}},
+    }
+    # examples/group/finder/main.go: inputs from the reference; expected values HAND-DERIVED from finder.go /
+    # internal.go / expression.go (the program prints them, the repository holds no expected output)
+    ex = read("examples/group/finder/main.go")
+    gofindthem_rules = var_after(ex, "gofindthemRules :=")
+    rules = var_after(ex, "rules :=")
+    raw_json = var_after(ex, "rawJson :=")
+    s5, s2, s3, s1 = '"string5"', '"string2"', '"string3"', '"string1"'
+    example = {
+        "source": "examples/group/finder/main.go:11-34,127-143 (inputs); expected values hand-derived",
+        "finder_rules": gofindthem_rules, "case_sensitive": False, "rules": rules, "rawJson": raw_json,
+        "object": {"Field1": "some pretty text with string1", "Field2": 42,
+                   "Field3": {"SomeField1": "some pretty text with string5",
+                              "SomeField2": ["some pretty text with string5", "some pretty text with string2",
+                                             "some pretty text with string3"]}},
+        "array": [{"FieldN": "some pretty text with string5", "FieldX": ""},
+                  {"FieldN": "some pretty text with string2", "FieldX": ""},
+                  {"FieldN": "some pretty text with string3", "FieldX": ""}],
+        # include paths = GetFieldNames() = ["Field3", "Field3.SomeField1"]: Field1 is not tagged
+        "expected_tags_with_field_names": {
+            "tag3": {"Field3.SomeField1": [s5], "Field3.SomeField2.index(0)": [s5]},
+            "tag1": {"Field3.SomeField2.index(1)": [s2]},
+            "tag2": {"Field3.SomeField2.index(2)": [s3]}},
+        "expected_rules_with_field_names": {"rule1": ['"tag1" or "tag2"'], "rule2": ['"tag3:Field3.SomeField1" or "tag4"'],
+                                            "rule3": ['"tag3:Field3" or "tag4"']},
+        "expected_tags_all_fields": {
+            "tag1": {"Field1": [s1], "Field3.SomeField2.index(1)": [s2]},
+            "tag3": {"Field3.SomeField1": [s5], "Field3.SomeField2.index(0)": [s5]},
+            "tag2": {"Field3.SomeField2.index(2)": [s3]}},
+        "expected_array_tags": {"tag3": {"index(0).FieldN": [s5]}, "tag1": {"index(1).FieldN": [s2]},
+                                "tag2": {"index(2).FieldN": [s3]}},
+        "expected_array_rules": {"rule1": ['"tag1" or "tag2"']},
+    }
+    dump("group_finder.json", {"source": "group/finder/finder_test.go:45-502, group/finder/internal_test.go:9-99",
+                               "add_rules": add_rules, "evaluate": evaluate, "valid_path": valid,
+                               "tag_object": tag_object, "example": example, "cases": add_rules})
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference not mounted at %s; the committed JSON is the artefact" % REF)
     main()
+    group_main()

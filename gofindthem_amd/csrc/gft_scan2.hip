@@ -81,6 +81,7 @@ struct Ctx {
 // Positions before the document start need no special casing here: the bytes there (the previous document's, or
 // zeros in front of the blob) can only change keys of windows that reach across the start, and every term such a
 // window may name is longer than p + 1 and is dropped by the length check at emission.
+constexpr int kStageAWays = 2;      // stage A: candidates a lane works on at once
 struct Cand { uint32_t p, x, x3, tw, sid; bool go_long; };
 struct Text8 { uint32_t tw, w; };
 __device__ __forceinline__ Text8 cand_load_slow(const Ctx& c, uint32_t p) {   // within 7 bytes of the blob start
@@ -565,27 +566,38 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     // stage A: every flagged position -> LDS-only decisions; short terms are emitted here, positions that may
                     // end a term of length >= 4 are compacted in place to the front of the list (write index <= read index)
-                    // (two candidates per lane and trip: their loads and table lookups are in flight together; lanes
-                    // past the end of the list work on a copy of entry 0 and stay silent)
+                    // (kStageAWays candidates per lane and trip: their loads and table lookups are in flight together;
+                    // lanes past the end of the list work on a copy of entry 0 and stay silent)
                     uint32_t ns = 0;
-                    for (uint32_t i0 = 0; i0 < ptotal; i0 += 128) {
-                        const uint32_t ia = i0 + lane, ib = ia + 64;
-                        const bool on_a = ia < ptotal, on_b = ib < ptotal;
-                        const uint32_t rel_a = cand[on_a ? ia : 0], rel_b = cand[on_b ? ib : 0];
-                        const uint32_t pa = un.lo + rel_a, pb = un.lo + rel_b;
-                        const Text8 ta = cand_load(c, pa), tb = cand_load(c, pb);
-                        Cand ka, kb;
-                        cand_keys(c, pa, ta, ka); cand_keys(c, pb, tb, kb);
-                        cand_decide(c, ka); cand_decide(c, kb);
-                        finish_short(c, pa, on_a ? ka.sid : 0, ka.x3, fifo, nf);
-                        finish_short(c, pb, on_b ? kb.sid : 0, kb.x3, fifo, nf);
-                        // all reads of this trip are done (ia, ib >= every write index below)
-                        const uint64_t sa = __ballot(on_a && ka.go_long), sb = __ballot(on_b && kb.go_long);
+                    for (uint32_t i0 = 0; i0 < ptotal; i0 += 64 * kStageAWays) {
+                        bool on[kStageAWays];
+                        uint32_t rel[kStageAWays];
+                        Text8 tx[kStageAWays];
+                        Cand k[kStageAWays];
+#pragma unroll
+                        for (int q = 0; q < kStageAWays; q++) {
+                            const uint32_t i = i0 + 64 * q + lane;
+                            on[q] = i < ptotal;
+                            rel[q] = cand[on[q] ? i : 0];
+                        }
+#pragma unroll
+                        for (int q = 0; q < kStageAWays; q++) tx[q] = cand_load(c, un.lo + rel[q]);
+#pragma unroll
+                        for (int q = 0; q < kStageAWays; q++) cand_keys(c, un.lo + rel[q], tx[q], k[q]);
+#pragma unroll
+                        for (int q = 0; q < kStageAWays; q++) cand_decide(c, k[q]);
+#pragma unroll
+                        for (int q = 0; q < kStageAWays; q++)
+                            if (i0 + 64 * q < ptotal) finish_short(c, k[q].p, on[q] ? k[q].sid : 0, k[q].x3, fifo, nf);
+                        // all reads of this trip are done (every read index >= every write index below)
                         const uint64_t below = (1ull << lane) - 1;
-                        if (on_a && ka.go_long) cand[ns + __popcll(sa & below)] = (uint16_t)rel_a;
-                        ns += (uint32_t)__popcll(sa);
-                        if (on_b && kb.go_long) cand[ns + __popcll(sb & below)] = (uint16_t)rel_b;
-                        ns += (uint32_t)__popcll(sb);
+#pragma unroll
+                        for (int q = 0; q < kStageAWays; q++) {
+                            const bool keep = on[q] && k[q].go_long;
+                            const uint64_t sb = __ballot(keep);
+                            if (keep) cand[ns + __popcll(sb & below)] = (uint16_t)rel[q];
+                            ns += (uint32_t)__popcll(sb);
+                        }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();

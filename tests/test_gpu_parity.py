@@ -156,3 +156,52 @@ def test_solver_fixtures_on_gpu(eng):
     assert np.array_equal(got, want)
     for d, c in enumerate(cases):
         assert bool(got[d, 0] >> d & 1) is c[2], c
+
+
+def test_many_short_terms_overflow_records(eng):
+    """more than 254 distinct short-term records: LDS ids run out and the overflow table in global memory takes over
+    (scan2_tables.cpp short3_big); dense matches also shrink the work units (adaptive unit size)"""
+    import itertools
+    alpha = "abcdefghijklmnopqrst"
+    terms = ["".join(p) for p in itertools.product(alpha, repeat=2)]                      # 400 two-letter terms
+    terms += ["".join(p) for p in itertools.product(alpha[:9], repeat=3)]                   # 729 three-letter terms
+    terms += ["abcde", "tsrqponm", "aaaa", "bcbcbcbcbcbcbcbcbcbcbcbcbcbcbcbc"]
+    o = both(eng, sorted(set(t.encode() for t in terms)))
+    rng = np.random.default_rng(5)
+    texts = [bytes(ord(alpha[i]) for i in rng.integers(0, len(alpha), n)) for n in (0, 1, 2, 3, 5, 64, 700, 5000, 9000, 30000)]
+    texts.append(b"bc" * 40 + b"abcde" + b"x" + b"tsrqponm")
+    blob, off = docs(texts)
+    assert_csr_equal(eng.scan(blob, off), o.scan(blob, off))
+    # the process path (balanced, unordered kernel) twice: the second call runs with the unit size the first one learned
+    exprs = ['"ab" and "abc"', 'inord("aaa" and "bcb")', 'not "tsrqponm"', '"abcde" or "aaaa"', 'inord("qr" and "st" and "ab")']
+    o.set_expressions(exprs, True)
+    progs, extra = _programs(o, eng, exprs, True)
+    assert not extra
+    eng.set_programs(progs)
+    want = o.process(blob, off)
+    assert np.array_equal(eng.process(blob, off), want)
+    assert np.array_equal(eng.process(blob, off), want)
+
+
+def test_deep_buckets_and_long_terms(eng):
+    """hundreds of terms ending with the same four bytes (one bucket, far more entries than the deferred list holds) and
+    terms longer than a slot's 24 inline bytes (term_blob compare)"""
+    rng = np.random.default_rng(11)
+    alpha = b"abcdefgh"
+    terms = set()
+    for _ in range(700):
+        L = int(rng.integers(1, 40))
+        terms.add(bytes(alpha[i] for i in rng.integers(0, 8, L)) + b"wxyz")
+    terms |= {b"wxyz", b"awxyz", b"h" * 60 + b"wxyz", b"abcdefgh" * 6}
+    tl = sorted(terms)
+    o = both(eng, tl)
+    planted = b"".join(tl[i] + b"-" for i in rng.integers(0, len(tl), 600))
+    noise = bytes(alpha[i] for i in rng.integers(0, 8, 20000)).replace(b"aaa", b"wxyz")
+    blob, off = docs([planted, noise, b"wxyz", b"xyz", b"h" * 59 + b"wxyz", b"h" * 61 + b"wxyz" + b"abcdefgh" * 7])
+    assert_csr_equal(eng.scan(blob, off), o.scan(blob, off))
+    exprs = ['"wxyz"', '"awxyz" and not "%s"' % ("h" * 60 + "wxyz"), 'inord("%s" and "wxyz")' % ("abcdefgh" * 6)]
+    exprs += ['"%s"' % t.decode() for t in tl[:40]]
+    o.set_expressions(exprs, True)
+    progs, extra = _programs(o, eng, exprs, True)
+    eng.set_programs(progs)
+    assert np.array_equal(eng.process(blob, off), o.process(blob, off))

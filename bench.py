@@ -100,6 +100,17 @@ def main():
     rc = L.gft_scan_device(eh, text.data_ptr(), doc_off.data_ptr(), args.docs, _lib.GFT_FOLD_ASCII, C.byref(m))
     assert rc == 0, L.gft_last_error(eh)
     n_matches = int(m.n_matches)
+    # hits per document (the CSR offsets of that scan live in engine-owned device memory)
+    hits_max = None
+    try:
+        moff = torch.empty(args.docs + 1, dtype=torch.int64, device=dev)
+        hip = C.CDLL("libamdhip64.so")
+        if hip.hipMemcpy(C.c_void_p(moff.data_ptr()), C.c_void_p(m.match_off), C.c_size_t(8 * (args.docs + 1)), C.c_int(3)) == 0:
+            hits_max = int((moff[1:] - moff[:-1]).max().item())
+    except OSError:
+        pass
+    from gofindthem_amd.workload import read_ceiling_gbps
+    ceiling_gbps = read_ceiling_gbps(text)
     setup_s = time.time() - t_setup
 
     # ---- timed region -------------------------------------------------------------------------------------
@@ -124,21 +135,17 @@ def main():
     solve_ms, solve_n = prof("solve")
     aux_ms, aux_n = prof("aux")
 
-    # ---- parity in the same run: sampled documents against the CPU oracle, bit-exact ------------------------------
-    from oracle.pyoracle import Oracle
+    # ---- same-run consistency that needs no oracle: the corpus generator's host and device forms agree on a sample,
+    # and (N > 1) rank 0's slice of the gathered result is what it computed itself --------------------------------
     S = min(args.parity_docs, args.docs)
     h_text, h_off = wl.docs_host(first, S)
     d_off = doc_off[:S + 1].cpu().numpy().astype(np.uint64)
     gen_ok = bool(np.array_equal(d_off, h_off)) and bool(
         np.array_equal(text[:int(h_off[-1])].cpu().numpy(), h_text))
-    orc = Oracle(terms)
-    orc.set_expressions(exprs, case_sensitive=False)
-    want = orc.process(h_text, h_off, fold=True, n_threads=min(8, os.cpu_count() or 1))
-    got = bitmap[:S].cpu().numpy().view(np.uint32)
-    parity_ok = gen_ok and bool(np.array_equal(got, want))
-    parity_ok = all_ranks_ok(parity_ok, dev)
-    if world > 1 and rank == 0:   # rank 0's slice of the gathered result is what it computed itself
+    parity_ok = all_ranks_ok(gen_ok, dev)
+    if world > 1 and rank == 0:
         parity_ok = parity_ok and bool(torch.equal(gather.parts[0], bitmap))
+    parity = "not checked in this run (the CPU oracle runs in the cpu_baseline leg, N = 1 only); tests/ -m gpu hold the parity proofs"
 
     # ---- CPU baseline (rank 0, N == 1): the oracle = our restatement of the reference path, on this host ---------------
     cpu = None
@@ -147,14 +154,23 @@ def main():
         cores = min(cores, args.cpu_threads)      # a 1-GPU box's CPU share is 16 cores
         n_cpu = args.cpu_docs if args.cpu_docs > 0 else min(args.docs, 24000 * cores)   # ~10-15 s of CPU work
         n_cpu = min(n_cpu, args.docs)
+        from oracle.pyoracle import Oracle     # the checker: only this leg touches oracle/
+        orc = Oracle(terms)
+        orc.set_expressions(exprs, case_sensitive=False)
         c_off = doc_off[:n_cpu + 1].cpu().numpy().astype(np.uint64)
         c_text = text[:int(c_off[-1])].cpu().numpy()
+        n1 = min(n_cpu, 6000)                   # the reference's own execution model: one goroutine (benchmark_test.go:422-425)
+        t1 = time.perf_counter()
+        orc.process(c_text[:int(c_off[n1])], c_off[:n1 + 1], fold=True, n_threads=1)
+        t1 = time.perf_counter() - t1
         tc = time.perf_counter()
         ref = orc.process(c_text, c_off, fold=True, n_threads=cores)
         tc = time.perf_counter() - tc
         same = bool(np.array_equal(ref, bitmap[:n_cpu].cpu().numpy().view(np.uint32)))
         parity_ok = parity_ok and same
+        parity = ("bit-exact vs CPU oracle on the first %d documents" % n_cpu) if same else "MISMATCH vs CPU oracle"
         cpu = {"value": n_cpu / tc, "unit": "docs/s", "cores": cores, "kind": "port",
+               "single_thread_docs_per_s": n1 / t1,
                "input_GBps": float(c_off[-1]) / tc / 1e9,
                "sample": "first %d documents of the same corpus (%.1f MB), oracle/ac_oracle.cpp ProcessText "
                          "restatement, %d std::thread workers, %.1f s; bitmap equal to the GPU's: %s"
@@ -192,14 +208,16 @@ def main():
                                    % (args.terms, args.exprs, "AND/OR/NOT" if args.inord == 0 else
                                       "AND/OR/NOT + %.0f%% INORD" % (args.inord * 100), args.docs),
                        "docs_per_gpu": args.docs, "text_bytes_per_gpu": text_bytes, "matches_per_gpu": n_matches,
-                       "matches_per_doc": n_matches / args.docs, "parallelism": "docs sharded x%d" % world},
+                       "matches_per_doc": n_matches / args.docs, "matches_per_doc_max": hits_max,
+                       "parallelism": "docs sharded x%d" % world},
             "roofline": {"bound": "hbm", "kernel": "k_scan2 (suffix-window scan)", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,
+                         "measured_read_ceiling": ceiling_gbps, "frac_of_measured_ceiling": achieved / ceiling_gbps,
                          "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": scan_avg_ms, "launches": scan_n},
             "kernels_ms_per_step": {"scan": scan_ms / args.steps, "solve": solve_ms / args.steps,
                                     "aux(units+prefix sums+gather)": aux_ms / args.steps},
             "cpu_baseline": cpu,
-            "parity": "bit-exact vs CPU oracle on sampled documents" if parity_ok else "PARITY FAILED",
+            "parity": parity if parity_ok else "PARITY FAILED",
             "setup_s": setup_s,
         }
         print(json.dumps(out))

@@ -45,6 +45,8 @@ def _lib():
         L.gfw_doc_fill_host.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, vp, vp, C.c_uint32, vp, C.c_uint32, vp, vp]
         L.gfw_doc_lengths_dev.restype = C.c_int
         L.gfw_doc_lengths_dev.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, vp, C.c_uint32, vp, C.c_uint32, vp, vp]
+        L.gfw_read_sum_dev.restype = C.c_int
+        L.gfw_read_sum_dev.argtypes = [vp, C.c_uint64, vp, vp]
         L.gfw_doc_fill_dev.restype = C.c_int
         L.gfw_doc_fill_dev.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, vp, vp, C.c_uint32, vp, C.c_uint32, vp, vp, vp]
         _LIB = L
@@ -126,6 +128,24 @@ class Workload:
         assert rc == 0, rc
         torch.cuda.synchronize()
         return text[:total], off
+
+
+def read_ceiling_gbps(buf, reps=5):
+    """achievable HBM read bandwidth on this device: a coalesced sum over `buf` (a torch uint8 CUDA tensor), GB/s"""
+    import torch
+    L = _lib()
+    scratch = torch.zeros(1, dtype=torch.int64, device=buf.device)
+    st = torch.cuda.current_stream().cuda_stream
+    nbytes = int(buf.numel()) & ~15
+    L.gfw_read_sum_dev(buf.data_ptr(), nbytes, scratch.data_ptr(), st)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(reps):
+        rc = L.gfw_read_sum_dev(buf.data_ptr(), nbytes, scratch.data_ptr(), st)
+        assert rc == 0
+    ev1.record()
+    torch.cuda.synchronize()
+    return nbytes * reps / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
 
 
 def make_expressions(terms, n_exprs, inord_fraction=0.0, seed=BASE_SEED + 3, regexes=(), cover=False):

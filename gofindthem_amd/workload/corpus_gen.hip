@@ -56,9 +56,31 @@ __global__ void __launch_bounds__(256) k_doc_fill(uint64_t base_seed, uint64_t f
     }
 }
 
+// achievable-read ceiling: every lane sums 16-byte loads of a grid-strided slice of the buffer ("a
+// trivial coalesced sum-reduction kernel over the same blob")
+__global__ void __launch_bounds__(256) k_read_sum(const uint4* __restrict__ p, uint64_t n16, uint64_t* __restrict__ out) {
+    uint64_t acc = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const uint4 a = p[i], b = p[i + stride], c = p[i + 2 * stride], d = p[i + 3 * stride];
+        acc += (uint64_t)a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w + c.x + c.y + c.z + c.w + d.x + d.y + d.z + d.w;
+    }
+    for (; i < n16; i += stride) { const uint4 a = p[i]; acc += (uint64_t)a.x + a.y + a.z + a.w; }
+    for (int s = 32; s; s >>= 1) acc += __shfl_xor(acc, s, 64);
+    if ((threadIdx.x & 63) == 0 && acc == 0x0123456789ABCDEFull) out[0] = acc;    // keep the loads alive
+}
+
 }  // namespace
 
 extern "C" {
+
+int gfw_read_sum_dev(const void* d_buf, uint64_t bytes, uint64_t* d_scratch, void* stream) {
+    const uint64_t n16 = bytes / 16;
+    if (!n16) return 0;
+    k_read_sum<<<dim3(256 * 8), dim3(256), 0, (hipStream_t)stream>>>((const uint4*)d_buf, n16, d_scratch);
+    return (int)hipGetLastError();
+}
 
 int gfw_doc_lengths_dev(uint64_t base_seed, uint64_t first, uint64_t n, const uint64_t* d_vocab_off, uint32_t n_vocab,
                         const uint32_t* d_dict_idx, uint32_t n_terms, uint32_t* d_len_out, void* stream) {

@@ -73,6 +73,7 @@ struct gft_engine {
     DevBuf d_fprog, d_fprog_off, d_groups; // fused internal form + INORD group table
     DevBuf d_order, d_blk_deep;            // evaluation order of the programs (gft_set_programs)
     uint32_t fprog_words = 0;
+    uint32_t n_inord_groups = 0;           // fused INORD ops: 0 = the solver never reads positions
     DevBuf d_pscratch;                    // HBM presence matrices when n_slots * 8 B does not fit LDS
 
     // workspace
@@ -372,6 +373,8 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         const uint64_t n_waves = (uint64_t)e->n_cus * e->scan2_k2_waves;
         P.slab = (uint32_t)std::min<uint64_t>(kScan2Slab, std::max<uint64_t>(64, e->pool_cap / (2 * n_waves)));
         P.ordered = need_csr ? 1 : 0;   // the solver reads presence / successor positions: any order will do
+        // presence-only mode: positions are only read by INORD groups (and by CSR callers)
+        P.want_pos = (need_csr || e->n_inord_groups > 0) ? 1 : 0;
         const char* dbg = getenv("GFT_SCAN_DEBUG");
         P.dbg = dbg ? (uint32_t)atoi(dbg) : 0;
         P.dbg_counters = nullptr;
@@ -776,6 +779,8 @@ int gft_set_programs(gft_engine* e, const uint32_t* prog_words, const uint64_t* 
     HIP_TRY(hipStreamSynchronize(e->stream), "program upload");
     e->n_exprs = n_exprs; e->n_extra = n_extra; e->have_programs = true;
     e->fprog_words = (uint32_t)fw.size();
+    e->n_inord_groups = 0;
+    for (uint32_t w : fw) e->n_inord_groups += (w >> 28) == kFopInord;
     return GFT_OK;
 }
 

@@ -202,6 +202,7 @@ struct Scan2Params {
     uint64_t* n_matches;         // exact number of matches (the cursor includes slab slack)
     uint32_t slab;               // pool entries a wave reserves per global atomic (<= kScan2Slab)
     uint32_t ordered;            // 1: matches of a unit in text order (CSR results); 0: any order (solver input)
+    uint32_t want_pos;           // 0: presence only -- no expression has an INORD group, pool_pos is not written
     uint32_t dbg;                // GFT_SCAN_DEBUG bits (timing studies only): 1 = skip verification, 2 = count flags
     uint64_t* dbg_counters;      // [4] when dbg & 2: flagged positions, table probes, entries compared, -
 };

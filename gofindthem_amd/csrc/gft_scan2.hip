@@ -233,7 +233,7 @@ __device__ __forceinline__ void cand_finish(const Ctx& c, const Cand& k, uint32_
             if (cnt < kScan2StageCap) stage[cnt * 64] = make_uint2(term, pos);
         } else {
             P.pool_term[out_base + cnt] = term;
-            P.pool_pos[out_base + cnt] = pos;
+            if (P.want_pos) P.pool_pos[out_base + cnt] = pos;
         }
         cnt++;
     };
@@ -645,7 +645,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
                         for (uint32_t i = lane; i < nh; i += 64) {
                             const uint2 r = fifo[i];
                             P.pool_term[base + i] = r.x;
-                            P.pool_pos[base + i] = r.y;
+                            if (P.want_pos) P.pool_pos[base + i] = r.y;
                         }
                     done = true;
                 }
@@ -681,7 +681,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
                     if (k < cnt) {
                         const uint2 r = stage[k * 64];
                         P.pool_term[mine + k] = r.x;
-                        P.pool_pos[mine + k] = r.y;
+                        if (P.want_pos) P.pool_pos[mine + k] = r.y;
                     }
             }
             // lanes whose matches did not fit the staging area run the verification again, writing directly

@@ -64,6 +64,7 @@ struct gft_engine {
     DevBuf d_s2_short3, d_s2_shorts_packed, d_s2_short3_big, d_s2_fpt;
     uint32_t scan2_short3_bytes = 0;
     uint32_t scan2_k2_waves = 0, scan2_cand_cap = 0;    // scan2_plan
+    bool csr_sorted_in_gather = false;                  // this call: balanced scan + sort in the gather
     uint32_t scan2_unit_max = kScan2UnitMax;            // bytes per work unit (adapts to the match density)
 
     // programs
@@ -372,7 +373,11 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         // slab slack is at most one slab per resident wave: keep it below half the pool
         const uint64_t n_waves = (uint64_t)e->n_cus * e->scan2_k2_waves;
         P.slab = (uint32_t)std::min<uint64_t>(kScan2Slab, std::max<uint64_t>(64, e->pool_cap / (2 * n_waves)));
-        P.ordered = need_csr ? 1 : 0;   // the solver reads presence / successor positions: any order will do
+        // the balanced path serves both callers: the solver reads presence / successor positions in any order, and
+        // CSR results are put into emission order by the gather (k_gather_sorted); GFT_SCAN_ORDERED=1 keeps the
+        // in-kernel ordered path for CSR results (the cross-check of the two)
+        e->csr_sorted_in_gather = need_csr && !getenv("GFT_SCAN_ORDERED");
+        P.ordered = (need_csr && !e->csr_sorted_in_gather) ? 1 : 0;
         // presence-only mode: positions are only read by INORD groups (and by CSR callers)
         P.want_pos = (need_csr || e->n_inord_groups > 0) ? 1 : 0;
         const char* dbg = getenv("GFT_SCAN_DEBUG");
@@ -400,7 +405,7 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
                     (unsigned long long)c4[2], (unsigned long long)total);
         }
         if (cursor <= e->pool_cap) {
-            if (!need_csr && text_hi > text_lo) {
+            if (P.ordered == 0 && text_hi > text_lo) {
                 // a unit of maximal size should fill ~75 % of the fifo
                 const double per_byte = (double)total / (double)(text_hi - text_lo);
                 const double want = per_byte > 0 ? 0.75 * kScan2FifoCap / per_byte : (double)kScan2UnitMax;
@@ -452,7 +457,9 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         HIP_TRY(launch_gather(e->d_unit_start.as<uint64_t>(), e->d_unit_count.as<uint32_t>(),
                               e->d_unit_out.as<uint64_t>(), n_units, e->d_pool_term.as<uint32_t>(),
                               e->d_pool_pos.as<uint32_t>(), e->d_term.as<uint32_t>(), e->d_pos.as<uint32_t>(),
-                              e->d_unit_base.as<uint64_t>(), n_docs, e->d_match_off.as<uint64_t>(), e->n_cus, st),
+                              e->d_unit_base.as<uint64_t>(), n_docs, e->d_match_off.as<uint64_t>(), e->n_cus, st,
+                              (e->use_scan2 && e->csr_sorted_in_gather) ? e->d_units.as<Unit>() : nullptr,
+                              e->d_term_len.as<uint32_t>(), (e->build_flags & GFT_POS_END) ? 1u : 0u),
                 "gather");
     }
     *n_matches = total;

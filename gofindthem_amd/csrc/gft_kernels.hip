@@ -238,6 +238,66 @@ __global__ void __launch_bounds__(256) k_gather(const uint64_t* __restrict__ uni
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// k_gather_sorted: the same for slabs written by the balanced (unordered) path of gft_scan2: a unit's matches are put
+// into the reference's emission order -- end offset ascending, longer term first -- on the way.  One wave per unit;
+// at most kScan2FifoCap matches (larger units were written by the ordered path and are copied as they are).  Rank sort:
+// keys (end - unit.lo) << 18 | (2^18 - 1 - len) sit in LDS, every lane counts the keys below each of its own.
+// ------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_gather_sorted(const Unit* __restrict__ units,
+                                                       const uint64_t* __restrict__ unit_start,
+                                                       const uint32_t* __restrict__ unit_count,
+                                                       const uint64_t* __restrict__ unit_out, uint64_t n_units,
+                                                       const uint32_t* __restrict__ pool_term,
+                                                       const uint32_t* __restrict__ pool_pos,
+                                                       const uint32_t* __restrict__ term_len, uint32_t pos_end,
+                                                       uint32_t* __restrict__ term_id, uint32_t* __restrict__ pos) {
+    __shared__ uint32_t keys_all[4][kScan2FifoCap];
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    uint32_t* keys = keys_all[wave];
+    constexpr uint32_t kPer = kScan2FifoCap / kLane;
+    for (uint64_t u = (uint64_t)blockIdx.x * wpb + wave; u < n_units; u += (uint64_t)gridDim.x * wpb) {
+        const uint64_t s = unit_start[u], d = unit_out[u];
+        const uint32_t n = unit_count[u];
+        if (n > kScan2FifoCap) {                      // already in order
+            for (uint32_t i = lane; i < n; i += kLane) { term_id[d + i] = pool_term[s + i]; pos[d + i] = pool_pos[s + i]; }
+            continue;
+        }
+        const uint32_t lo = units[u].lo;
+        uint32_t t[kPer], p[kPer], k[kPer];
+#pragma unroll
+        for (uint32_t q = 0; q < kPer; q++) {
+            const uint32_t i = lane + q * kLane;
+            k[q] = 0xFFFFFFFFu;
+            if (i < n) {
+                t[q] = pool_term[s + i];
+                p[q] = pool_pos[s + i];
+                const uint32_t L = term_len[t[q]];
+                const uint32_t end = pos_end ? p[q] : p[q] + L - 1;
+                k[q] = (end - lo) << 18 | (0x3FFFFu - L);
+                keys[i] = k[q];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint32_t rank[kPer];
+#pragma unroll
+        for (uint32_t q = 0; q < kPer; q++) rank[q] = 0;
+        const uint32_t rounds = (n + kLane - 1) / kLane;       // own items in use (wave-uniform)
+        for (uint32_t j = 0; j < n; j++) {
+            const uint32_t kj = keys[j];                        // broadcast read
+#pragma unroll
+            for (uint32_t q = 0; q < kPer; q++)
+                if (q < rounds) rank[q] += kj < k[q] ? 1u : 0u;
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < kPer; q++)
+            if (lane + q * kLane < n) { term_id[d + rank[q]] = t[q]; pos[d + rank[q]] = p[q]; }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 __global__ void __launch_bounds__(256) k_match_off(const uint64_t* __restrict__ unit_base,
                                                    const uint64_t* __restrict__ unit_out, uint64_t n_docs,
                                                    uint64_t* __restrict__ match_off) {
@@ -304,10 +364,15 @@ hipError_t launch_scan_units(const ScanParams& P, unsigned n_cus, hipStream_t st
 hipError_t launch_gather(const uint64_t* d_unit_start, const uint32_t* d_unit_count, const uint64_t* d_unit_out,
                          uint64_t n_units, const uint32_t* d_pool_term, const uint32_t* d_pool_pos, uint32_t* d_term,
                          uint32_t* d_pos, const uint64_t* d_unit_base, uint64_t n_docs, uint64_t* d_match_off,
-                         unsigned n_cus, hipStream_t st) {
+                         unsigned n_cus, hipStream_t st, const Unit* d_units_to_sort, const uint32_t* d_term_len,
+                         uint32_t pos_end) {
     k_match_off<<<dim3((unsigned)((n_docs + 1 + 255) / 256)), dim3(256), 0, st>>>(d_unit_base, d_unit_out, n_docs,
                                                                                   d_match_off);
-    if (n_units)
+    if (n_units && d_units_to_sort)
+        k_gather_sorted<<<dim3(grid_for(n_units, 4, n_cus * 16)), dim3(256), 0, st>>>(
+            d_units_to_sort, d_unit_start, d_unit_count, d_unit_out, n_units, d_pool_term, d_pool_pos, d_term_len, pos_end,
+            d_term, d_pos);
+    else if (n_units)
         k_gather<<<dim3(grid_for(n_units, 4, n_cus * 16)), dim3(256), 0, st>>>(
             d_unit_start, d_unit_count, d_unit_out, n_units, d_pool_term, d_pool_pos, d_term, d_pos);
     return hipGetLastError();

@@ -221,10 +221,12 @@ hipError_t launch_exclusive_scan(const uint32_t* d_in, uint64_t n, uint64_t* d_o
                                  hipStream_t st);
 size_t scan_units_lds_bytes(uint32_t n_lds_states, uint32_t n_classes);
 hipError_t launch_scan_units(const ScanParams& P, unsigned n_cus, hipStream_t st);
+// d_units_to_sort != nullptr: the slabs come from gft_scan2's balanced path and are sorted into emission order on the way
 hipError_t launch_gather(const uint64_t* d_unit_start, const uint32_t* d_unit_count, const uint64_t* d_unit_out,
                          uint64_t n_units, const uint32_t* d_pool_term, const uint32_t* d_pool_pos, uint32_t* d_term,
                          uint32_t* d_pos, const uint64_t* d_unit_base, uint64_t n_docs, uint64_t* d_match_off,
-                         unsigned n_cus, hipStream_t st);
+                         unsigned n_cus, hipStream_t st, const Unit* d_units_to_sort = nullptr,
+                         const uint32_t* d_term_len = nullptr, uint32_t pos_end = 0);
 size_t solve_lds_bytes(uint32_t n_slots, uint32_t tile_words, bool p_in_lds, uint32_t prog_words, uint32_t n_exprs,
                        bool prog_in_lds);
 hipError_t launch_solve(const SolveParams& S, bool p_in_lds, bool prog_in_lds, unsigned grid, hipStream_t st);

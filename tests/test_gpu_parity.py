@@ -9,11 +9,16 @@ from oracle.pyoracle import Oracle, POS_END, POS_START
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["window", "dfa"], autouse=True)
+@pytest.fixture(params=["window", "window-ordered", "dfa"], autouse=True)
 def scan_kernel(request, monkeypatch):
-    """every test runs against both scan kernels: the suffix-window kernel (default) and the general two-tier
-    DFA kernel (forced with GFT_SCAN_KERNEL=dfa, read by gft_build)"""
-    monkeypatch.setenv("GFT_SCAN_KERNEL", request.param)
+    """every test runs against the suffix-window kernel (default: balanced path, CSR results sorted by the gather),
+    the same kernel's in-kernel ordered path (GFT_SCAN_ORDERED=1) and the general two-tier DFA kernel
+    (GFT_SCAN_KERNEL=dfa, read by gft_build)"""
+    monkeypatch.setenv("GFT_SCAN_KERNEL", request.param.split("-")[0])
+    if request.param.endswith("-ordered"):
+        monkeypatch.setenv("GFT_SCAN_ORDERED", "1")
+    else:
+        monkeypatch.delenv("GFT_SCAN_ORDERED", raising=False)
     return request.param
 
 

@@ -49,6 +49,7 @@ for mode in args.modes.split(","):
     for _ in range(args.reps):
         m = run()
     ms, n = eng.profile_read("scan")
+    aux, na = eng.profile_read("aux")
     eng.profile(False)
-    print("GFT_SCAN_DEBUG=%s  scan kernel %.3f ms/launch  (%.1f GB/s of text)  matches=%d"
-          % (mode, ms / n, nbytes / (ms / n) / 1e6, m.n_matches), flush=True)
+    print("GFT_SCAN_DEBUG=%s  scan kernel %.3f ms/launch  (%.1f GB/s of text)  aux %.3f ms/call  matches=%d"
+          % (mode, ms / n, nbytes / (ms / n) / 1e6, aux / max(args.reps, 1), m.n_matches), flush=True)

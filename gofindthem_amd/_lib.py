@@ -39,6 +39,7 @@ SYMBOLS = {
     "gft_set_programs": (_i, [_vp, _vp, _vp, _u32, _u32]),
     "gft_n_exprs": (_u32, [_vp]),
     "gft_process": (_i, [_vp, _vp, _vp, _u64, _u32, C.POINTER(GftExtra), _vp]),
+    "gft_process_again": (_i, [_vp, _u64, C.POINTER(GftExtra), _vp]),
     "gft_process_device": (_i, [_vp, _vp, _vp, _u64, _u32, C.POINTER(GftExtra), _vp]),
     "gft_finder_create": (_i, [C.POINTER(_vp), _i, _i]),
     "gft_finder_destroy": (None, [_vp]),
@@ -55,6 +56,7 @@ SYMBOLS = {
     "gft_finder_force_build": (_i, [_vp]),
     "gft_finder_process_text": (_i, [_vp, C.c_char_p, _u64, _vp, _u32, C.POINTER(_u32)]),
     "gft_finder_process_texts": (_i, [_vp, _vp, _vp, _u64, _vp]),
+    "gft_finder_last_regex_docs": (_u64, [_vp]),
     "gft_finder_process_device": (_i, [_vp, _vp, _vp, _u64, _vp]),
     "gft_finder_debug_add_literal": (_i, [_vp, _i, C.c_char_p, _u32]),
     "gft_finder_debug_set_updated": (_i, [_vp, _i, _i]),
@@ -71,6 +73,7 @@ SYMBOLS = {
     "gft_group_dsl_parse": (_i, [C.c_char_p, _u64, _vp, _u64, C.POINTER(_u64)]),
     "gft_group_dsl_tokens": (_i, [C.c_char_p, _u64, _vp, _u64, C.POINTER(_u64)]),
     "gft_dsl_parse": (_i, [C.c_char_p, _u64, _i, _vp, _u64, C.POINTER(_u64)]),
+    "gft_regex_required_literals": (_i, [C.c_char_p, _u64, _vp, _u64, C.POINTER(_u64)]),
     "gft_dsl_tokens": (_i, [C.c_char_p, _u64, _vp, _u64, C.POINTER(_u64)]),
     "gft_to_lower": (_i, [C.c_char_p, _u64, _vp, _u64, C.POINTER(_u64)]),
     "gft_profile_enable": (_i, [_vp, _i]),

@@ -75,6 +75,127 @@ std::string rune_str(int32_t cp) { std::string s; encode_rune(cp, s); return s; 
 int32_t DecodeRune(const std::string& s, size_t i, size_t* adv) { return decode_rune(s, i, adv); }
 void EncodeRune(int32_t cp, std::string& out) { encode_rune(cp, out); }
 
+// ---- regex prefilter literals ---------------------------------------------------------------------------------------
+std::vector<std::string> RegexRequiredLiterals(const std::string& p, size_t min_len) {
+    std::vector<std::string> out;
+    std::string cur;
+    std::vector<size_t> starts;          // byte offsets in cur where each character (rune) of the run begins
+    auto flush = [&]() {
+        if (cur.size() >= min_len) out.push_back(cur);
+        cur.clear(); starts.clear();
+    };
+    auto drop_last_char = [&]() {       // the last character carries a quantifier that allows zero repeats
+        if (starts.empty()) return;
+        cur.resize(starts.back());
+        starts.pop_back();
+    };
+    auto push_bytes = [&](const char* b, size_t n) { starts.push_back(cur.size()); cur.append(b, n); };
+    const size_t n = p.size();
+    size_t i = 0;
+    bool last_is_char = false;           // the previous atom is a literal character sitting at the end of cur
+    while (i < n) {
+        const unsigned char c = (unsigned char)p[i];
+        bool atom_is_char = false;
+        if (c == '\\') {
+            if (i + 1 >= n) return {};
+            const unsigned char e = (unsigned char)p[i + 1];
+            if (e == 'd' || e == 'w' || e == 's' || e == 'D' || e == 'W' || e == 'S' || e == 'b' || e == 'B' || e == 'A' || e == 'z') {
+                flush();
+                i += 2;
+            } else if ((e >= '0' && e <= '9') || (e >= 'a' && e <= 'z') || (e >= 'A' && e <= 'Z') || e >= 0x80) {
+                return {};               // \x41, \pL, \Q..\E, \n, \t, octal ...: not modelled
+            } else {
+                push_bytes((const char*)&p[i + 1], 1);     // escaped punctuation is itself
+                atom_is_char = true;
+                i += 2;
+            }
+        } else if (c == '[') {
+            // character class: skip to its closing bracket
+            size_t j = i + 1;
+            if (j < n && p[j] == '^') j++;
+            if (j < n && p[j] == ']') j++;
+            for (;;) {
+                if (j >= n) return {};
+                if (p[j] == '\\') { j += 2; continue; }
+                if (p[j] == '[' && j + 1 < n && p[j + 1] == ':') {
+                    const size_t k = p.find(":]", j + 2);
+                    if (k == std::string::npos) return {};
+                    j = k + 2;
+                    continue;
+                }
+                if (p[j] == ']') break;
+                j++;
+            }
+            flush();
+            i = j + 1;
+        } else if (c == '(') {
+            if (i + 1 < n && p[i + 1] == '?') {
+                // (?:...) and (?P<name>...) are plain groups; anything else sets flags
+                if (!(i + 2 < n && (p[i + 2] == ':' || p[i + 2] == 'P'))) return {};
+            }
+            // a group is an unknown atom: skip to the matching parenthesis
+            int depth = 0;
+            size_t j = i;
+            for (;;) {
+                if (j >= n) return {};
+                if (p[j] == '\\') { j += 2; continue; }
+                if (p[j] == '[') {
+                    size_t k = j + 1;
+                    if (k < n && p[k] == '^') k++;
+                    if (k < n && p[k] == ']') k++;
+                    while (k < n && p[k] != ']') k += p[k] == '\\' ? 2 : 1;
+                    if (k >= n) return {};
+                    j = k + 1;
+                    continue;
+                }
+                if (p[j] == '(') { if (j + 1 < n && p[j + 1] == '?' && !(j + 2 < n && (p[j + 2] == ':' || p[j + 2] == 'P'))) return {}; depth++; }
+                if (p[j] == ')') { depth--; if (depth == 0) break; }
+                j++;
+            }
+            flush();
+            i = j + 1;
+        } else if (c == ')') {
+            return {};                   // unbalanced
+        } else if (c == '|') {
+            return {};                   // top-level alternation: no literal is required by every branch in general
+        } else if (c == '.' || c == '^' || c == '$') {
+            flush();
+            i++;
+        } else if (c == '*' || c == '?' || c == '+' || c == '{') {
+            size_t j = i + 1;
+            bool zero_ok = c == '*' || c == '?';
+            if (c == '{') {
+                // {m}, {m,}, {m,n}; anything else is a literal brace in RE2 -- not modelled
+                size_t k = i + 1;
+                uint64_t m = 0;
+                bool digits = false;
+                while (k < n && p[k] >= '0' && p[k] <= '9') { m = m * 10 + (uint64_t)(p[k] - '0'); k++; digits = true; if (m > 1000000) return {}; }
+                if (!digits) return {};
+                if (k < n && p[k] == ',') { k++; while (k < n && p[k] >= '0' && p[k] <= '9') k++; }
+                if (k >= n || p[k] != '}') return {};
+                zero_ok = m == 0;
+                j = k + 1;
+            }
+            if (j < n && p[j] == '?') j++;       // lazy form
+            if (last_is_char) {
+                if (zero_ok) drop_last_char();
+                flush();                          // the run ends at the repeated character either way
+            }
+            i = j;
+        } else {
+            // an ordinary character (all bytes of a UTF-8 sequence belong to one character)
+            size_t adv = 1;
+            if (c >= 0x80) { (void)decode_rune(p, i, &adv); }
+            push_bytes(&p[i], adv);
+            atom_is_char = true;
+            i += adv;
+        }
+        last_is_char = atom_is_char;
+    }
+    flush();
+    return out;
+}
+
 bool IsAscii(const std::string& s) {
     for (unsigned char c : s) if (c >= 0x80) return false;
     return true;
@@ -477,6 +598,12 @@ void json_list(const std::vector<std::string>& v, std::string& o) {
 }  // namespace
 
 extern "C" {
+
+int gft_regex_required_literals(const uint8_t* pattern, uint64_t len, char* out, uint64_t cap, uint64_t* needed) {
+    std::string doc;
+    json_list(gft::dsl::RegexRequiredLiterals(std::string((const char*)pattern, (size_t)len)), doc);
+    return emit_out(doc, out, cap, needed);
+}
 
 int gft_dsl_parse(const uint8_t* expr, uint64_t len, int case_sensitive, char* out, uint64_t cap, uint64_t* needed) {
     using namespace gft::dsl;

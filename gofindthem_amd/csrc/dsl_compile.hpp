@@ -54,6 +54,12 @@ ParseResult Parse(const std::string& src, bool case_sensitive);
 int32_t DecodeRune(const std::string& s, size_t i, size_t* adv);
 void EncodeRune(int32_t cp, std::string& out);
 
+// Literal runs that every match of an RE2-syntax pattern must contain, in pattern order (the
+// regex prefilter).  Conservative: anything not understood yields no literal from that part, or no literals at all
+// (alternation at the top level, flag groups, \x / \p / \Q escapes, malformed repeats).  Runs shorter than min_len bytes
+// are dropped.  An empty result means the pattern cannot be prefiltered.
+std::vector<std::string> RegexRequiredLiterals(const std::string& pattern, size_t min_len = 2);
+
 // strings.ToLower for the parser's literals and for document text (Unicode simple case mapping)
 std::string ToLower(const std::string& s);
 bool IsAscii(const std::string& s);

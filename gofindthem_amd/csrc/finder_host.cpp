@@ -111,11 +111,31 @@ Error Finder::AddExpressionWithTag(const std::string& expression, const std::str
         updatedSubMachine = false;
     }
     for (const auto& g : r.regexes) {
-        if (rgx_set_.insert(g).second) regexes_.push_back(g);
+        if (rgx_set_.insert(g).second) {
+            regexes_.push_back(g);
+            rgx_required_.push_back(dsl::RegexRequiredLiterals(g));
+            if (gpu_sub_) updatedSubMachine = false;        // the prefilter's literals join the device dictionary
+        }
         updatedRgxMachine = false;
     }
     programs_dirty_ = true;
     return "";
+}
+
+bool Finder::prefilter_active() const {
+    if (!gpu_sub_ || regexes_.empty()) return false;
+    if (const char* e = getenv("GFT_REGEX_PREFILTER")) if (e[0] == '0') return false;
+    for (const auto& r : rgx_required_) if (r.empty()) return false;   // one unfilterable regex makes every document a candidate
+    return rgx_required_.size() == regexes_.size();
+}
+
+std::vector<std::string> Finder::device_dictionary() const {
+    std::vector<std::string> dict = keywords_;
+    if (prefilter_active())
+        for (const auto& r : rgx_required_)
+            for (const auto& lit : r)
+                if (!kw_set_.count(lit) && std::find(dict.begin() + (long)keywords_.size(), dict.end(), lit) == dict.end()) dict.push_back(lit);
+    return dict;
 }
 
 Error Finder::fail_gft(int rc) {
@@ -129,7 +149,7 @@ Error Finder::sync_device() {
     gft_engine* h = gpu_->handle();
     // With a foreign substring engine (or no keywords at all) every literal is a caller-supplied slot and the
     // device dictionary is empty; otherwise the dictionary was built by GpuEngine::BuildEngine in collect().
-    const bool want_empty = !gpu_sub_ || keywords_.empty();
+    const bool want_empty = !gpu_sub_ || device_dictionary().empty();
     if (want_empty && (!empty_ready_ || gpu_->builds() != seen_builds_)) {
         const uint64_t off0[1] = {0};
         const uint8_t z = 0;
@@ -160,8 +180,16 @@ Error Finder::sync_device() {
         dsl::CompileProgram(*w.expression, slot_of, words);
         poff.push_back(words.size());
     }
+    if (prefilter_active())
+        for (const auto& req : rgx_required_) {               // hidden program j: every required literal is present
+            for (size_t i = 0; i < req.size(); i++) {
+                words.push_back(GFT_OP_UNIT << 28 | slot_of(req[i]));
+                if (i) words.push_back(GFT_OP_AND << 28);
+            }
+            poff.push_back(words.size());
+        }
     if (words.empty()) words.push_back(0);
-    int rc = gft_set_programs(h, words.data(), poff.data(), (uint32_t)expressions_.size(), n_extra);
+    int rc = gft_set_programs(h, words.data(), poff.data(), (uint32_t)(poff.size() - 1), n_extra);
     if (rc) return fail_gft(rc);
     slot_of_ = std::move(slots);   // literal -> slot, for addMatchesToSolverMap
     seen_builds_ = gpu_->builds();
@@ -181,15 +209,16 @@ void Finder::add_matches(const std::vector<Match>& ms, std::vector<Record>& out)
 
 // engine calls of ProcessText for one (already lower-cased) document, in the reference's order
 // (finder/finder.go:146-176).  Matches are appended to `pending` and mapped to slots after sync_device().
-Error Finder::collect(const std::string& text, bool run_sub, std::vector<Record>& out) {
+Error Finder::collect(const std::string& text, bool run_sub, std::vector<Record>& out, bool run_rgx) {
     std::vector<Match> all;
-    if (!keywords_.empty()) {
+    const std::vector<std::string> dict = gpu_sub_ ? device_dictionary() : keywords_;
+    if (!dict.empty()) {
         if (!updatedSubMachine) {
-            Error err = subEng_->BuildEngine(keywords_, caseSensitive_);
+            Error err = subEng_->BuildEngine(dict, caseSensitive_);
             if (!err.empty()) { last_code_ = GFT_E_ENGINE; return err; }
             updatedSubMachine = true;
         }
-        if (run_sub) {
+        if (run_sub && !keywords_.empty()) {
             Error err = subEng_->FindSubstrings(text, all);
             if (!err.empty()) { last_code_ = GFT_E_ENGINE; return err; }
         }
@@ -200,8 +229,10 @@ Error Finder::collect(const std::string& text, bool run_sub, std::vector<Record>
             if (!err.empty()) { last_code_ = GFT_E_ENGINE; return err; }
             updatedRgxMachine = true;
         }
-        Error err = rgxEng_->FindRegexes(text, all);
-        if (!err.empty()) { last_code_ = GFT_E_ENGINE; return err; }
+        if (run_rgx) {
+            Error err = rgxEng_->FindRegexes(text, all);
+            if (!err.empty()) { last_code_ = GFT_E_ENGINE; return err; }
+        }
     }
     // solveExpressions (finder.go:199-215) aborts on the first Solve error; such errors are properties of the
     // expression tree alone (see dsl::SolveError), so they are raised here, after the engine calls, like the
@@ -226,7 +257,7 @@ Error Finder::ProcessText(const std::string& text_in, std::vector<ExpressionResu
     std::vector<uint32_t> xs(recs.size() + 1), xp(recs.size() + 1);
     for (size_t i = 0; i < recs.size(); i++) { xs[i] = recs[i].slot; xp[i] = recs[i].pos; }
     gft_extra_matches x{xoff, xs.data(), xp.data()};
-    const size_t words = (expressions_.size() + 31) / 32;
+    const size_t words = (total_programs() + 31) / 32;        // hidden prefilter programs sit behind the user's
     std::vector<uint32_t> bm(std::max<size_t>(words, 1), 0);
     int rc = gft_process(gpu_->handle(), (const uint8_t*)text.data(), doff, 1, 0, &x, bm.data());
     if (rc) return fail_gft(rc);
@@ -250,6 +281,7 @@ Error Finder::ProcessTexts(const uint8_t* blob, const uint64_t* doc_off, uint64_
         if (ascii) flags = GFT_FOLD_ASCII;
     }
     const bool need_host_text = !caseSensitive_ && !ascii;
+    if (prefilter_active() && n_docs) return process_texts_prefiltered(blob, doc_off, n_docs, bitmap, flags, need_host_text);
     const bool per_doc_engines = !gpu_sub_ || !regexes_.empty();
     std::vector<Record> recs;
     std::vector<uint64_t> xoff(1, 0);
@@ -274,8 +306,67 @@ Error Finder::ProcessTexts(const uint8_t* blob, const uint64_t* doc_off, uint64_
     std::vector<uint32_t> xs(recs.size() + 1), xp(recs.size() + 1);
     for (size_t i = 0; i < recs.size(); i++) { xs[i] = recs[i].slot; xp[i] = recs[i].pos; }
     gft_extra_matches x{xoff.data(), xs.data(), xp.data()};
+    // (a disabled prefilter still leaves its programs out: total_programs() == expressions_.size() then)
     int rc = gft_process(gpu_->handle(), blob, doc_off, n_docs, flags, per_doc_engines && n_docs ? &x : nullptr, bitmap);
     if (rc) return fail_gft(rc);
+    return "";
+}
+
+// ProcessTexts with regex terms and the GPU substring engine: solve once without regex hits, run the host regex engine
+// only where a regex's required literals are all present, solve again with those hits (the scan is reused)
+Error Finder::process_texts_prefiltered(const uint8_t* blob, const uint64_t* doc_off, uint64_t n_docs, uint32_t* bitmap,
+                                        uint32_t flags, bool need_host_text) {
+    std::vector<uint8_t> lowered;
+    std::vector<uint64_t> loff;
+    if (need_host_text) {
+        loff.assign(1, 0);
+        for (uint64_t d = 0; d < n_docs; d++) {
+            const std::string t = dsl::ToLower(std::string((const char*)blob + doc_off[d], (size_t)(doc_off[d + 1] - doc_off[d])));
+            lowered.insert(lowered.end(), t.begin(), t.end());
+            loff.push_back(lowered.size());
+        }
+        lowered.push_back(0);
+        blob = lowered.data(); doc_off = loff.data(); flags = 0;
+    }
+    std::vector<Record> none;
+    Error err = collect(std::string(), false, none, false);       // engine builds + programs, no Find* call
+    if (!err.empty()) return err;
+    const size_t n_user = expressions_.size(), n_all = total_programs();
+    const size_t uw = (n_user + 31) / 32, aw = (n_all + 31) / 32;
+    std::vector<uint32_t> full((size_t)n_docs * aw + 1, 0);
+    int rc = gft_process(gpu_->handle(), blob, doc_off, n_docs, flags, nullptr, full.data());
+    if (rc) return fail_gft(rc);
+    // candidates: a hidden program fired
+    std::vector<Record> recs;
+    std::vector<uint64_t> xoff(1, 0);
+    last_regex_docs = 0;
+    for (uint64_t d = 0; d < n_docs; d++) {
+        const uint32_t* row = full.data() + d * aw;
+        bool cand = false;
+        for (size_t e = n_user; e < n_all && !cand; e++) cand = row[e >> 5] >> (e & 31) & 1;
+        if (cand) {
+            last_regex_docs++;
+            std::string t((const char*)blob + doc_off[d], (size_t)(doc_off[d + 1] - doc_off[d]));
+            if (!caseSensitive_ && !need_host_text) t = dsl::ToLower(t);     // ASCII batch: fold here for the host engine
+            std::vector<Match> ms;
+            Error e2 = rgxEng_->FindRegexes(t, ms);
+            if (!e2.empty()) { last_code_ = GFT_E_ENGINE; return e2; }
+            add_matches(ms, recs);
+        }
+        xoff.push_back(recs.size());
+    }
+    if (!recs.empty()) {
+        std::vector<uint32_t> xs(recs.size()), xp(recs.size());
+        for (size_t i = 0; i < recs.size(); i++) { xs[i] = recs[i].slot; xp[i] = recs[i].pos; }
+        gft_extra_matches x{xoff.data(), xs.data(), xp.data()};
+        rc = gft_process_again(gpu_->handle(), n_docs, &x, full.data());
+        if (rc) return fail_gft(rc);
+    }
+    // the user's expressions are the first n_user bits of every row
+    const uint32_t tail = (n_user & 31) ? (1u << (n_user & 31)) - 1 : 0xFFFFFFFFu;
+    for (uint64_t d = 0; d < n_docs; d++)
+        for (size_t w = 0; w < uw; w++)
+            bitmap[d * uw + w] = full[d * aw + w] & (w + 1 == uw ? tail : 0xFFFFFFFFu);
     return "";
 }
 
@@ -405,6 +496,8 @@ int gft_finder_expression(const gft_finder* f, uint32_t i, const uint8_t** str, 
     }
     return GFT_OK;
 }
+
+uint64_t gft_finder_last_regex_docs(const gft_finder* f) { return f && f->finder ? f->finder->last_regex_docs : 0; }
 
 int gft_finder_force_build(gft_finder* f) {
     if (!f) return GFT_E_INVALID;

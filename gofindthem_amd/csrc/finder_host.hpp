@@ -117,6 +117,7 @@ public:
     };
     const std::vector<ExprWrapper>& expressions() const { return expressions_; }
     int last_code() const { return last_code_; }
+    uint64_t last_regex_docs = 0;        // documents the host regex engine saw in the last prefiltered ProcessTexts
 
     // test hooks (finder_test.go pokes the struct fields directly)
     void debug_add_literal(int which, const std::string& lit);
@@ -127,7 +128,18 @@ private:
     Error sync_device();
     Error fail_gft(int rc);
     void add_matches(const std::vector<Match>& ms, std::vector<Record>& out);
-    Error collect(const std::string& lowered, bool run_sub, std::vector<Record>& out);
+    Error collect(const std::string& lowered, bool run_sub, std::vector<Record>& out, bool run_rgx = true);
+    Error process_texts_prefiltered(const uint8_t* blob, const uint64_t* doc_off, uint64_t n_docs, uint32_t* bitmap,
+                                    uint32_t flags, bool need_host_text);
+
+    // ---- regex prefilter.  With the GPU substring engine every regex that has required literals
+    // (dsl::RegexRequiredLiterals) gets a hidden AND-of-literals program behind the user's expressions; the literals
+    // join the device dictionary.  A batch is then solved once without regex hits, the host regex engine runs only on
+    // the documents whose hidden programs fired, and the solver runs again (scan reused) if any of them matched.
+    bool prefilter_active() const;
+    std::vector<std::string> device_dictionary() const;     // keywords (+ hidden literals when the prefilter is active)
+    size_t total_programs() const { return expressions_.size() + (prefilter_active() ? regexes_.size() : 0); }
+    std::vector<std::vector<std::string>> rgx_required_;    // per regex: literal runs every match contains
 
     std::vector<ExprWrapper> expressions_;
     std::vector<std::string> keywords_, regexes_;

@@ -64,6 +64,7 @@ struct gft_engine {
     DevBuf d_s2_short3, d_s2_shorts_packed, d_s2_short3_big, d_s2_fpt;
     uint32_t scan2_short3_bytes = 0;
     uint32_t scan2_k2_waves = 0, scan2_cand_cap = 0;    // scan2_plan
+    uint64_t scan_valid_docs = ~0ull;                   // documents of the last gft_process scan still in the pool (~0: none)
     bool csr_sorted_in_gather = false;                  // this call: balanced scan + sort in the gather
     uint32_t scan2_unit_max = kScan2UnitMax;            // bytes per work unit (adapts to the match density)
 
@@ -304,6 +305,7 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
                   bool need_csr, uint64_t* n_matches) {
     hipStream_t st = e->stream;
     *n_matches = 0;
+    e->scan_valid_docs = ~0ull;           // the pool is about to be overwritten
     HIP_TRY(e->d_match_off.ensure((n_docs + 1) * 8), "match_off alloc");
     if (n_docs == 0) {
         HIP_TRY(hipMemsetAsync(e->d_match_off.p, 0, 8, st), "memset");
@@ -639,6 +641,7 @@ int gft_build(gft_engine* e, const uint8_t* terms_blob, const uint64_t* term_off
     HIP_TRY(e->d_nmatches.ensure(8), "table upload");
     HIP_TRY(hipStreamSynchronize(e->stream), "table upload");
     e->built = true;
+    e->scan_valid_docs = ~0ull;
     e->scan2_unit_max = kScan2UnitMax;
     e->have_programs = false;   // slots refer to the dictionary: programs must be set again
     e->n_exprs = 0;
@@ -785,6 +788,7 @@ int gft_set_programs(gft_engine* e, const uint32_t* prog_words, const uint64_t* 
     if ((rc = upload(e, e->d_blk_deep, blk_deep, "program upload"))) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream), "program upload");
     e->n_exprs = n_exprs; e->n_extra = n_extra; e->have_programs = true;
+    e->scan_valid_docs = ~0ull;          // positions may not have been written for the old program set
     e->fprog_words = (uint32_t)fw.size();
     e->n_inord_groups = 0;
     for (uint32_t w : fw) e->n_inord_groups += (w >> 28) == kFopInord;
@@ -808,6 +812,49 @@ int gft_process_device(gft_engine* e, const uint8_t* d_text_blob, const uint64_t
     return GFT_OK;
 }
 
+namespace {
+// caller-supplied matches (host arrays) -> device copies; pdx stays null when there are none
+int upload_extra(gft_engine* e, const gft_extra_matches* extra, uint64_t n_docs, gft_extra_matches& dx, const gft_extra_matches*& pdx) {
+    pdx = nullptr;
+    if (!(extra && extra->off && n_docs)) return GFT_OK;
+    const uint64_t nx = extra->off[n_docs];
+    HIP_TRY(e->d_xoff.ensure((n_docs + 1) * 8), "extra alloc");
+    HIP_TRY(e->d_xslot.ensure(std::max<uint64_t>(nx, 1) * 4), "extra alloc");
+    HIP_TRY(e->d_xpos.ensure(std::max<uint64_t>(nx, 1) * 4), "extra alloc");
+    HIP_TRY(hipMemcpyAsync(e->d_xoff.p, extra->off, (n_docs + 1) * 8, hipMemcpyHostToDevice, e->stream), "extra upload");
+    if (nx) {
+        for (uint64_t i = 0; i < nx; i++)
+            if (extra->slot[i] >= e->tab.terms.size() + e->n_extra) return fail(e, GFT_E_INVALID, "extra slot out of range");
+        HIP_TRY(hipMemcpyAsync(e->d_xslot.p, extra->slot, nx * 4, hipMemcpyHostToDevice, e->stream), "extra upload");
+        HIP_TRY(hipMemcpyAsync(e->d_xpos.p, extra->pos, nx * 4, hipMemcpyHostToDevice, e->stream), "extra upload");
+    }
+    dx.off = e->d_xoff.as<uint64_t>(); dx.slot = e->d_xslot.as<uint32_t>(); dx.pos = e->d_xpos.as<uint32_t>();
+    pdx = &dx;
+    return GFT_OK;
+}
+}  // namespace
+
+int gft_process_again(gft_engine* e, uint64_t n_docs, const gft_extra_matches* extra, uint32_t* hit_bitmap) {
+    if (!e) return GFT_E_INVALID;
+    if (e->device < 0) return fail(e, GFT_E_HIP, "no HIP device available");
+    if (!e->built || !e->have_programs) return fail(e, GFT_E_NOT_BUILT, "engine not ready");
+    if (e->scan_valid_docs != n_docs || !n_docs) return fail(e, GFT_E_INVALID, "gft_process_again: no scan of these documents to reuse");
+    DeviceGuard g(e->device);
+    gft_extra_matches dx;
+    const gft_extra_matches* pdx = nullptr;
+    int rc = upload_extra(e, extra, n_docs, dx, pdx);
+    if (rc) return rc;
+    const uint64_t words = (e->n_exprs + 31) / 32;
+    rc = solve_pipeline(e, n_docs, pdx, e->d_bitmap.as<uint32_t>());
+    if (rc) return rc;
+    if (n_docs * words) {
+        if (!hit_bitmap) return fail(e, GFT_E_INVALID, "null bitmap");
+        HIP_TRY(hipMemcpyAsync(hit_bitmap, e->d_bitmap.p, n_docs * words * 4, hipMemcpyDeviceToHost, e->stream), "download");
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream), "solve pipeline");
+    return GFT_OK;
+}
+
 int gft_process(gft_engine* e, const uint8_t* text_blob, const uint64_t* doc_off, uint64_t n_docs, uint32_t flags,
                 const gft_extra_matches* extra, uint32_t* hit_bitmap) {
     if (!e || (n_docs && !doc_off)) return e ? fail(e, GFT_E_INVALID, "null argument") : GFT_E_INVALID;
@@ -819,26 +866,14 @@ int gft_process(gft_engine* e, const uint8_t* text_blob, const uint64_t* doc_off
     if (rc) return rc;
     gft_extra_matches dx;
     const gft_extra_matches* pdx = nullptr;
-    if (extra && extra->off && n_docs) {
-        const uint64_t nx = extra->off[n_docs];
-        HIP_TRY(e->d_xoff.ensure((n_docs + 1) * 8), "extra alloc");
-        HIP_TRY(e->d_xslot.ensure(std::max<uint64_t>(nx, 1) * 4), "extra alloc");
-        HIP_TRY(e->d_xpos.ensure(std::max<uint64_t>(nx, 1) * 4), "extra alloc");
-        HIP_TRY(hipMemcpyAsync(e->d_xoff.p, extra->off, (n_docs + 1) * 8, hipMemcpyHostToDevice, e->stream), "extra upload");
-        if (nx) {
-            for (uint64_t i = 0; i < nx; i++)
-                if (extra->slot[i] >= e->tab.terms.size() + e->n_extra) return fail(e, GFT_E_INVALID, "extra slot out of range");
-            HIP_TRY(hipMemcpyAsync(e->d_xslot.p, extra->slot, nx * 4, hipMemcpyHostToDevice, e->stream), "extra upload");
-            HIP_TRY(hipMemcpyAsync(e->d_xpos.p, extra->pos, nx * 4, hipMemcpyHostToDevice, e->stream), "extra upload");
-        }
-        dx.off = e->d_xoff.as<uint64_t>(); dx.slot = e->d_xslot.as<uint32_t>(); dx.pos = e->d_xpos.as<uint32_t>();
-        pdx = &dx;
-    }
+    rc = upload_extra(e, extra, n_docs, dx, pdx);
+    if (rc) return rc;
     const uint64_t words = (e->n_exprs + 31) / 32;
     HIP_TRY(e->d_bitmap.ensure(std::max<uint64_t>(n_docs * words, 1) * 4), "bitmap alloc");
     uint64_t nm = 0;
     rc = scan_pipeline(e, e->d_text.as<uint8_t>(), e->d_doc_off.as<uint64_t>(), n_docs, flags, false, &nm);
     if (rc) return rc;
+    e->scan_valid_docs = n_docs;          // gft_process_again may reuse this scan
     rc = solve_pipeline(e, n_docs, pdx, e->d_bitmap.as<uint32_t>());
     if (rc) return rc;
     if (n_docs * words) {

@@ -119,6 +119,10 @@ typedef struct gft_extra_matches {
 int gft_process(gft_engine* e, const uint8_t* text_blob, const uint64_t* doc_off, uint64_t n_docs, uint32_t flags,
                 const gft_extra_matches* extra, uint32_t* hit_bitmap);
 /* Device-resident variant (all pointers are device pointers, bitmap written in HBM). */
+/* Solve again over the documents of the LAST gft_process call on this engine (same n_docs), with other caller-supplied
+ * matches: the scan results are still in the engine, only the solver kernel runs.  The finder's regex prefilter uses it:
+ * first pass without regex hits, host regex engine on the candidate documents only, second pass with their hits. */
+int gft_process_again(gft_engine* e, uint64_t n_docs, const gft_extra_matches* extra, uint32_t* hit_bitmap);
 int gft_process_device(gft_engine* e, const uint8_t* d_text_blob, const uint64_t* d_doc_off, uint64_t n_docs,
                        uint32_t flags, const gft_extra_matches* d_extra, uint32_t* d_hit_bitmap);
 
@@ -164,6 +168,9 @@ int gft_finder_process_text(gft_finder* f, const uint8_t* text, uint64_t text_le
 /* Batch extension: one bitmap row per document (layout as gft_process). */
 int gft_finder_process_texts(gft_finder* f, const uint8_t* text_blob, const uint64_t* doc_off, uint64_t n_docs,
                              uint32_t* hit_bitmap);
+/* documents the host regex engine was called on by the last gft_finder_process_texts (the regex prefilter, SURVEY.md
+ * 8(f) #3, sends it only documents that contain every required literal of some regex; GFT_REGEX_PREFILTER=0 disables) */
+uint64_t gft_finder_last_regex_docs(const gft_finder* f);
 /* Same with the corpus resident in HBM (GPU substring engine, no regex terms). */
 int gft_finder_process_device(gft_finder* f, const uint8_t* d_text_blob, const uint64_t* d_doc_off, uint64_t n_docs,
                               uint32_t* d_hit_bitmap);
@@ -210,6 +217,9 @@ int gft_group_dsl_tokens(const uint8_t* expr, uint64_t len, char* out, uint64_t 
  *   gft_to_lower  : strings.ToLower of the input (raw bytes out, not JSON). */
 int gft_dsl_parse(const uint8_t* expr, uint64_t len, int case_sensitive, char* out, uint64_t cap, uint64_t* needed);
 int gft_dsl_tokens(const uint8_t* expr, uint64_t len, char* out, uint64_t cap, uint64_t* needed);
+/* the literal runs every match of an RE2-syntax pattern must contain, as a JSON array (empty: the pattern cannot be
+ * prefiltered) -- what the finder's regex prefilter adds to the device dictionary */
+int gft_regex_required_literals(const uint8_t* pattern, uint64_t len, char* out, uint64_t cap, uint64_t* needed);
 int gft_to_lower(const uint8_t* in, uint64_t len, uint8_t* out, uint64_t cap, uint64_t* needed);
 
 /* ---- measurement hooks (bench.py) ---------------------------------------------------------------------- */

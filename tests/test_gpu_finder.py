@@ -187,3 +187,58 @@ def test_process_texts_matches_oracle_with_regex_terms():
     want = o.process(text, off, fold=True, extra=extra)
     assert np.array_equal(bm, want)
     assert any(len(x) for x in (lits,))
+
+
+def _oracle_with_regex(f, exprs, text, off, n):
+    """expected bitmap: CPU oracle + the host regex stand-in on EVERY document (what the reference does)"""
+    kws = sorted(f.GetKeywords())
+    o = Oracle(kws)
+    o.set_expressions(exprs, False)
+    eng = PyRegexpEngine()
+    eng.BuildEngine(sorted(f.GetRegexes()), False)
+    offs, lits, poss = [0], [], []
+    for d in range(n):
+        t = bytes(text[int(off[d]):int(off[d + 1])])
+        for m in eng.FindRegexes(t):
+            lits.append(o.literals.index(m.Term))
+            poss.append(m.Position)
+        offs.append(len(lits))
+    extra = (np.asarray(offs, np.uint64), np.asarray(lits or [0], np.int32), np.asarray(poss or [0], np.int64))
+    return o.process(text, off, fold=True, extra=extra), len(set(np.searchsorted(offs, range(len(lits)), side="right")))
+
+
+@pytest.mark.parametrize("prefilter", ["1", "0"])
+def test_regex_prefilter_same_results_fewer_regex_calls(prefilter, monkeypatch):
+    """with the GPU engine, regexes whose matches must contain literal runs get hidden
+    AND-of-literals programs; the host regex engine then only sees the documents where one fired.  Results are those of
+    running it everywhere (the oracle side does exactly that); GFT_REGEX_PREFILTER=0 is the everywhere path."""
+    from gofindthem_amd.workload import Workload, make_expressions
+    monkeypatch.setenv("GFT_REGEX_PREFILTER", prefilter)
+    w = Workload(300)
+    terms = w.terms()
+    text, off = w.docs_host(0, 200)
+    sample = bytes(text[:int(off[40])]).decode("ascii").split()
+    rng = np.random.default_rng(3)
+    words = [x for x in sample if len(x) >= 6]
+    rx = []
+    for _ in range(6):                              # wA.*wB (README.md:14-15 shape) from words that do occur, plus rarer shapes
+        a, b = words[int(rng.integers(len(words)))], words[int(rng.integers(len(words)))]
+        rx.append("%s.*%s" % (a[:4], b[-4:]))
+    rx += ["%s[a-z]+%s" % (words[5][:3], words[5][-2:]), "zzqq.*never", "%s[ ]+%s" % (sample[10], sample[11])]
+    exprs = make_expressions(terms, 80, inord_fraction=0.3, regexes=rx)
+    f = Finder(GpuEngine(), PyRegexpEngine(), False)
+    f.AddExpressions(exprs)
+    assert sorted(f.GetRegexes()) == sorted(set(rx))
+    bm = f.ProcessTexts(blob=text, doc_off=off)
+    want, docs_with_hits = _oracle_with_regex(f, exprs, text, off, 200)
+    assert np.array_equal(bm, want)
+    assert docs_with_hits > 0
+    seen = int(_lib.load().gft_finder_last_regex_docs(f._h))
+    if prefilter == "1":
+        assert docs_with_hits <= seen < 200          # candidates: a superset of the documents with hits, not everything
+    # keyword set is the user's, the hidden literals are not visible (finder.go:58-63 GetKeywords)
+    assert sorted(f.GetKeywords()) == sorted(set(k for k in f.GetKeywords()))
+    # single-document calls agree
+    for d in (0, 7, 199):
+        one = f.ProcessText(bytes(text[int(off[d]):int(off[d + 1])]))
+        assert [r.ExpresionIndex for r in one] == [i for i in range(len(exprs)) if want[d, i >> 5] >> (i & 31) & 1]

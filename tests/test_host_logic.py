@@ -205,3 +205,47 @@ def test_force_build_quirk():
     assert len(rgx.calls) == 2 and len(sub.calls) == 1
     f.AddExpression('"a"')                                # a known keyword still clears the flag (finder.go:123-126)
     assert f.debug_get_updated() == (False, False)
+
+
+# ---- regex prefilter: required literals ------------------------------------------------------------
+def _required(pattern):
+    import ctypes as C
+    import json
+    L = _lib.load()
+    p = pattern.encode("utf-8")
+    buf = C.create_string_buffer(4096)
+    need = C.c_uint64()
+    assert L.gft_regex_required_literals(p, len(p), C.cast(buf, C.c_void_p), 4096, C.byref(need)) == 0
+    return json.loads(buf.value.decode("utf-8"))
+
+
+@pytest.mark.parametrize("pattern,want", [
+    ("en.*nr", ["en", "nr"]), ("po[a-z]+ud", ["po", "ud"]), ("q+", []), ("abc", ["abc"]), ("ab?c", []), ("abc?d", ["ab"]),
+    ("ab*cd", ["cd"]), ("abc+de", ["abc", "de"]), ("a{2}bc", ["bc"]), ("xy{0,3}zw", ["zw"]), ("xy{1,3}zw", ["xy", "zw"]),
+    (r"foo\.bar", ["foo.bar"]), (r"foo\dbar", ["foo", "bar"]), (r"a\x41b", []), ("(ab|cd)ef", ["ef"]), ("ab|cd", []),
+    ("(?i)abc", []), ("(?:ab)+cd", ["cd"]), ("^hello$", ["hello"]), ("he[l]lo wor.d", ["he", "lo wor"]), ("é+x", ["é"]),
+    ("ééé?x", ["éé"]), ("ab)", []), ("a[bc", []), ("ab{x", []), (r"\Qab\E", []), ("héllo wörld", ["héllo wörld"]),
+    (r"(?P<n>ab)cd\s+ef", ["cd", "ef"]), ("ab.*?cd", ["ab", "cd"]), ("[[:alpha:]]+foo", ["foo"]), (r"[\]]ab", ["ab"])])
+def test_regex_required_literals(pattern, want):
+    assert _required(pattern) == want
+
+
+def test_regex_required_literals_are_required():
+    """property: whenever the pattern matches a text, every extracted literal occurs in it (checked with Python's re
+    on random texts over a small alphabet, for patterns both engines read the same way)"""
+    import random
+    import re
+    rng = random.Random(7)
+    pats = ["ab.*ba", "a+bb", "ab[ab]+ba", "(ab)+ba", "ab?ba", "aab*", "ba{2}b", "b.a.b", "abb|baa", "ab{1,2}a", "^ab.*b$",
+            r"a\.?bb", "(?:ba)*ab", "bab+a", "a[^a]b", "abba?b"]
+    for pat in pats:
+        lits = _required(pat)
+        rx = re.compile(pat)
+        hits = 0
+        for _ in range(3000):
+            t = "".join(rng.choice("ab.") for _ in range(rng.randint(0, 12)))
+            if rx.search(t):
+                hits += 1
+                for lit in lits:
+                    assert lit in t, (pat, lits, t)
+        assert hits > 0, pat

@@ -167,9 +167,9 @@ GFT_HD inline uint32_t scan2_fpt_byte(uint32_t code, uint32_t xmix, uint32_t f_l
     return code << 5 | h >> 27;
 }
 GFT_HD inline bool scan2_fpt_pass(uint32_t cell, uint32_t xmix, uint32_t f_lo) {
-    if (cell == 0) return false;
-    if (cell == kScan2FptAmbiguous) return true;
-    return scan2_fpt_byte(cell >> 5, xmix, f_lo) == cell;
+    // no early outs: lanes of a wave hold different cells, straight-line code with selects is cheaper than the branches
+    const bool same = scan2_fpt_byte(cell >> 5, xmix, f_lo) == cell;
+    return (cell == kScan2FptAmbiguous) | ((cell != 0) & same);
 }
 
 struct Scan2Params {

@@ -120,7 +120,7 @@ __device__ __forceinline__ void cand_keys(const Ctx& c, uint32_t p, const Text8 
 __device__ __forceinline__ void cand_decide(const Ctx& c, Cand& k) {
     const uint32_t f0 = c.fpt[scan2_fpt_cell(k.x, 0)], f1 = c.fpt[scan2_fpt_cell(k.x, 1)];
     const uint32_t xm = scan2_fpt_xmix(k.x);
-    k.go_long = scan2_fpt_pass(f0, xm, k.tw) || scan2_fpt_pass(f1, xm, k.tw);
+    k.go_long = ((int)scan2_fpt_pass(f0, xm, k.tw) | (int)scan2_fpt_pass(f1, xm, k.tw)) != 0;
     if (c.P.dbg & 12) {         // timing studies (wrong results): 4 = no bucket-table access, 8 = no short-term records
         if (c.P.dbg & 4) k.go_long = false;
         if (c.P.dbg & 8) k.sid = 0;

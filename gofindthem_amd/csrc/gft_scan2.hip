@@ -216,9 +216,15 @@ __device__ __forceinline__ bool entry_ok(const Ctx& c, uint32_t p, const Front& 
 
 // the three words of short-term record `sid` of 3-window x3 (LDS; ids beyond 254 live in global memory)
 __device__ __forceinline__ void short_record(const Ctx& c, uint32_t sid, uint32_t x3, uint32_t (&r)[3]) {
-    const uint32_t* src = c.lrec + 3 * sid;
-    if (__builtin_expect(sid == 255 && c.P.short3_big != nullptr, 0)) src = c.P.shorts_packed + 3 * (size_t)c.P.short3_big[x3];
+    // two separate accesses (an LDS read, and -- rarely -- a global one): a pointer that may be either would turn both
+    // into flat loads, which wait on the vector-memory AND the LDS counters
+    const bool big = sid == 255 && c.P.short3_big != nullptr;
+    const uint32_t* src = c.lrec + 3 * (big ? 0 : sid);
     r[0] = src[0]; r[1] = src[1]; r[2] = src[2];
+    if (__builtin_expect(big, 0)) {
+        const uint32_t* g = c.P.shorts_packed + 3 * (size_t)c.P.short3_big[x3];
+        r[0] = g[0]; r[1] = g[1]; r[2] = g[2];
+    }
 }
 
 // step 3 (ordered path): all terms that end at p, longest first.  MODE 0: count and stage per lane in LDS;

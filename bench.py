@@ -82,15 +82,23 @@ def main():
     first, _ = shard_range(rank, world, args.docs)
     text, doc_off = wl.docs_device(first, args.docs, device=dev)
     words = (args.exprs + 31) // 32
-    bitmap = torch.zeros((args.docs, words), dtype=torch.int32, device=dev)
-    gather = BitmapGather(bitmap)          # rank 0 receives every rank's bitmap: the path's only exchange step
+    # two result buffers: the gather of batch i (the path's only exchange step, RCCL over xGMI) is in flight on the
+    # process group's stream while batch i + 1 is scanned and solved; everything is complete before the closing fence
+    bitmaps = [torch.zeros((args.docs, words), dtype=torch.int32, device=dev) for _ in range(2 if world > 1 else 1)]
+    bitmap = bitmaps[0]
+    gather = BitmapGather(bitmaps)         # rank 0 receives every rank's bitmap
     text_bytes = int(text.numel())
+    n_steps_done = [0]
 
     def step():
-        finder.ProcessDevice(text.data_ptr(), doc_off.data_ptr(), args.docs, bitmap.data_ptr())
-        gather()
+        slot = n_steps_done[0] % len(bitmaps)
+        n_steps_done[0] += 1
+        gather.wait(slot)                  # the previous exchange out of this buffer has landed
+        finder.ProcessDevice(text.data_ptr(), doc_off.data_ptr(), args.docs, bitmaps[slot].data_ptr())
+        gather.start(slot)
 
     def fence():
+        gather.drain()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -144,7 +152,9 @@ def main():
         np.array_equal(text[:int(h_off[-1])].cpu().numpy(), h_text))
     parity_ok = all_ranks_ok(gen_ok, dev)
     if world > 1 and rank == 0:
-        parity_ok = parity_ok and bool(torch.equal(gather.parts[0], bitmap))
+        last = (n_steps_done[0] - 1) % len(bitmaps)
+        parity_ok = parity_ok and bool(torch.equal(gather.slot_parts[last][0], bitmaps[last]))
+        bitmap = bitmaps[last]
     parity = "not checked in this run (the CPU oracle runs in the cpu_baseline leg, N = 1 only); tests/ -m gpu hold the parity proofs"
 
     # ---- CPU baseline (rank 0, N == 1): the oracle = our restatement of the reference path, on this host ---------------

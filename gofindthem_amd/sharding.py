@@ -26,17 +26,25 @@ def split_docs(n_docs, world):
 
 
 class BitmapGather:
-    """rank 0 receives every rank's [docs, words] int32 bitmap; buffers are allocated once and reused per step"""
+    """rank 0 receives every rank's [docs, words] int32 bitmap; buffers are allocated once and reused per step.
+
+    One local bitmap: `gather()` is the plain collective.  Several local bitmaps (slots): `start(slot)` launches the
+    gather of that slot asynchronously and `wait(slot)` is called before the slot is written again, so the exchange of
+    batch i travels over xGMI while batch i + 1 is scanned and solved (the collective runs on the process group's own
+    stream); `drain()` completes everything that is still in flight."""
 
     def __init__(self, local_bitmap, rows_per_rank=None):
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
-        self.local = local_bitmap
-        self.parts = None
+        self.locals = list(local_bitmap) if isinstance(local_bitmap, (list, tuple)) else [local_bitmap]
+        self.local = self.locals[0]
+        self.slot_parts = [None] * len(self.locals)
+        self.pending = [None] * len(self.locals)
         if self.world > 1 and self.rank == 0:
-            rows = rows_per_rank or [local_bitmap.shape[0]] * self.world
-            self.parts = [torch.empty((r, local_bitmap.shape[1]), dtype=local_bitmap.dtype, device=local_bitmap.device)
-                          for r in rows]
+            rows = rows_per_rank or [self.local.shape[0]] * self.world
+            self.slot_parts = [[torch.empty((r, self.local.shape[1]), dtype=self.local.dtype, device=self.local.device)
+                                for r in rows] for _ in self.locals]
+        self.parts = self.slot_parts[0]
         if self.world > 1 and rows_per_rank is not None and len(set(rows_per_rank)) > 1:
             raise ValueError("dist.gather needs equal shard sizes; pad the last shard or use split sizes that divide")
 
@@ -45,9 +53,22 @@ class BitmapGather:
             dist.gather(self.local, self.parts, dst=0)
         return self.parts if self.world > 1 else [self.local]
 
-    def full(self):
+    def start(self, slot):
+        if self.world > 1:
+            self.pending[slot] = dist.gather(self.locals[slot], self.slot_parts[slot], dst=0, async_op=True)
+
+    def wait(self, slot):
+        if self.pending[slot] is not None:
+            self.pending[slot].wait()
+            self.pending[slot] = None
+
+    def drain(self):
+        for s in range(len(self.locals)):
+            self.wait(s)
+
+    def full(self, slot=0):
         """rank 0: the bitmap of all documents in document order"""
-        parts = self.parts if self.world > 1 else [self.local]
+        parts = self.slot_parts[slot] if self.world > 1 else [self.locals[slot]]
         return torch.cat(parts, 0) if self.rank == 0 else None
 
 

@@ -52,7 +52,17 @@ def _worker(rank, world, port, use_gpu, out_path):
         local = torch.from_numpy(o.process(text, off, fold=True).view(np.int32))
     g = BitmapGather(local)
     g()
-    ok = all_ranks_ok(True, "cpu")
+    # pipelined form (bench.py, N > 1): two result buffers, gathers in flight while the next batch is computed
+    other = local ^ 0x55
+    gp = BitmapGather([local.clone(), other])
+    gp.start(0)
+    gp.start(1)
+    gp.wait(0)
+    gp.drain()
+    pipelined_ok = True
+    if rank == 0:
+        pipelined_ok = bool(torch.equal(gp.full(0), g.full())) and bool(torch.equal(gp.full(1), g.full() ^ 0x55))
+    ok = all_ranks_ok(pipelined_ok, "cpu")
     t = max_over_ranks(float(rank), "cpu")
     if rank == 0:
         full = g.full().numpy().view(np.uint32)

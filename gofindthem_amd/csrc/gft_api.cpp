@@ -301,8 +301,10 @@ int ensure_pool(gft_engine* e, uint64_t entries) {
 
 // The device pipeline shared by scan and process.  On success the canonical CSR sits in e->d_match_off /
 // d_term / d_pos and *n_matches is set.
+constexpr uint64_t kHostUnitDocs = 1024;   // batches up to this many documents get their unit table from the host
+
 int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_off, uint64_t n_docs, uint32_t flags,
-                  bool need_csr, uint64_t* n_matches) {
+                  bool need_csr, uint64_t* n_matches, const uint64_t* h_doc_off = nullptr) {
     hipStream_t st = e->stream;
     *n_matches = 0;
     e->scan_valid_docs = ~0ull;           // the pool is about to be overwritten
@@ -322,17 +324,40 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
     HIP_TRY(e->d_unit_base.ensure((n_docs + 1) * 8), "unit alloc");
     HIP_TRY(e->d_partial.ensure(scan_partials_needed(n_docs) * 8), "unit alloc");
     uint64_t n_units = 0, text_lo = 0, text_hi = 0;
-    {
-        ProfScope ps(e, "aux");
-        HIP_TRY(launch_unit_count(d_doc_off, n_docs, unit_max, e->d_unit_cnt.as<uint32_t>(), st), "unit_count");
-        HIP_TRY(launch_exclusive_scan(e->d_unit_cnt.as<uint32_t>(), n_docs, e->d_unit_base.as<uint64_t>(),
-                                      e->d_partial.as<uint64_t>(), st), "unit scan");
+    // small batches from host memory (a single ProcessText / FindSubstrings call is the reference's own shape): the unit
+    // table is a few entries, computed here and uploaded instead of five kernel launches and a synchronising read-back
+    const bool host_units = h_doc_off != nullptr && n_docs <= kHostUnitDocs;
+    std::vector<uint64_t> hub;
+    std::vector<Unit> hun;
+    if (host_units) {
+        hub.assign(n_docs + 1, 0);
+        for (uint64_t d = 0; d < n_docs; d++) {
+            if (h_doc_off[d + 1] < h_doc_off[d]) return fail(e, GFT_E_INVALID, "doc_off is not ascending");
+            const uint64_t n = h_doc_off[d + 1] - h_doc_off[d];
+            const uint64_t k = n <= unit_max ? 1 : (n + unit_max - 1) / unit_max;
+            hub[d + 1] = hub[d] + k;
+            const uint64_t per = (n + k - 1) / k;                 // as k_unit_fill
+            for (uint64_t i = 0; i < k; i++) {
+                uint64_t lo = i * per, hi = lo + per < n ? lo + per : n;
+                if (lo > n) lo = n;
+                hun.push_back(Unit{(uint32_t)d, (uint32_t)lo, (uint32_t)hi});
+            }
+        }
+        n_units = hub[n_docs]; text_lo = h_doc_off[0]; text_hi = h_doc_off[n_docs];
+        HIP_TRY(hipMemcpyAsync(e->d_unit_base.p, hub.data(), (n_docs + 1) * 8, hipMemcpyHostToDevice, st), "unit upload");
+    } else {
+        {
+            ProfScope ps(e, "aux");
+            HIP_TRY(launch_unit_count(d_doc_off, n_docs, unit_max, e->d_unit_cnt.as<uint32_t>(), st), "unit_count");
+            HIP_TRY(launch_exclusive_scan(e->d_unit_cnt.as<uint32_t>(), n_docs, e->d_unit_base.as<uint64_t>(),
+                                          e->d_partial.as<uint64_t>(), st), "unit scan");
+        }
+        HIP_TRY(hipMemcpyAsync(&n_units, e->d_unit_base.as<uint64_t>() + n_docs, 8, hipMemcpyDeviceToHost, st), "readback");
+        HIP_TRY(hipMemcpyAsync(&text_lo, d_doc_off, 8, hipMemcpyDeviceToHost, st), "readback");
+        HIP_TRY(hipMemcpyAsync(&text_hi, d_doc_off + n_docs, 8, hipMemcpyDeviceToHost, st), "readback");
+        HIP_TRY(hipStreamSynchronize(st), "sync");
+        if (text_hi < text_lo) return fail(e, GFT_E_INVALID, "doc_off is not ascending");
     }
-    HIP_TRY(hipMemcpyAsync(&n_units, e->d_unit_base.as<uint64_t>() + n_docs, 8, hipMemcpyDeviceToHost, st), "readback");
-    HIP_TRY(hipMemcpyAsync(&text_lo, d_doc_off, 8, hipMemcpyDeviceToHost, st), "readback");
-    HIP_TRY(hipMemcpyAsync(&text_hi, d_doc_off + n_docs, 8, hipMemcpyDeviceToHost, st), "readback");
-    HIP_TRY(hipStreamSynchronize(st), "sync");
-    if (text_hi < text_lo) return fail(e, GFT_E_INVALID, "doc_off is not ascending");
 
     HIP_TRY(e->d_units.ensure(n_units * sizeof(Unit)), "unit alloc");
     HIP_TRY(e->d_unit_start.ensure(n_units * 8), "unit alloc");
@@ -342,7 +367,11 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
     HIP_TRY(e->d_cursor.ensure(8), "cursor alloc");
     {
         ProfScope ps(e, "aux");
-        HIP_TRY(launch_unit_fill(d_doc_off, n_docs, e->d_unit_base.as<uint64_t>(), e->d_units.as<Unit>(), st), "unit_fill");
+        if (host_units) {
+            if (n_units) HIP_TRY(hipMemcpyAsync(e->d_units.p, hun.data(), n_units * sizeof(Unit), hipMemcpyHostToDevice, st), "unit upload");
+        } else {
+            HIP_TRY(launch_unit_fill(d_doc_off, n_docs, e->d_unit_base.as<uint64_t>(), e->d_units.as<Unit>(), st), "unit_fill");
+        }
     }
 
     // 2. automaton walk into the slab pool; grow the pool and re-run if it overflowed (never truncate)
@@ -703,7 +732,7 @@ int gft_scan(gft_engine* e, const uint8_t* text_blob, const uint64_t* doc_off, u
     int rc = stage_docs(e, text_blob, doc_off, n_docs);
     if (rc) return rc;
     uint64_t nm = 0;
-    rc = scan_pipeline(e, e->d_text.as<uint8_t>(), e->d_doc_off.as<uint64_t>(), n_docs, flags, true, &nm);
+    rc = scan_pipeline(e, e->d_text.as<uint8_t>(), e->d_doc_off.as<uint64_t>(), n_docs, flags, true, &nm, doc_off);
     if (rc) return rc;
     e->h_match_off.assign(n_docs + 1, 0);
     e->h_term.assign(nm, 0);
@@ -871,7 +900,7 @@ int gft_process(gft_engine* e, const uint8_t* text_blob, const uint64_t* doc_off
     const uint64_t words = (e->n_exprs + 31) / 32;
     HIP_TRY(e->d_bitmap.ensure(std::max<uint64_t>(n_docs * words, 1) * 4), "bitmap alloc");
     uint64_t nm = 0;
-    rc = scan_pipeline(e, e->d_text.as<uint8_t>(), e->d_doc_off.as<uint64_t>(), n_docs, flags, false, &nm);
+    rc = scan_pipeline(e, e->d_text.as<uint8_t>(), e->d_doc_off.as<uint64_t>(), n_docs, flags, false, &nm, doc_off);
     if (rc) return rc;
     e->scan_valid_docs = n_docs;          // gft_process_again may reuse this scan
     rc = solve_pipeline(e, n_docs, pdx, e->d_bitmap.as<uint32_t>());

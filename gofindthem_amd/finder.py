@@ -249,11 +249,11 @@ class Finder:
         idx = np.zeros(cap, dtype=np.uint32)
         n = C.c_uint32()
         self._check(self._L.gft_finder_process_text(self._h, b, len(b), idx.ctypes.data, cap, C.byref(n)))
-        out = []
-        for i in idx[:n.value].tolist():
-            s, t, _ = self.expression(i)
-            out.append(ExpressionResult(i, s, t))
-        return out
+        cache = self.__dict__.setdefault("_expr_cache", [])      # (source, tag) per registered expression
+        while len(cache) < self.n_expressions:
+            s, t, _ = self.expression(len(cache))
+            cache.append((s, t))
+        return [ExpressionResult(i, cache[i][0], cache[i][1]) for i in idx[:n.value].tolist()]
 
     def ProcessTexts(self, texts=None, blob=None, doc_off=None):
         """batch extension -> uint32 bitmap [n_docs, ceil(E/32)]"""

@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <thread>
 
 namespace gft {
 
@@ -244,6 +245,28 @@ Error Finder::collect(const std::string& text, bool run_sub, std::vector<Record>
     return "";
 }
 
+// no byte of [p, p + n) has its top bit set; eight bytes per step, a few threads for large batches
+static bool all_ascii(const uint8_t* p, uint64_t n) {
+    auto range = [](const uint8_t* q, uint64_t m) {
+        uint64_t acc = 0, i = 0;
+        for (; i + 8 <= m; i += 8) { uint64_t w; memcpy(&w, q + i, 8); acc |= w; }
+        for (; i < m; i++) acc |= q[i];
+        return (acc & 0x8080808080808080ull) == 0;
+    };
+    if (n < (16u << 20)) return range(p, n);
+    constexpr unsigned kT = 4;
+    bool ok[kT];
+    std::thread th[kT];
+    const uint64_t part = (n + kT - 1) / kT;
+    for (unsigned t = 0; t < kT; t++) {
+        const uint64_t a = std::min(n, t * part), b = std::min(n, (t + 1) * part);
+        th[t] = std::thread([&ok, t, p, a, b, range] { ok[t] = range(p + a, b - a); });
+    }
+    bool all = true;
+    for (unsigned t = 0; t < kT; t++) { th[t].join(); all = all && ok[t]; }
+    return all;
+}
+
 // finder/finder.go:139-179
 Error Finder::ProcessText(const std::string& text_in, std::vector<ExpressionResult>& expRes) {
     expRes.clear();
@@ -277,7 +300,7 @@ Error Finder::ProcessTexts(const uint8_t* blob, const uint64_t* doc_off, uint64_
     const uint64_t total = n_docs ? doc_off[n_docs] : 0;
     bool ascii = true;
     if (!caseSensitive_) {
-        for (uint64_t i = n_docs ? doc_off[0] : 0; i < total && ascii; i++) ascii = blob[i] < 0x80;
+        ascii = all_ascii(blob + (n_docs ? doc_off[0] : 0), total - (n_docs ? doc_off[0] : 0));
         if (ascii) flags = GFT_FOLD_ASCII;
     }
     const bool need_host_text = !caseSensitive_ && !ascii;

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <cstdlib>
@@ -46,6 +47,10 @@ struct ProfCat {
 struct gft_engine {
     int device = 0;
     hipStream_t stream = nullptr;
+    // host -> device staging of large caller buffers: two pinned bounce buffers, filled by a few copy threads while the
+    // previous one is on the wire (a hipMemcpy from pageable memory stages through one thread)
+    void* pin[2] = {nullptr, nullptr};
+    hipEvent_t pin_ev[2] = {nullptr, nullptr};
     bool own_stream = false;
     unsigned n_cus = 256;
     size_t lds_max = 65536;
@@ -584,6 +589,10 @@ void gft_engine_destroy(gft_engine* e) {
                          &e->d_term, &e->d_pos, &e->d_match_off, &e->d_text, &e->d_doc_off, &e->d_bitmap, &e->d_xoff,
                          &e->d_xslot, &e->d_xpos};
         for (DevBuf* b : all) b->release();
+        for (int k = 0; k < 2; k++) {
+            if (e->pin[k]) (void)hipHostFree(e->pin[k]);
+            if (e->pin_ev[k]) (void)hipEventDestroy(e->pin_ev[k]);
+        }
         if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     }
     delete e;
@@ -714,11 +723,43 @@ int gft_scan_device(gft_engine* e, const uint8_t* d_text_blob, const uint64_t* d
     return GFT_OK;
 }
 
+constexpr size_t kPinChunk = 32u << 20;      // bytes per bounce buffer
+constexpr unsigned kPinThreads = 4;
+
+// pageable host memory -> device through the pinned bounce buffers
+static int h2d_staged(gft_engine* e, void* dst, const void* src, size_t bytes) {
+    if (bytes < (8u << 20)) {
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, e->stream), "upload");
+        return GFT_OK;
+    }
+    for (int k = 0; k < 2; k++) {
+        if (!e->pin[k]) HIP_TRY(hipHostMalloc(&e->pin[k], kPinChunk, hipHostMallocDefault), "pinned alloc");
+        if (!e->pin_ev[k]) HIP_TRY(hipEventCreateWithFlags(&e->pin_ev[k], hipEventDisableTiming), "event");
+    }
+    size_t done = 0;
+    for (int k = 0; done < bytes; k ^= 1) {
+        const size_t n = std::min(kPinChunk, bytes - done);
+        HIP_TRY(hipEventSynchronize(e->pin_ev[k]), "staging");        // the copy out of this buffer has finished
+        const uint8_t* s0 = (const uint8_t*)src + done;
+        uint8_t* d0 = (uint8_t*)e->pin[k];
+        std::thread th[kPinThreads];
+        const size_t part = (n + kPinThreads - 1) / kPinThreads;
+        for (unsigned t = 1; t < kPinThreads; t++)
+            th[t] = std::thread([=] { const size_t a = std::min(n, t * part), b = std::min(n, (t + 1) * part); if (b > a) memcpy(d0 + a, s0 + a, b - a); });
+        memcpy(d0, s0, std::min(n, part));
+        for (unsigned t = 1; t < kPinThreads; t++) th[t].join();
+        HIP_TRY(hipMemcpyAsync((uint8_t*)dst + done, e->pin[k], n, hipMemcpyHostToDevice, e->stream), "upload");
+        HIP_TRY(hipEventRecord(e->pin_ev[k], e->stream), "staging");
+        done += n;
+    }
+    return GFT_OK;
+}
+
 static int stage_docs(gft_engine* e, const uint8_t* text_blob, const uint64_t* doc_off, uint64_t n_docs) {
     const uint64_t bytes = n_docs ? doc_off[n_docs] : 0;
     HIP_TRY(e->d_text.ensure(bytes + 64), "text alloc");
     HIP_TRY(e->d_doc_off.ensure((n_docs + 1) * 8), "doc_off alloc");
-    if (bytes) HIP_TRY(hipMemcpyAsync(e->d_text.p, text_blob, bytes, hipMemcpyHostToDevice, e->stream), "text upload");
+    if (bytes) { int rc = h2d_staged(e, e->d_text.p, text_blob, bytes); if (rc) return rc; }
     if (n_docs) HIP_TRY(hipMemcpyAsync(e->d_doc_off.p, doc_off, (n_docs + 1) * 8, hipMemcpyHostToDevice, e->stream), "doc_off upload");
     return GFT_OK;
 }

@@ -191,7 +191,10 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         # algorithmic bytes of the dominant (scan) kernel per launch: text once + one offset entry per document +
         # 8 bytes per match written
-        alg_bytes = text_bytes + 8 * args.docs + 8 * n_matches
+        # (u32 term id + u32 position per match; without INORD expressions the path is presence-only and
+        # writes the term ids alone, so only those 4 bytes count)
+        per_match = 8 if args.inord > 0 else 4
+        alg_bytes = text_bytes + 8 * args.docs + per_match * n_matches
         scan_avg_ms = scan_ms / max(scan_n, 1)
         achieved = alg_bytes / (scan_avg_ms * 1e-3) / 1e9 if scan_n else 0.0
         # HBM traffic of the scan kernel from rocprofv3 PMC passes (profiles/r1_pmc_traffic.json; it cannot be

@@ -126,14 +126,18 @@ struct Scan2Short {
     uint32_t pad;
 };
 constexpr uint32_t kScan2Short3Max = 32768;      // bytes of LDS a direct 3-window table may take (K' <= 32)
-constexpr uint32_t kScan2FptSize = 16384;        // one byte per hashed window key
-constexpr uint32_t kScan2FptAmbiguous = 0xFF;    // several terms share the byte: always go to the bucket table
-// Fingerprint table: every window key that ends a term of length >= 4 owns ONE of its two candidate cells (cuckoo
-// placement at build time).  cell byte = code << 5 | fp5(key, the term's bytes in front of the window); code 1..5
-// says how many front bytes the fingerprint covers (0..4); 0 = empty cell; 0xFF = always go to the bucket table.
-// Front bytes as loaded from the text: `f_lo` = text[p-7..p-4] (little endian), case bit cleared on both sides so the
-// same table serves exact and ASCII-folded scans (the bucket table does the exact compare).  A position passes if
-// either of its two cells passes.  All hashing is 24-bit multiplies (v_mul_u32_u24 / v_mad_u32_u24: full rate).
+constexpr uint32_t kScan2FptSize = 20480;        // cells (one byte each)
+constexpr uint32_t kScan2FptAmbiguous = 0xFF;    // always go to the bucket table
+// Fingerprint table: the LDS-only answer to "can a term of length >= 4 end here at all?" for a position whose window
+// passed the filter.  One cell per TERM (cuckoo placement at build time):
+//   * a term of length exactly 4 is its window: it owns the cell x-hash(key), byte = 5 << 5 | fp5(key);
+//   * a longer term is keyed by (window key, the byte in front of the window): it owns one of the two cells
+//     g-hash_{0,1}(key, b1), byte = code << 5 | fp5(key, b1, the next code - 1 bytes further to the front), code 1..4.
+//     Terms that share a window almost always differ in b1, so multi-term buckets get real fingerprints too; two terms
+//     with the same (key, b1) take both cells, three or more make the cell kScan2FptAmbiguous.
+// 0 = empty cell.  Front bytes as loaded from the text: tw = text[p-7..p-4] (little endian, p-4 on top), case bit cleared
+// on both sides so the same table serves exact and ASCII-folded scans (the bucket table does the exact compare).
+// A position passes if its x-cell or either g-cell passes.  All hashing is 24-bit multiplies (v_mul_u32_u24: full rate).
 // low 32 bits of (a mod 2^24) * (C mod 2^24).  On the device this must be v_mul_u32_u24 (full rate); the compiler
 // tends to pick the quarter-rate v_mul_lo_u32 for the generic form, hence the explicit instruction.
 template <uint32_t C>
@@ -151,25 +155,31 @@ GFT_HD inline uint32_t scan2_slot_hash(uint32_t x, int which, uint32_t shift) {
     const uint32_t xf = x ^ (x >> 20);             // keys beyond 24 bits (hashed alphabets) keep their top bits in play
     return (which ? scan2_mul24c<0x85EBCBu>(xf) : scan2_mul24c<0x9E3779u>(xf)) >> shift;
 }
-GFT_HD inline uint32_t scan2_fpt_cell(uint32_t x, int which) {          // 14 bits
-    return (which ? scan2_mul24c<0xB2AE35u>(x) : scan2_mul24c<0x3779B1u>(x)) >> 18;
+GFT_HD inline uint32_t scan2_fpt_index(uint32_t h) {
+    return (kScan2FptSize & (kScan2FptSize - 1)) == 0 ? h >> (32 - __builtin_ctz(kScan2FptSize)) : scan2_mul24c<kScan2FptSize>(h >> 16) >> 16;
 }
-GFT_HD inline uint32_t scan2_fpt_code(uint32_t term_len) {            // term_len >= 4
-    const uint32_t nf = term_len - 4;
-    return nf < 4 ? nf + 1 : 5;
+GFT_HD inline uint32_t scan2_fpt_xcell(uint32_t x) { return scan2_fpt_index(scan2_mul24c<0x3779B1u>(x)); }
+GFT_HD inline uint32_t scan2_fpt_gcell(uint32_t x, uint32_t b1n, int which) {
+    return scan2_fpt_index(which ? scan2_mul24c<0xB2AE35u>(x) + scan2_mul24c<0x9E4F2Du>(b1n)
+                                 : scan2_mul24c<0xC2B2AFu>(x) + scan2_mul24c<0x27D4EBu>(b1n));
 }
 GFT_HD inline uint32_t scan2_fpt_xmix(uint32_t x) { return scan2_mul24c<0xD4EB2Fu>(x); }
-GFT_HD inline uint32_t scan2_fpt_byte(uint32_t code, uint32_t xmix, uint32_t f_lo) {
-    // the n = code - 1 bytes next to the window, right-justified; n == 0 covers nothing
-    const uint32_t f = f_lo & 0xDFDFDFDFu;
-    const uint32_t a = code == 1 ? 0u : f >> ((40u - 8u * code) & 31u);
-    const uint32_t h = scan2_mul24c<0xEBCA6Bu>(a ^ (a >> 11)) + xmix;
+GFT_HD inline uint32_t scan2_fpt_xbyte(uint32_t xmix) { return 5u << 5 | xmix >> 27; }
+// twn = tw & 0xDFDFDFDF; code 1..4 covers b1 plus 0..3 more bytes (p-5, p-6, p-7)
+GFT_HD inline uint32_t scan2_fpt_gbyte(uint32_t code, uint32_t xmix, uint32_t twn) {
+    const uint32_t rest = twn & 0x00FFFFFFu;
+    const uint32_t a = code == 1 ? 0u : rest >> ((32u - 8u * code) & 31u);
+    const uint32_t h = scan2_mul24c<0xEBCA6Bu>(a ^ (a >> 11)) + xmix + scan2_mul24c<0x5BD1E9u>(twn >> 24);
     return code << 5 | h >> 27;
 }
-GFT_HD inline bool scan2_fpt_pass(uint32_t cell, uint32_t xmix, uint32_t f_lo) {
-    // no early outs: lanes of a wave hold different cells, straight-line code with selects is cheaper than the branches
-    const bool same = scan2_fpt_byte(cell >> 5, xmix, f_lo) == cell;
-    return (cell == kScan2FptAmbiguous) | ((cell != 0) & same);
+GFT_HD inline bool scan2_fpt_pass(uint32_t cx, uint32_t cg0, uint32_t cg1, uint32_t xmix, uint32_t tw) {
+    // no early outs: lanes of a wave hold different cells, straight-line code with selects is cheaper than branches
+    const uint32_t twn = tw & 0xDFDFDFDFu;
+    const uint32_t k0 = cg0 >> 5, k1 = cg1 >> 5;
+    const bool g0 = (k0 - 1u < 4u) & (scan2_fpt_gbyte(k0, xmix, twn) == cg0);
+    const bool g1 = (k1 - 1u < 4u) & (scan2_fpt_gbyte(k1, xmix, twn) == cg1);
+    const bool amb = (cx == kScan2FptAmbiguous) | (cg0 == kScan2FptAmbiguous) | (cg1 == kScan2FptAmbiguous);
+    return (cx == scan2_fpt_xbyte(xmix)) | g0 | g1 | amb;
 }
 
 struct Scan2Params {

@@ -118,9 +118,9 @@ __device__ __forceinline__ void cand_keys(const Ctx& c, uint32_t p, const Text8 
 // LDS-only decision: can a term of length >= 4 end here at all (fingerprint of the bytes in front of the window)?
 // Most flagged positions stop here without touching L2.
 __device__ __forceinline__ void cand_decide(const Ctx& c, Cand& k) {
-    const uint32_t f0 = c.fpt[scan2_fpt_cell(k.x, 0)], f1 = c.fpt[scan2_fpt_cell(k.x, 1)];
-    const uint32_t xm = scan2_fpt_xmix(k.x);
-    k.go_long = ((int)scan2_fpt_pass(f0, xm, k.tw) | (int)scan2_fpt_pass(f1, xm, k.tw)) != 0;
+    const uint32_t b1n = (k.tw >> 24) & 0xDFu;
+    const uint32_t cx = c.fpt[scan2_fpt_xcell(k.x)], cg0 = c.fpt[scan2_fpt_gcell(k.x, b1n, 0)], cg1 = c.fpt[scan2_fpt_gcell(k.x, b1n, 1)];
+    k.go_long = scan2_fpt_pass(cx, cg0, cg1, scan2_fpt_xmix(k.x), k.tw);
     if (c.P.dbg & 12) {         // timing studies (wrong results): 4 = no bucket-table access, 8 = no short-term records
         if (c.P.dbg & 4) k.go_long = false;
         if (c.P.dbg & 8) k.sid = 0;

@@ -113,9 +113,6 @@ void build_scan2_tables(const AcTables& ac, Scan2Tables& t) {
         return r;
     };
     t.fpt.assign(kScan2FptSize, 0);
-    struct FpItem { uint32_t key; uint8_t val[2]; uint32_t n; };
-    std::vector<FpItem> fp_items;
-    std::vector<uint32_t> homeless;
     std::vector<Scan2Slot> items;        // one per key: the term itself, or the header of a multi-term bucket
     for (auto& kv : buckets) {
         auto& v = kv.second;
@@ -128,18 +125,6 @@ void build_scan2_tables(const AcTables& ac, Scan2Tables& t) {
         } else {
             items.push_back(Scan2Slot{key, kScan2Multi | (uint32_t)t.more.size(), (uint32_t)v.size(), {0, 0, 0, 0, 0}});
             for (const Ent& e : v) t.more.push_back(make_slot(key, e));
-        }
-        // fingerprint cells (cuckoo: two candidate cells per key).  A one-term bucket owns one cell; a two-term bucket
-        // needs both of its cells (one fingerprint each); larger buckets pass everything.
-        fp_items.push_back(FpItem{key, {0, 0}, (uint32_t)std::min<size_t>(v.size(), 3)});
-        for (size_t i = 0; i < v.size() && i < 2; i++) {
-            // front bytes as a text load would see them: f_lo = term[L-8..L-4)
-            const std::string& s = ac.terms[v[i].term_id];
-            const int L = (int)s.size();
-            uint32_t f_lo = 0;
-            for (int k = 0; k < 4; k++)
-                if (L - 8 + k >= 0) f_lo |= (uint32_t)(uint8_t)s[L - 8 + k] << (8 * k);
-            fp_items.back().val[i] = (uint8_t)scan2_fpt_byte(scan2_fpt_code((uint32_t)L), scan2_fpt_xmix(key), f_lo);
         }
     }
     {
@@ -166,43 +151,67 @@ void build_scan2_tables(const AcTables& ac, Scan2Tables& t) {
             if (ok) break;       // else: a larger table (two keys sharing both slots with a third cannot happen twice)
         }
     }
+    // ---- fingerprint table: one cell per term (gft_kernels.hpp) ---------------------------------------------------------
     {
-        std::vector<uint32_t> owner(kScan2FptSize, 0);
-        std::vector<uint8_t> pinned(kScan2FptSize, 0);     // cells of two-term buckets cannot be displaced
-        // two-term buckets first (they have no freedom), then the one-term buckets by random-walk cuckoo
-        for (const FpItem& it : fp_items) {
-            const uint32_t c0 = scan2_fpt_cell(it.key, 0), c1 = scan2_fpt_cell(it.key, 1);
-            if (it.n >= 3 || (it.n == 2 && c0 == c1)) { homeless.push_back(it.key); continue; }
-            if (it.n != 2) continue;
-            if (t.fpt[c0] == 0 && t.fpt[c1] == 0) {
-                t.fpt[c0] = it.val[0]; t.fpt[c1] = it.val[1];
-                pinned[c0] = pinned[c1] = 1;
-            } else {
-                homeless.push_back(it.key);
+        struct GItem { uint32_t x, b1n; uint8_t val; };
+        std::vector<uint32_t> ambiguous;                       // cells that must pass everything
+        std::vector<uint8_t> pinned(kScan2FptSize, 0);
+        std::map<std::pair<uint32_t, uint32_t>, std::vector<uint8_t>> groups;   // (key, b1n) -> distinct cell bytes
+        for (const auto& kv : buckets) {
+            const uint32_t x = kv.first, xm = scan2_fpt_xmix(x);
+            for (const Ent& e : kv.second) {
+                const std::string& s = ac.terms[e.term_id];
+                const int L = (int)s.size();
+                if (L == 4) {
+                    const uint32_t c = scan2_fpt_xcell(x);
+                    const uint8_t v = (uint8_t)scan2_fpt_xbyte(xm);
+                    if (t.fpt[c] != 0 && t.fpt[c] != v) ambiguous.push_back(c);
+                    t.fpt[c] = v;
+                    pinned[c] = 1;
+                    continue;
+                }
+                uint32_t tw = 0;                               // text[p-7..p-4] under this term
+                for (int k = 0; k < 4; k++)
+                    if (L - 8 + k >= 0) tw |= (uint32_t)(uint8_t)s[L - 8 + k] << (8 * k);
+                const uint32_t twn = tw & 0xDFDFDFDFu;
+                const uint32_t code = (uint32_t)std::min(L - 5, 3) + 1;
+                auto& g = groups[{x, twn >> 24}];
+                const uint8_t v = (uint8_t)scan2_fpt_gbyte(code, xm, twn);
+                if (std::find(g.begin(), g.end(), v) == g.end()) g.push_back(v);
             }
         }
+        std::vector<GItem> singles;
+        for (const auto& kv : groups) {
+            const uint32_t x = kv.first.first, b1n = kv.first.second;
+            const uint32_t c0 = scan2_fpt_gcell(x, b1n, 0), c1 = scan2_fpt_gcell(x, b1n, 1);
+            if (kv.second.size() == 1) { singles.push_back(GItem{x, b1n, kv.second[0]}); continue; }
+            if (kv.second.size() == 2 && c0 != c1 && t.fpt[c0] == 0 && t.fpt[c1] == 0) {
+                t.fpt[c0] = kv.second[0]; t.fpt[c1] = kv.second[1];
+                pinned[c0] = pinned[c1] = 1;
+            } else {
+                ambiguous.push_back(c0);
+            }
+        }
+        std::vector<GItem> owner(kScan2FptSize, GItem{0, 0, 0});
         uint32_t rng = 0x12345u;
-        for (const FpItem& it : fp_items) {
-            if (it.n != 1) continue;
-            uint32_t ck = it.key;
-            uint8_t cv = it.val[0];
+        for (GItem cur : singles) {
             bool placed = false;
             for (int kick = 0; kick < 500 && !placed; kick++) {
-                const uint32_t c0 = scan2_fpt_cell(ck, 0), c1 = scan2_fpt_cell(ck, 1);
-                if (t.fpt[c0] == 0) { t.fpt[c0] = cv; owner[c0] = ck; placed = true; break; }
-                if (t.fpt[c1] == 0) { t.fpt[c1] = cv; owner[c1] = ck; placed = true; break; }
+                const uint32_t c0 = scan2_fpt_gcell(cur.x, cur.b1n, 0), c1 = scan2_fpt_gcell(cur.x, cur.b1n, 1);
+                if (t.fpt[c0] == 0) { t.fpt[c0] = cur.val; owner[c0] = cur; placed = true; break; }
+                if (t.fpt[c1] == 0) { t.fpt[c1] = cur.val; owner[c1] = cur; placed = true; break; }
                 rng = rng * 1664525u + 1013904223u;
                 uint32_t victim = (rng >> 16) & 1 ? c1 : c0;
                 if (pinned[victim]) victim = victim == c0 ? c1 : c0;
-                if (pinned[victim]) break;                      // both cells belong to two-term buckets
-                std::swap(cv, t.fpt[victim]);
-                std::swap(ck, owner[victim]);
+                if (pinned[victim]) break;                      // both cells are taken by items that cannot move
+                std::swap(cur, owner[victim]);                  // the newcomer moves in, the old tenant looks on
+                t.fpt[victim] = owner[victim].val;
             }
-            if (!placed) homeless.push_back(ck);
+            if (!placed) ambiguous.push_back(scan2_fpt_gcell(cur.x, cur.b1n, 0));
         }
+        // cells that pass everything are set last: whatever lived there passes too
+        for (uint32_t c : ambiguous) t.fpt[c] = kScan2FptAmbiguous;
     }
-    // keys the cuckoo walk could not place: their first cell passes everything (set last, nothing moves any more)
-    for (uint32_t k : homeless) t.fpt[scan2_fpt_cell(k, 0)] = kScan2FptAmbiguous;
     t.term_blob.insert(t.term_blob.end(), 8, 0);
     t.term_off.push_back((uint32_t)t.term_blob.size());
     if (t.more.empty()) t.more.push_back(Scan2Slot{kScan2EmptyKey, 0, 0, {0, 0, 0, 0, 0}});

@@ -567,7 +567,9 @@ int gft_engine_create(gft_engine** out, int device) {
         e->lds_max = std::max<size_t>(prop.sharedMemPerBlock, (size_t)std::max(optin, 0));
         if (std::string(prop.gcnArchName).find("gfx950") != std::string::npos) e->lds_max = std::max<size_t>(e->lds_max, 160 * 1024);
     }
-    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) == hipSuccess) e->own_stream = true;
+    // a blocking stream: ordered with the legacy default stream, which is where a caller that never names a stream
+    // (torch's default stream, plain hipMemcpy) produces the device buffers it hands to *_device entry points
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamDefault) == hipSuccess) e->own_stream = true;
     else e->stream = nullptr;
     *out = e;
     return GFT_OK;
@@ -608,7 +610,7 @@ int gft_set_stream(gft_engine* e, void* hip_stream) {
     e->own_stream = false;
     e->stream = (hipStream_t)hip_stream;
     if (!hip_stream) {
-        HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking), "stream create");
+        HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamDefault), "stream create");
         e->own_stream = true;
     }
     return GFT_OK;

@@ -50,7 +50,10 @@ typedef struct gft_engine gft_engine;
 int gft_engine_create(gft_engine** out, int device);
 void gft_engine_destroy(gft_engine* e);
 const char* gft_last_error(const gft_engine* e);
-/* Run all work of this engine on an existing HIP stream (hipStream_t passed as void*); NULL = own stream. */
+/* Run all work of this engine on an existing HIP stream (hipStream_t passed as void*).  NULL = a stream of the
+ * engine's own, created blocking, i.e. ordered with the legacy default stream: device buffers produced there (torch's
+ * default stream, plain hipMemcpy) can be handed to the *_device entry points without an explicit synchronisation.
+ * Every entry point returns after its work has completed. */
 int gft_set_stream(gft_engine* e, void* hip_stream);
 
 /* ---- SubstringEngine.BuildEngine (finder/substringEngine.go:98-106) ----------------------------------- */

@@ -575,19 +575,29 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
                     // (kStageAWays candidates per lane and trip: their loads and table lookups are in flight together;
                     // lanes past the end of the list work on a copy of entry 0 and stay silent)
                     uint32_t ns = 0;
+                    // (the list entries and text of trip t + 1 are fetched while trip t is worked on)
+                    bool n_on[kStageAWays];
+                    uint32_t n_rel[kStageAWays];
+                    Text8 n_tx[kStageAWays];
+                    auto fetch = [&](uint32_t i0) {
+#pragma unroll
+                        for (int q = 0; q < kStageAWays; q++) {
+                            const uint32_t i = i0 + 64 * q + lane;
+                            n_on[q] = i < ptotal;
+                            n_rel[q] = cand[n_on[q] ? i : 0];
+                        }
+#pragma unroll
+                        for (int q = 0; q < kStageAWays; q++) n_tx[q] = cand_load(c, un.lo + n_rel[q]);
+                    };
+                    fetch(0);
                     for (uint32_t i0 = 0; i0 < ptotal; i0 += 64 * kStageAWays) {
                         bool on[kStageAWays];
                         uint32_t rel[kStageAWays];
                         Text8 tx[kStageAWays];
                         Cand k[kStageAWays];
 #pragma unroll
-                        for (int q = 0; q < kStageAWays; q++) {
-                            const uint32_t i = i0 + 64 * q + lane;
-                            on[q] = i < ptotal;
-                            rel[q] = cand[on[q] ? i : 0];
-                        }
-#pragma unroll
-                        for (int q = 0; q < kStageAWays; q++) tx[q] = cand_load(c, un.lo + rel[q]);
+                        for (int q = 0; q < kStageAWays; q++) { on[q] = n_on[q]; rel[q] = n_rel[q]; tx[q] = n_tx[q]; }
+                        if (i0 + 64 * kStageAWays < ptotal) fetch(i0 + 64 * kStageAWays);
 #pragma unroll
                         for (int q = 0; q < kStageAWays; q++) cand_keys(c, un.lo + rel[q], tx[q], k[q]);
 #pragma unroll

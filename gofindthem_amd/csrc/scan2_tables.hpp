@@ -6,13 +6,14 @@
 //              here".  LDS, probed once per text byte, no dependent chain between bytes.
 //   * short3   byte per 3-class window: which terms of length <= 3 end here (id of a small record holding up to three
 //              terms, longest first).  LDS; answers the bulk of all matches without leaving the CU.
-//   * fpt      byte per hashed window key: for windows that end exactly one term of length >= 4, how many bytes in
-//              front of the window that term has and a 5-bit fingerprint of them.  LDS; rejects most positions where
-//              the window matches but the bytes in front do not, before any L2 access.
+//   * fpt      byte per TERM of length >= 4 (cuckoo placement), keyed by (window key, byte in front of the window):
+//              how many more front bytes the cell covers and a 5-bit fingerprint of them; terms of length exactly 4 are
+//              keyed by the window alone.  LDS; rejects most positions where the window matches but the bytes in front do
+//              not, before any L2 access -- also for windows shared by several terms.
 //   * slots    window -> the terms of length >= 4 that end with exactly that window, longest first == the reference's
-//              emission order (node, then its dictionary-suffix chain).  L2; a term longer than the window is confirmed
-//              by comparing the bytes in front of it, so every match is found from its own END position and no failure
-//              links are needed.
+//              emission order (node, then its dictionary-suffix chain).  L2, 32-byte slots, two-choice placement; a slot
+//              carries the term's bytes in front of the window (up to 24-byte terms inline), so every match is found from
+//              its own END position and no failure links are needed.
 // Same inputs as NewStringMatcher (finder/substringEngine.go:103); same outputs as MatchAll (:111-116).
 #pragma once
 #include <cstdint>

@@ -395,7 +395,7 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         P.shorts_packed = e->d_s2_shorts_packed.as<uint32_t>(); P.shorts_words = (uint32_t)std::min<size_t>(e->s2.shorts_packed.size(), 255 * 3);
         P.short3_big = e->s2.short3_big.empty() ? nullptr : e->d_s2_short3_big.as<uint32_t>();
         P.cand_cap = e->scan2_cand_cap;
-        P.slots = e->d_s2_slots.as<Scan2Slot>(); P.slot_shift = e->s2.slot_shift;
+        P.slots = e->d_s2_slots.as<Scan2Slot>(); P.slot_shift = e->s2.slot_shift; P.slot_seed = e->s2.slot_seed;
         P.more = e->d_s2_more.as<Scan2Slot>();
         P.fold = (flags & GFT_FOLD_ASCII) ? 1 : 0;
         P.cls = P.fold ? e->d_s2_cls_fold.as<uint8_t>() : e->d_s2_cls.as<uint8_t>();

@@ -150,9 +150,10 @@ GFT_HD inline uint32_t scan2_mul24c(uint32_t a) {
     return (uint32_t)((uint64_t)(a & 0xFFFFFFu) * (uint64_t)(C & 0xFFFFFFu));
 #endif
 }
-// the two candidate slots of a window key (table of 2^lg slots, shift = 32 - lg)
-GFT_HD inline uint32_t scan2_slot_hash(uint32_t x, int which, uint32_t shift) {
-    const uint32_t xf = x ^ (x >> 20);             // keys beyond 24 bits (hashed alphabets) keep their top bits in play
+// the two candidate slots of a window key (table of 2^lg slots, shift = 32 - lg).  `seed` is chosen by the table builder:
+// a handful of structured keys can share both slots with others; another seed separates them without growing the table
+GFT_HD inline uint32_t scan2_slot_hash(uint32_t x, int which, uint32_t shift, uint32_t seed) {
+    const uint32_t xf = (x ^ (x >> 20)) + seed;    // keys beyond 24 bits (hashed alphabets) keep their top bits in play
     return (which ? scan2_mul24c<0x85EBCBu>(xf) : scan2_mul24c<0x9E3779u>(xf)) >> shift;
 }
 GFT_HD inline uint32_t scan2_fpt_index(uint32_t h) {
@@ -197,7 +198,7 @@ struct Scan2Params {
     uint32_t cand_cap;           // entries of a wave's LDS candidate list (scan2_plan)
     const uint8_t* fpt;          // [kScan2FptSize], copied to LDS
     const Scan2Slot* slots;      // 2^lg slots, slot_shift = 32 - lg
-    uint32_t slot_shift;
+    uint32_t slot_shift, slot_seed;
     const Scan2Slot* more;
     const uint8_t* cls;          // [256] byte -> class (the folded table when GFT_FOLD_ASCII)
     const uint8_t* term_blob;

@@ -248,8 +248,8 @@ __device__ __forceinline__ void cand_finish(const Ctx& c, const Cand& k, uint32_
     };
     // ---- terms of length >= 4, longest first ---------------------------------------------------------------------
     if (k.go_long) {
-        const Slot s0 = slot_load(&P.slots[scan2_slot_hash(k.x, 0, P.slot_shift)]);
-        const Slot s1 = slot_load(&P.slots[scan2_slot_hash(k.x, 1, P.slot_shift)]);
+        const Slot s0 = slot_load(&P.slots[scan2_slot_hash(k.x, 0, P.slot_shift, P.slot_seed)]);
+        const Slot s1 = slot_load(&P.slots[scan2_slot_hash(k.x, 1, P.slot_shift, P.slot_seed)]);
         Front t = front_load(c, p, k.tw);
         if (P.fold) front_fold(t);
         Slot e;
@@ -636,8 +636,8 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
                         const Front fr = front_load(c, p, t8.tw);
                         Cand k;
                         cand_keys(c, p, t8, k);
-                        const Slot s0 = slot_load(&P.slots[scan2_slot_hash(k.x, 0, P.slot_shift)]);
-                        const Slot s1 = slot_load(&P.slots[scan2_slot_hash(k.x, 1, P.slot_shift)]);
+                        const Slot s0 = slot_load(&P.slots[scan2_slot_hash(k.x, 0, P.slot_shift, P.slot_seed)]);
+                        const Slot s1 = slot_load(&P.slots[scan2_slot_hash(k.x, 1, P.slot_shift, P.slot_seed)]);
                         finish_long(c, on, rel, k, s0, s1, fr, fifo, nf, dfr);
                     }
                     if (dfr.n) drain_deferred(c, un.lo, fifo, nf, dfr);

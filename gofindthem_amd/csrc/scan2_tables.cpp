@@ -130,9 +130,12 @@ void build_scan2_tables(const AcTables& ac, Scan2Tables& t) {
     {
         uint32_t lg = 10;
         while ((1ull << lg) < 2 * items.size()) lg++;        // load <= 0.5 (two choices place that easily)
-        for (;; lg++) {
+        for (uint32_t attempt = 0;; attempt++) {
+            // eight seeds per size, then the next size
+            if (attempt && attempt % 8 == 0) lg++;
             if (lg > 28) { t.why_not = "bucket table too large"; return; }
             t.slot_shift = 32 - lg;
+            t.slot_seed = (attempt % 8) * 0x9E37u;
             t.slots.assign((size_t)1 << lg, Scan2Slot{kScan2EmptyKey, 0, 0, {0, 0, 0, 0, 0}});
             uint32_t rng = 0x2545F491u;
             bool ok = true;
@@ -140,7 +143,8 @@ void build_scan2_tables(const AcTables& ac, Scan2Tables& t) {
                 Scan2Slot cur = it;
                 bool placed = false;
                 for (int kick = 0; kick < 1000 && !placed; kick++) {
-                    const uint32_t h0 = scan2_slot_hash(cur.key, 0, t.slot_shift), h1 = scan2_slot_hash(cur.key, 1, t.slot_shift);
+                    const uint32_t h0 = scan2_slot_hash(cur.key, 0, t.slot_shift, t.slot_seed),
+                                   h1 = scan2_slot_hash(cur.key, 1, t.slot_shift, t.slot_seed);
                     if (t.slots[h0].key == kScan2EmptyKey) { t.slots[h0] = cur; placed = true; break; }
                     if (t.slots[h1].key == kScan2EmptyKey) { t.slots[h1] = cur; placed = true; break; }
                     rng = rng * 1664525u + 1013904223u;
@@ -148,7 +152,7 @@ void build_scan2_tables(const AcTables& ac, Scan2Tables& t) {
                 }
                 if (!placed) { ok = false; break; }
             }
-            if (ok) break;       // else: a larger table (two keys sharing both slots with a third cannot happen twice)
+            if (ok) break;
         }
     }
     // ---- fingerprint table: one cell per term (gft_kernels.hpp) ---------------------------------------------------------

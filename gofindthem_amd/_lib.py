@@ -30,6 +30,8 @@ SYMBOLS = {
     "gft_last_error": (C.c_char_p, [_vp]),
     "gft_set_stream": (_i, [_vp, _vp]),
     "gft_build": (_i, [_vp, _vp, _vp, _u32, _u32]),
+    "gft_export_tables": (_i, [_vp, _vp, _u64, C.POINTER(_u64)]),
+    "gft_import_tables": (_i, [_vp, C.c_char_p, _u64]),
     "gft_n_terms": (_u32, [_vp]),
     "gft_n_states": (_u32, [_vp]),
     "gft_term": (_i, [_vp, _u32, C.POINTER(_vp), C.POINTER(_u32)]),

@@ -541,6 +541,33 @@ int solve_pipeline(gft_engine* e, uint64_t n_docs, const gft_extra_matches* d_ex
 
 }  // namespace
 
+// ---- compiled tables as one blob (BuildEngine for a large dictionary is paid once) -----------------
+namespace {
+constexpr uint32_t kTablesMagic = 0x54544647u;   // "GFTT"
+constexpr uint32_t kTablesVersion = 3;           // bump when a table layout or a hash function changes
+
+struct Writer {
+    std::vector<uint8_t> b;
+    void raw(const void* p, size_t n) { const uint8_t* q = (const uint8_t*)p; b.insert(b.end(), q, q + n); }
+    void u32(uint32_t v) { raw(&v, 4); }
+    void u64(uint64_t v) { raw(&v, 8); }
+    template <class T> void vec(const std::vector<T>& v) { u64(v.size()); if (!v.empty()) raw(v.data(), v.size() * sizeof(T)); }
+};
+struct Reader {
+    const uint8_t* p; uint64_t n, i = 0; bool ok = true;
+    bool raw(void* d, size_t k) { if (!ok || k > n - i) { ok = false; return false; } memcpy(d, p + i, k); i += k; return true; }
+    uint32_t u32() { uint32_t v = 0; raw(&v, 4); return v; }
+    uint64_t u64() { uint64_t v = 0; raw(&v, 8); return v; }
+    template <class T> void vec(std::vector<T>& v) {
+        const uint64_t k = u64();
+        if (!ok || k > (n - i) / sizeof(T)) { ok = false; return; }
+        v.resize((size_t)k);
+        if (k) raw(v.data(), (size_t)k * sizeof(T));
+    }
+};
+}  // namespace
+
+
 extern "C" {
 
 int gft_engine_create(gft_engine** out, int device) {
@@ -616,17 +643,8 @@ int gft_set_stream(gft_engine* e, void* hip_stream) {
     return GFT_OK;
 }
 
-int gft_build(gft_engine* e, const uint8_t* terms_blob, const uint64_t* term_off, uint32_t n_terms, uint32_t flags) {
-    if (!e || (n_terms && (!terms_blob || !term_off))) return e ? fail(e, GFT_E_INVALID, "null argument") : GFT_E_INVALID;
-    if (e->device < 0) return fail(e, GFT_E_HIP, "no HIP device available");
-    std::vector<std::string> terms;
-    terms.reserve(n_terms);
-    for (uint32_t i = 0; i < n_terms; i++) {
-        if (term_off[i + 1] < term_off[i]) return fail(e, GFT_E_INVALID, "term_off is not ascending");
-        terms.emplace_back((const char*)terms_blob + term_off[i], (size_t)(term_off[i + 1] - term_off[i]));
-    }
-    e->built = false;
-    build_ac_tables(std::move(terms), e->tab);
+// e->tab / e->s2 hold compiled tables (from gft_build or gft_import_tables): check them against the device, upload
+static int install_tables(gft_engine* e, uint32_t flags) {
     if (e->tab.max_term_len + 1024 > kTextBuf)
         return fail(e, GFT_E_UNSUPPORTED, "keyword longer than " + std::to_string(kTextBuf - 1024) + " bytes");
     if (e->tab.n_states >= 0x7FFFFFFFu) return fail(e, GFT_E_UNSUPPORTED, "automaton too large");
@@ -646,8 +664,7 @@ int gft_build(gft_engine* e, const uint8_t* terms_blob, const uint64_t* term_off
     if ((rc = upload(e, e->d_out_term, e->tab.out_term, "table upload"))) return rc;
     if ((rc = upload(e, e->d_out_link, e->tab.out_link, "table upload"))) return rc;
     if ((rc = upload(e, e->d_term_len, e->tab.term_len, "table upload"))) return rc;
-    // suffix-window tables (the fast path); GFT_SCAN_KERNEL=dfa forces the general two-tier DFA kernel
-    build_scan2_tables(e->tab, e->s2);
+    // GFT_SCAN_KERNEL=dfa forces the general two-tier DFA kernel
     const char* force = getenv("GFT_SCAN_KERNEL");
     const bool k2_fits = e->s2.supported && scan2_plan((uint32_t)e->s2.filter.size(), (uint32_t)e->s2.short3.size(),
                                                         (uint32_t)std::min<size_t>(e->s2.shorts_packed.size(), 255 * 3), e->lds_max - 512,
@@ -688,6 +705,22 @@ int gft_build(gft_engine* e, const uint8_t* terms_blob, const uint64_t* term_off
     return GFT_OK;
 }
 
+
+int gft_build(gft_engine* e, const uint8_t* terms_blob, const uint64_t* term_off, uint32_t n_terms, uint32_t flags) {
+    if (!e || (n_terms && (!terms_blob || !term_off))) return e ? fail(e, GFT_E_INVALID, "null argument") : GFT_E_INVALID;
+    if (e->device < 0) return fail(e, GFT_E_HIP, "no HIP device available");
+    std::vector<std::string> terms;
+    terms.reserve(n_terms);
+    for (uint32_t i = 0; i < n_terms; i++) {
+        if (term_off[i + 1] < term_off[i]) return fail(e, GFT_E_INVALID, "term_off is not ascending");
+        terms.emplace_back((const char*)terms_blob + term_off[i], (size_t)(term_off[i + 1] - term_off[i]));
+    }
+    e->built = false;
+    build_ac_tables(std::move(terms), e->tab);
+    build_scan2_tables(e->tab, e->s2);     // suffix-window tables (the fast path)
+    return install_tables(e, flags);
+}
+
 uint32_t gft_n_terms(const gft_engine* e) { return e ? (uint32_t)e->tab.terms.size() : 0; }
 uint32_t gft_n_states(const gft_engine* e) { return e ? e->tab.n_states : 0; }
 uint32_t gft_n_exprs(const gft_engine* e) { return e ? e->n_exprs : 0; }
@@ -706,6 +739,77 @@ int64_t gft_term_id(const gft_engine* e, const uint8_t* term, uint32_t len) {
     auto it = std::lower_bound(e->tab.terms.begin(), e->tab.terms.end(), s);
     if (it == e->tab.terms.end() || *it != s) return -1;
     return (int64_t)(it - e->tab.terms.begin());
+}
+
+
+int gft_export_tables(const gft_engine* e, uint8_t* out, uint64_t cap, uint64_t* needed) {
+    if (!e) return GFT_E_INVALID;
+    if (!e->built) return fail(e, GFT_E_NOT_BUILT, "gft_build has not been called");
+    Writer w;
+    w.u32(kTablesMagic); w.u32(kTablesVersion); w.u32((uint32_t)sizeof(Scan2Slot)); w.u32(kScan2FptSize); w.u32(e->build_flags);
+    const AcTables& a = e->tab;
+    w.u64(a.terms.size());
+    for (const auto& t : a.terms) { w.u64(t.size()); w.raw(t.data(), t.size()); }
+    w.u32(a.n_classes); w.raw(a.byte_class, 256); w.u32(a.n_states); w.u32(a.max_term_len);
+    w.vec(a.delta); w.vec(a.out_term); w.vec(a.out_link); w.vec(a.term_len); w.vec(a.depth); w.vec(a.fail);
+    w.vec(a.child_begin); w.vec(a.in_class);
+    const Scan2Tables& t = e->s2;
+    w.u32(t.supported ? 1 : 0); w.u32(t.kp); w.u32(t.pad_class); w.u32(t.hashed ? 1 : 0); w.u32(t.filter_bits); w.u32(t.hash_shift);
+    w.vec(t.filter); w.vec(t.short3); w.vec(t.shorts); w.vec(t.short3_big); w.vec(t.shorts_packed); w.vec(t.fpt);
+    w.u32(t.slot_shift); w.u32(t.slot_seed); w.vec(t.slots); w.vec(t.more);
+    w.raw(t.cls, 256); w.raw(t.cls_fold, 256); w.vec(t.term_blob); w.vec(t.term_off); w.u64(t.n_keys);
+    uint64_t sum = 1469598103934665603ull;          // FNV-1a over everything before it
+    for (uint8_t c : w.b) { sum ^= c; sum *= 1099511628211ull; }
+    w.u64(sum);
+    if (needed) *needed = w.b.size();
+    if (!out || cap < w.b.size()) return GFT_E_INVALID;
+    memcpy(out, w.b.data(), w.b.size());
+    return GFT_OK;
+}
+
+int gft_import_tables(gft_engine* e, const uint8_t* blob, uint64_t len) {
+    if (!e || !blob) return e ? fail(e, GFT_E_INVALID, "null argument") : GFT_E_INVALID;
+    if (len < 28) return fail(e, GFT_E_INVALID, "table blob too short");
+    uint64_t sum = 1469598103934665603ull, stored;
+    for (uint64_t i = 0; i + 8 < len; i++) { sum ^= blob[i]; sum *= 1099511628211ull; }
+    memcpy(&stored, blob + len - 8, 8);
+    if (sum != stored) return fail(e, GFT_E_INVALID, "table blob is corrupt (checksum)");
+    Reader r{blob, len - 8};
+    if (r.u32() != kTablesMagic) return fail(e, GFT_E_INVALID, "not a gft table blob");
+    if (r.u32() != kTablesVersion || r.u32() != sizeof(Scan2Slot) || r.u32() != kScan2FptSize)
+        return fail(e, GFT_E_UNSUPPORTED, "table blob was written by another library version");
+    const uint32_t flags = r.u32();
+    AcTables a;
+    const uint64_t nt = r.u64();
+    if (!r.ok || nt > len) return fail(e, GFT_E_INVALID, "table blob is truncated");
+    a.terms.resize((size_t)nt);
+    for (auto& t : a.terms) {
+        const uint64_t k = r.u64();
+        if (!r.ok || k > r.n - r.i) return fail(e, GFT_E_INVALID, "table blob is truncated");
+        t.assign((const char*)r.p + r.i, (size_t)k);
+        r.i += k;
+    }
+    a.n_classes = r.u32(); r.raw(a.byte_class, 256); a.n_states = r.u32(); a.max_term_len = r.u32();
+    r.vec(a.delta); r.vec(a.out_term); r.vec(a.out_link); r.vec(a.term_len); r.vec(a.depth); r.vec(a.fail);
+    r.vec(a.child_begin); r.vec(a.in_class);
+    Scan2Tables t;
+    t.supported = r.u32() != 0; t.kp = r.u32(); t.pad_class = r.u32(); t.hashed = r.u32() != 0; t.filter_bits = r.u32(); t.hash_shift = r.u32();
+    r.vec(t.filter); r.vec(t.short3); r.vec(t.shorts); r.vec(t.short3_big); r.vec(t.shorts_packed); r.vec(t.fpt);
+    t.slot_shift = r.u32(); t.slot_seed = r.u32(); r.vec(t.slots); r.vec(t.more);
+    r.raw(t.cls, 256); r.raw(t.cls_fold, 256); r.vec(t.term_blob); r.vec(t.term_off); t.n_keys = r.u64();
+    if (!r.ok || r.i != r.n) return fail(e, GFT_E_INVALID, "table blob is truncated");
+    // shape checks the kernels rely on
+    if (a.n_classes == 0 || a.n_classes > 256 || a.delta.size() != (size_t)a.n_states * a.n_classes || a.out_term.size() != a.n_states ||
+        a.out_link.size() != a.n_states || a.term_len.size() != a.terms.size() ||
+        (t.supported && (t.fpt.size() != kScan2FptSize || t.slots.size() != ((size_t)1 << (32 - t.slot_shift)) || t.term_off.size() != a.terms.size() + 1 ||
+                         t.filter.size() * 32 != t.filter_bits)))
+        return fail(e, GFT_E_INVALID, "table blob is inconsistent");
+    if (!t.supported) t.why_not = "not supported by the suffix-window kernel (imported tables)";
+    if (e->device < 0) return fail(e, GFT_E_HIP, "no HIP device available");
+    e->built = false;
+    e->tab = std::move(a);
+    e->s2 = std::move(t);
+    return install_tables(e, flags);
 }
 
 int gft_scan_device(gft_engine* e, const uint8_t* d_text_blob, const uint64_t* d_doc_off, uint64_t n_docs,

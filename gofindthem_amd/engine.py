@@ -59,6 +59,20 @@ class Engine:
         blob, off = pack(terms)
         self._check(self._L.gft_build(self._h, _p(blob), _p(off), len(terms), 1 if pos_end else 0))
 
+    def export_tables(self):
+        """the compiled tables of the current dictionary as bytes (gft_export_tables)"""
+        need = C.c_uint64(0)
+        self._L.gft_export_tables(self._h, None, 0, C.byref(need))
+        if not need.value:
+            self._check(_lib.GFT_E_NOT_BUILT)
+        buf = (C.c_uint8 * need.value)()
+        self._check(self._L.gft_export_tables(self._h, C.cast(buf, C.c_void_p), need.value, C.byref(need)))
+        return bytes(buf)
+
+    def import_tables(self, blob):
+        """install tables written by export_tables: same effect as the build() that produced them"""
+        self._check(self._L.gft_import_tables(self._h, blob, len(blob)))
+
     @property
     def n_terms(self):
         return self._L.gft_n_terms(self._h)

@@ -67,6 +67,13 @@ int gft_term(const gft_engine* e, uint32_t term_id, const uint8_t** ptr, uint32_
 /* bytes of a term -> term_id, or -1 if it is not in the dictionary */
 int64_t gft_term_id(const gft_engine* e, const uint8_t* term, uint32_t len);
 
+/* Compiled tables of the current dictionary as one blob (compiling a 100 k-term dictionary costs
+ * ~0.6 s of host time; a blob is installed with a copy and an upload).  gft_export_tables writes into out (cap bytes) and
+ * the size into *needed (GFT_E_INVALID when cap is too small); gft_import_tables is equivalent to the gft_build call that
+ * produced the blob (same terms, ids and flags).  Blobs are tied to the library version that wrote them. */
+int gft_export_tables(const gft_engine* e, uint8_t* out, uint64_t cap, uint64_t* needed);
+int gft_import_tables(gft_engine* e, const uint8_t* blob, uint64_t len);
+
 /* ---- SubstringEngine.FindSubstrings (finder/substringEngine.go:110-119), batched ------------------------ */
 /* CSR result: matches of document d are [match_off[d], match_off[d+1]).  Buffers are library-owned and stay
  * valid until the next call on the same engine. */

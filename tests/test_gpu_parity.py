@@ -210,3 +210,33 @@ def test_deep_buckets_and_long_terms(eng):
     progs, extra = _programs(o, eng, exprs, True)
     eng.set_programs(progs)
     assert np.array_equal(eng.process(blob, off), o.process(blob, off))
+
+
+def test_table_export_import_roundtrip(eng, scan_kernel):
+    """compiled tables as a blob -- a second engine that imports it behaves like the one that built
+    them (same term ids, same matches, same expression results); damaged or foreign blobs are refused"""
+    from gofindthem_amd.engine import Engine, GftError
+    from gofindthem_amd.workload import Workload, make_expressions
+    w = Workload(2000)
+    terms = w.terms()
+    o = both(eng, terms)
+    blob = eng.export_tables()
+    assert len(blob) > 100_000
+    e2 = Engine()
+    try:
+        e2.import_tables(blob)
+        assert e2.terms() == eng.terms() and e2.n_states == eng.n_states
+        text, off = w.docs_host(0, 300)
+        assert_csr_equal(e2.scan(text, off, fold=True), o.scan(text, off, fold=True))
+        exprs = make_expressions(terms, 120, inord_fraction=0.4)
+        o.set_expressions(exprs, False)
+        progs, extra = _programs(o, e2, exprs, False)
+        e2.set_programs(progs)
+        assert np.array_equal(e2.process(text, off, fold=True), o.process(text, off, fold=True))
+        for bad in (blob[:-1], blob[:1000], b"GFTT" + blob[4:200], blob[:500] + bytes([blob[500] ^ 1]) + blob[501:], b""):
+            with pytest.raises(GftError):
+                e2.import_tables(bad)
+        # a refused blob leaves the engine as it was
+        assert_csr_equal(e2.scan(text, off, fold=True), o.scan(text, off, fold=True))
+    finally:
+        e2.close()

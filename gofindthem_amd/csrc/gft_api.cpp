@@ -391,7 +391,7 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         P.filter = e->d_s2_filter.as<uint32_t>(); P.filter_words = (uint32_t)e->s2.filter.size();
         P.hashed = e->s2.hashed ? 1 : 0; P.hash_shift = e->s2.hash_shift;
         P.short3 = e->d_s2_short3.as<uint8_t>(); P.short3_bytes = e->scan2_short3_bytes;
-        P.fpt = e->d_s2_fpt.as<uint8_t>();
+        P.fpt = e->d_s2_fpt.as<uint8_t>(); P.fpt_lg = e->s2.fpt_lg;
         P.shorts_packed = e->d_s2_shorts_packed.as<uint32_t>(); P.shorts_words = (uint32_t)std::min<size_t>(e->s2.shorts_packed.size(), 255 * 3);
         P.short3_big = e->s2.short3_big.empty() ? nullptr : e->d_s2_short3_big.as<uint32_t>();
         P.cand_cap = e->scan2_cand_cap;
@@ -544,7 +544,7 @@ int solve_pipeline(gft_engine* e, uint64_t n_docs, const gft_extra_matches* d_ex
 // ---- compiled tables as one blob (BuildEngine for a large dictionary is paid once) -----------------
 namespace {
 constexpr uint32_t kTablesMagic = 0x54544647u;   // "GFTT"
-constexpr uint32_t kTablesVersion = 3;           // bump when a table layout or a hash function changes
+constexpr uint32_t kTablesVersion = 4;           // bump when a table layout or a hash function changes
 
 struct Writer {
     std::vector<uint8_t> b;
@@ -667,7 +667,8 @@ static int install_tables(gft_engine* e, uint32_t flags) {
     // GFT_SCAN_KERNEL=dfa forces the general two-tier DFA kernel
     const char* force = getenv("GFT_SCAN_KERNEL");
     const bool k2_fits = e->s2.supported && scan2_plan((uint32_t)e->s2.filter.size(), (uint32_t)e->s2.short3.size(),
-                                                        (uint32_t)std::min<size_t>(e->s2.shorts_packed.size(), 255 * 3), e->lds_max - 512,
+                                                        (uint32_t)std::min<size_t>(e->s2.shorts_packed.size(), 255 * 3),
+                                                        e->s2.fpt_lg ? 0u : kScan2FptSize, e->lds_max - 512,
                                                         &e->scan2_k2_waves, &e->scan2_cand_cap);
     e->use_scan2 = k2_fits && !(force && std::string(force) == "dfa");
     if (e->use_scan2 && getenv("GFT_SCAN_DEBUG")) {
@@ -675,7 +676,7 @@ static int install_tables(gft_engine* e, uint32_t flags) {
         for (uint8_t b : e->s2.fpt) { n_ff += b == 0xFF; n_used += b != 0; }
         for (const auto& s : e->s2.slots) { n_slots += s.key != kScan2EmptyKey; n_simple += s.key != kScan2EmptyKey && !(s.info & kScan2Multi); }
         fprintf(stderr, "[gft build debug] kp=%u keys=%zu (simple %zu) slots=%zu fpt: used=%zu always-pass=%zu of %u; shorts=%zu filter=%s %u bits waves=%u\n",
-                e->s2.kp, n_slots, n_simple, e->s2.slots.size(), n_used, n_ff, kScan2FptSize, e->s2.shorts.size() - 1,
+                e->s2.kp, n_slots, n_simple, e->s2.slots.size(), n_used, n_ff, (unsigned)e->s2.fpt.size(), e->s2.shorts.size() - 1,
                 e->s2.hashed ? "hashed" : "direct", e->s2.filter_bits, e->scan2_k2_waves);
         fprintf(stderr, "[gft build debug] candidate list capacity %u per wave\n", e->scan2_cand_cap);
     }
@@ -755,7 +756,7 @@ int gft_export_tables(const gft_engine* e, uint8_t* out, uint64_t cap, uint64_t*
     w.vec(a.child_begin); w.vec(a.in_class);
     const Scan2Tables& t = e->s2;
     w.u32(t.supported ? 1 : 0); w.u32(t.kp); w.u32(t.pad_class); w.u32(t.hashed ? 1 : 0); w.u32(t.filter_bits); w.u32(t.hash_shift);
-    w.vec(t.filter); w.vec(t.short3); w.vec(t.shorts); w.vec(t.short3_big); w.vec(t.shorts_packed); w.vec(t.fpt);
+    w.vec(t.filter); w.vec(t.short3); w.vec(t.shorts); w.vec(t.short3_big); w.vec(t.shorts_packed); w.u32(t.fpt_lg); w.vec(t.fpt);
     w.u32(t.slot_shift); w.u32(t.slot_seed); w.vec(t.slots); w.vec(t.more);
     w.raw(t.cls, 256); w.raw(t.cls_fold, 256); w.vec(t.term_blob); w.vec(t.term_off); w.u64(t.n_keys);
     uint64_t sum = 1469598103934665603ull;          // FNV-1a over everything before it
@@ -794,14 +795,14 @@ int gft_import_tables(gft_engine* e, const uint8_t* blob, uint64_t len) {
     r.vec(a.child_begin); r.vec(a.in_class);
     Scan2Tables t;
     t.supported = r.u32() != 0; t.kp = r.u32(); t.pad_class = r.u32(); t.hashed = r.u32() != 0; t.filter_bits = r.u32(); t.hash_shift = r.u32();
-    r.vec(t.filter); r.vec(t.short3); r.vec(t.shorts); r.vec(t.short3_big); r.vec(t.shorts_packed); r.vec(t.fpt);
+    r.vec(t.filter); r.vec(t.short3); r.vec(t.shorts); r.vec(t.short3_big); r.vec(t.shorts_packed); t.fpt_lg = r.u32(); r.vec(t.fpt);
     t.slot_shift = r.u32(); t.slot_seed = r.u32(); r.vec(t.slots); r.vec(t.more);
     r.raw(t.cls, 256); r.raw(t.cls_fold, 256); r.vec(t.term_blob); r.vec(t.term_off); t.n_keys = r.u64();
     if (!r.ok || r.i != r.n) return fail(e, GFT_E_INVALID, "table blob is truncated");
     // shape checks the kernels rely on
     if (a.n_classes == 0 || a.n_classes > 256 || a.delta.size() != (size_t)a.n_states * a.n_classes || a.out_term.size() != a.n_states ||
         a.out_link.size() != a.n_states || a.term_len.size() != a.terms.size() ||
-        (t.supported && (t.fpt.size() != kScan2FptSize || t.slots.size() != ((size_t)1 << (32 - t.slot_shift)) || t.term_off.size() != a.terms.size() + 1 ||
+        (t.supported && (t.fpt_lg > 28 || t.fpt.size() != (t.fpt_lg ? (size_t)1 << t.fpt_lg : (size_t)kScan2FptSize) || t.slots.size() != ((size_t)1 << (32 - t.slot_shift)) || t.term_off.size() != a.terms.size() + 1 ||
                          t.filter.size() * 32 != t.filter_bits)))
         return fail(e, GFT_E_INVALID, "table blob is inconsistent");
     if (!t.supported) t.why_not = "not supported by the suffix-window kernel (imported tables)";

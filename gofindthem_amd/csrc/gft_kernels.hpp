@@ -126,7 +126,9 @@ struct Scan2Short {
     uint32_t pad;
 };
 constexpr uint32_t kScan2Short3Max = 32768;      // bytes of LDS a direct 3-window table may take (K' <= 32)
-constexpr uint32_t kScan2FptSize = 20480;        // cells (one byte each)
+constexpr uint32_t kScan2FptSize = 20480;        // cells (one byte each) of the LDS-resident table
+constexpr uint32_t kScan2FptLdsItems = 11000;    // more terms of length >= 4 than this: the table moves to global memory (L2),
+                                                 // 2^fpt_lg cells at load <= 0.4 -- the LDS-spill path of large dictionaries
 constexpr uint32_t kScan2FptAmbiguous = 0xFF;    // always go to the bucket table
 // Fingerprint table: the LDS-only answer to "can a term of length >= 4 end here at all?" for a position whose window
 // passed the filter.  One cell per TERM (cuckoo placement at build time):
@@ -156,13 +158,14 @@ GFT_HD inline uint32_t scan2_slot_hash(uint32_t x, int which, uint32_t shift, ui
     const uint32_t xf = (x ^ (x >> 20)) + seed;    // keys beyond 24 bits (hashed alphabets) keep their top bits in play
     return (which ? scan2_mul24c<0x85EBCBu>(xf) : scan2_mul24c<0x9E3779u>(xf)) >> shift;
 }
-GFT_HD inline uint32_t scan2_fpt_index(uint32_t h) {
-    return (kScan2FptSize & (kScan2FptSize - 1)) == 0 ? h >> (32 - __builtin_ctz(kScan2FptSize)) : scan2_mul24c<kScan2FptSize>(h >> 16) >> 16;
+// fpt_lg == 0: the LDS table of kScan2FptSize cells; else a global table of 2^fpt_lg cells
+GFT_HD inline uint32_t scan2_fpt_index(uint32_t h, uint32_t fpt_lg) {
+    return fpt_lg ? h >> (32 - fpt_lg) : scan2_mul24c<kScan2FptSize>(h >> 16) >> 16;
 }
-GFT_HD inline uint32_t scan2_fpt_xcell(uint32_t x) { return scan2_fpt_index(scan2_mul24c<0x3779B1u>(x)); }
-GFT_HD inline uint32_t scan2_fpt_gcell(uint32_t x, uint32_t b1n, int which) {
+GFT_HD inline uint32_t scan2_fpt_xcell(uint32_t x, uint32_t fpt_lg) { return scan2_fpt_index(scan2_mul24c<0x3779B1u>(x), fpt_lg); }
+GFT_HD inline uint32_t scan2_fpt_gcell(uint32_t x, uint32_t b1n, int which, uint32_t fpt_lg) {
     return scan2_fpt_index(which ? scan2_mul24c<0xB2AE35u>(x) + scan2_mul24c<0x9E4F2Du>(b1n)
-                                 : scan2_mul24c<0xC2B2AFu>(x) + scan2_mul24c<0x27D4EBu>(b1n));
+                                 : scan2_mul24c<0xC2B2AFu>(x) + scan2_mul24c<0x27D4EBu>(b1n), fpt_lg);
 }
 GFT_HD inline uint32_t scan2_fpt_xmix(uint32_t x) { return scan2_mul24c<0xD4EB2Fu>(x); }
 GFT_HD inline uint32_t scan2_fpt_xbyte(uint32_t xmix) { return 5u << 5 | xmix >> 27; }
@@ -196,7 +199,8 @@ struct Scan2Params {
     uint32_t shorts_words;       // words staged in LDS (at most 255 records)
     const uint32_t* short3_big;  // full record id per 3-window for LDS byte 255 (nullptr: every record has an LDS id)
     uint32_t cand_cap;           // entries of a wave's LDS candidate list (scan2_plan)
-    const uint8_t* fpt;          // [kScan2FptSize], copied to LDS
+    const uint8_t* fpt;          // fpt_lg == 0: [kScan2FptSize], copied to LDS; else [2^fpt_lg], read in place (L2)
+    uint32_t fpt_lg;
     const Scan2Slot* slots;      // 2^lg slots, slot_shift = 32 - lg
     uint32_t slot_shift, slot_seed;
     const Scan2Slot* more;
@@ -218,8 +222,8 @@ struct Scan2Params {
     uint64_t* dbg_counters;      // [4] when dbg & 2: flagged positions, table probes, entries compared, -
 };
 // waves per workgroup (16, 12, 8 or 4) and candidate-list capacity that fit lds_max; false if nothing fits
-bool scan2_plan(uint32_t filter_words, uint32_t short3_bytes, uint32_t shorts_words, size_t lds_max, uint32_t* waves,
-                uint32_t* cand_cap);
+bool scan2_plan(uint32_t filter_words, uint32_t short3_bytes, uint32_t shorts_words, uint32_t fpt_lds_bytes, size_t lds_max,
+                uint32_t* waves, uint32_t* cand_cap);
 hipError_t launch_scan2(const Scan2Params& P, uint32_t waves, unsigned n_cus, hipStream_t st);
 
 hipError_t launch_unit_count(const uint64_t* d_doc_off, uint64_t n_docs, uint32_t unit_max, uint32_t* d_cnt,

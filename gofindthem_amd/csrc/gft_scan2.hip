@@ -68,7 +68,7 @@ struct Ctx {
     const uint8_t* cls;        // LDS
     const uint32_t* filt;      // LDS
     const uint8_t* short3;     // LDS (nullptr: the dictionary has no term shorter than the window)
-    const uint8_t* fpt;        // LDS
+    const uint8_t* fpt;        // LDS (fpt_lg == 0) or the global table
     const uint32_t* lrec;      // LDS: short-term records, 3 words each
     const uint8_t* dbase;      // first byte of the document
     uint64_t doc_abs;          // offset of the document inside the text blob
@@ -120,18 +120,22 @@ __device__ __forceinline__ void cand_keys(const Ctx& c, uint32_t p, const Text8 
 }
 // LDS-only decision: can a term of length >= 4 end here at all (fingerprint of the bytes in front of the window)?
 // Most flagged positions stop here without touching L2.
+template <bool FPT_LDS>
 __device__ __forceinline__ void cand_decide(const Ctx& c, Cand& k) {
     const uint32_t b1n = (k.tw >> 24) & 0xDFu;
-    const uint32_t cx = c.fpt[scan2_fpt_xcell(k.x)], cg0 = c.fpt[scan2_fpt_gcell(k.x, b1n, 0)], cg1 = c.fpt[scan2_fpt_gcell(k.x, b1n, 1)];
+    const uint32_t flg = FPT_LDS ? 0u : c.P.fpt_lg;
+    const uint8_t* f = FPT_LDS ? c.fpt : c.P.fpt;
+    const uint32_t cx = f[scan2_fpt_xcell(k.x, flg)], cg0 = f[scan2_fpt_gcell(k.x, b1n, 0, flg)], cg1 = f[scan2_fpt_gcell(k.x, b1n, 1, flg)];
     k.go_long = scan2_fpt_pass(cx, cg0, cg1, scan2_fpt_xmix(k.x), k.tw);
     if (c.P.dbg & 12) {         // timing studies (wrong results): 4 = no bucket-table access, 8 = no short-term records
         if (c.P.dbg & 4) k.go_long = false;
         if (c.P.dbg & 8) k.sid = 0;
     }
 }
+template <bool FPT_LDS>
 __device__ __forceinline__ void cand_text(const Ctx& c, uint32_t p, Cand& k) {
     cand_keys(c, p, cand_load(c, p), k);
-    cand_decide(c, k);
+    cand_decide<FPT_LDS>(c, k);
 }
 
 // step 2 (bucket table): the 20 bytes in front of the window as the slots store them, f[k] = text[p-7-4k .. p-4-4k]
@@ -389,14 +393,14 @@ __device__ __forceinline__ void drain_deferred(const Ctx& c, uint32_t unit_lo, u
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int MODE>
+template <int MODE, bool FPT_LDS>
 __device__ __forceinline__ void verify(const Ctx& c, uint32_t p, uint32_t& cnt, uint2* stage, uint64_t out_base) {
     Cand k;
-    cand_text(c, p, k);
+    cand_text<FPT_LDS>(c, p, k);
     if (k.go_long || k.sid) cand_finish<MODE>(c, k, cnt, stage, out_base);
 }
 
-template <int MODE>
+template <int MODE, bool FPT_LDS>
 __device__ __forceinline__ void verify_masks(const Ctx& c, uint32_t my_lo, uint32_t m0, uint32_t m1, uint32_t m2,
                                              uint32_t m3, uint32_t& cnt, uint2* stage, uint64_t out_base) {
     // one copy of the (large) verification body: the 32-position block index k is a scalar loop variable
@@ -406,28 +410,30 @@ __device__ __forceinline__ void verify_masks(const Ctx& c, uint32_t my_lo, uint3
             if (mk) {
                 const uint32_t i = __builtin_ctz(mk);
                 mk &= mk - 1;
-                verify<MODE>(c, my_lo + 32 * k + i, cnt, stage, out_base);
+                verify<MODE, FPT_LDS>(c, my_lo + 32 * k + i, cnt, stage, out_base);
             }
         }
     }
 }
 
 // ORDERED: matches of a unit leave in text order (CSR results); otherwise any order (solver input)
-template <bool HASHED, bool ORDERED>
+// FPT_LDS: the fingerprint table is staged in LDS (dictionaries up to kScan2FptLdsItems long terms); otherwise it is read
+// in place from global memory -- the spill path of large dictionaries, which also leaves more LDS to the candidate lists
+template <bool HASHED, bool ORDERED, bool FPT_LDS>
 __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
     extern __shared__ __align__(16) uint8_t smem[];
     uint8_t* cls = smem;
     uint32_t* filt = reinterpret_cast<uint32_t*>(smem + 256);
     uint8_t* short3 = smem + 256 + (size_t)P.filter_words * 4;
     uint8_t* fpt = short3 + P.short3_bytes;
-    uint32_t* lrec = reinterpret_cast<uint32_t*>(fpt + kScan2FptSize);
+    uint32_t* lrec = reinterpret_cast<uint32_t*>(fpt + (FPT_LDS ? kScan2FptSize : 0));
     uint8_t* wave_lds_all = reinterpret_cast<uint8_t*>(lrec) + ((P.shorts_words * 4 + 15) & ~15u);
 
     for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) cls[i] = P.cls[i];
     for (uint32_t i = threadIdx.x; i < P.filter_words; i += blockDim.x) filt[i] = P.filter[i];
     for (uint32_t i = threadIdx.x; i < P.short3_bytes / 4; i += blockDim.x)
         reinterpret_cast<uint32_t*>(short3)[i] = reinterpret_cast<const uint32_t*>(P.short3)[i];
-    for (uint32_t i = threadIdx.x; i < kScan2FptSize / 4; i += blockDim.x)
+    for (uint32_t i = threadIdx.x; FPT_LDS && i < kScan2FptSize / 4; i += blockDim.x)
         reinterpret_cast<uint32_t*>(fpt)[i] = reinterpret_cast<const uint32_t*>(P.fpt)[i];
     for (uint32_t i = threadIdx.x; i < P.shorts_words; i += blockDim.x) lrec[i] = P.shorts_packed[i];
     __syncthreads();
@@ -604,7 +610,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
 #pragma unroll
                         for (int q = 0; q < kStageAWays; q++) cand_keys(c, un.lo + rel[q], tx[q], k[q]);
 #pragma unroll
-                        for (int q = 0; q < kStageAWays; q++) cand_decide(c, k[q]);
+                        for (int q = 0; q < kStageAWays; q++) cand_decide<FPT_LDS>(c, k[q]);
 #pragma unroll
                         for (int q = 0; q < kStageAWays; q++)
                             if (i0 + 64 * q < ptotal) finish_short(c, k[q].p, on[q] ? k[q].sid : 0, k[q].x3, fifo, nf);
@@ -675,7 +681,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
         }
 
         // ---- phase 2, ordered path: every lane verifies its own positions in text order, stages matches in LDS ---------
-        verify_masks<0>(c, my_lo, m0, m1, m2, m3, cnt, stage, 0);
+        verify_masks<0, FPT_LDS>(c, my_lo, m0, m1, m2, m3, cnt, stage, 0);
 
         // ---- output -------------------------------------------------------------------------------------------------
         const uint32_t incl = wave_incl_scan(cnt);
@@ -707,7 +713,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
             const bool over = cnt > kScan2StageCap;
             if (__any(over)) {
                 uint32_t c2 = 0;
-                verify_masks<1>(c, my_lo, over ? m0 : 0, over ? m1 : 0, over ? m2 : 0, over ? m3 : 0, c2, stage, mine);
+                verify_masks<1, FPT_LDS>(c, my_lo, over ? m0 : 0, over ? m1 : 0, over ? m2 : 0, over ? m3 : 0, c2, stage, mine);
             }
         }
     }
@@ -717,13 +723,13 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
 
 }  // namespace
 
-static size_t scan2_fixed_lds(uint32_t filter_words, uint32_t short3_bytes, uint32_t shorts_words) {
-    return 256 + (size_t)filter_words * 4 + short3_bytes + kScan2FptSize + (((size_t)shorts_words * 4 + 15) & ~(size_t)15);
+static size_t scan2_fixed_lds(uint32_t filter_words, uint32_t short3_bytes, uint32_t shorts_words, uint32_t fpt_lds_bytes) {
+    return 256 + (size_t)filter_words * 4 + short3_bytes + fpt_lds_bytes + (((size_t)shorts_words * 4 + 15) & ~(size_t)15);
 }
 
-bool scan2_plan(uint32_t filter_words, uint32_t short3_bytes, uint32_t shorts_words, size_t lds_max, uint32_t* waves,
-                uint32_t* cand_cap) {
-    const size_t fixed = scan2_fixed_lds(filter_words, short3_bytes, shorts_words);
+bool scan2_plan(uint32_t filter_words, uint32_t short3_bytes, uint32_t shorts_words, uint32_t fpt_lds_bytes, size_t lds_max,
+                uint32_t* waves, uint32_t* cand_cap) {
+    const size_t fixed = scan2_fixed_lds(filter_words, short3_bytes, shorts_words, fpt_lds_bytes);
     for (uint32_t w : {16u, 12u, 8u, 4u}) {
         if (fixed + (size_t)w * (kScan2FifoCap * 8 + kScan2CandCapMin * 2) > lds_max) continue;
         size_t per = ((lds_max - fixed) / w) & ~(size_t)15;
@@ -737,11 +743,14 @@ bool scan2_plan(uint32_t filter_words, uint32_t short3_bytes, uint32_t shorts_wo
 
 hipError_t launch_scan2(const Scan2Params& P, uint32_t waves, unsigned n_cus, hipStream_t st) {
     if (!P.n_units) return hipSuccess;
-    const size_t lds = scan2_fixed_lds(P.filter_words, P.short3_bytes, P.shorts_words) +
+    const bool fl = P.fpt_lg == 0;
+    const size_t lds = scan2_fixed_lds(P.filter_words, P.short3_bytes, P.shorts_words, fl ? kScan2FptSize : 0) +
                        (size_t)waves * (kScan2FifoCap * 8 + P.cand_cap * 2);
     using Kern = void (*)(const Scan2Params);
-    const Kern fn = P.hashed ? (P.ordered ? k_scan2<true, true> : k_scan2<true, false>)
-                             : (P.ordered ? k_scan2<false, true> : k_scan2<false, false>);
+    static const Kern table[2][2][2] = {
+        {{k_scan2<false, false, false>, k_scan2<false, false, true>}, {k_scan2<false, true, false>, k_scan2<false, true, true>}},
+        {{k_scan2<true, false, false>, k_scan2<true, false, true>}, {k_scan2<true, true, false>, k_scan2<true, true, true>}}};
+    const Kern fn = table[P.hashed ? 1 : 0][P.ordered ? 1 : 0][fl ? 1 : 0];
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     uint64_t g = (P.n_units + waves - 1) / waves;

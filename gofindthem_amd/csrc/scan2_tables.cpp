@@ -112,7 +112,6 @@ void build_scan2_tables(const AcTables& ac, Scan2Tables& t) {
             }
         return r;
     };
-    t.fpt.assign(kScan2FptSize, 0);
     std::vector<Scan2Slot> items;        // one per key: the term itself, or the header of a multi-term bucket
     for (auto& kv : buckets) {
         auto& v = kv.second;
@@ -157,9 +156,16 @@ void build_scan2_tables(const AcTables& ac, Scan2Tables& t) {
     }
     // ---- fingerprint table: one cell per term (gft_kernels.hpp) ---------------------------------------------------------
     {
+        size_t n_items = 0;
+        for (const auto& kv : buckets) n_items += kv.second.size();
+        t.fpt_lg = 0;
+        if (n_items > kScan2FptLdsItems) { t.fpt_lg = 15; while (((size_t)1 << t.fpt_lg) * 2 < n_items * 5 && t.fpt_lg < 28) t.fpt_lg++; }
+        const uint32_t flg = t.fpt_lg;
+        const size_t n_cells = flg ? (size_t)1 << flg : kScan2FptSize;
+        t.fpt.assign(n_cells, 0);
         struct GItem { uint32_t x, b1n; uint8_t val; };
         std::vector<uint32_t> ambiguous;                       // cells that must pass everything
-        std::vector<uint8_t> pinned(kScan2FptSize, 0);
+        std::vector<uint8_t> pinned(n_cells, 0);
         std::map<std::pair<uint32_t, uint32_t>, std::vector<uint8_t>> groups;   // (key, b1n) -> distinct cell bytes
         for (const auto& kv : buckets) {
             const uint32_t x = kv.first, xm = scan2_fpt_xmix(x);
@@ -167,7 +173,7 @@ void build_scan2_tables(const AcTables& ac, Scan2Tables& t) {
                 const std::string& s = ac.terms[e.term_id];
                 const int L = (int)s.size();
                 if (L == 4) {
-                    const uint32_t c = scan2_fpt_xcell(x);
+                    const uint32_t c = scan2_fpt_xcell(x, flg);
                     const uint8_t v = (uint8_t)scan2_fpt_xbyte(xm);
                     if (t.fpt[c] != 0 && t.fpt[c] != v) ambiguous.push_back(c);
                     t.fpt[c] = v;
@@ -187,7 +193,7 @@ void build_scan2_tables(const AcTables& ac, Scan2Tables& t) {
         std::vector<GItem> singles;
         for (const auto& kv : groups) {
             const uint32_t x = kv.first.first, b1n = kv.first.second;
-            const uint32_t c0 = scan2_fpt_gcell(x, b1n, 0), c1 = scan2_fpt_gcell(x, b1n, 1);
+            const uint32_t c0 = scan2_fpt_gcell(x, b1n, 0, flg), c1 = scan2_fpt_gcell(x, b1n, 1, flg);
             if (kv.second.size() == 1) { singles.push_back(GItem{x, b1n, kv.second[0]}); continue; }
             if (kv.second.size() == 2 && c0 != c1 && t.fpt[c0] == 0 && t.fpt[c1] == 0) {
                 t.fpt[c0] = kv.second[0]; t.fpt[c1] = kv.second[1];
@@ -196,12 +202,12 @@ void build_scan2_tables(const AcTables& ac, Scan2Tables& t) {
                 ambiguous.push_back(c0);
             }
         }
-        std::vector<GItem> owner(kScan2FptSize, GItem{0, 0, 0});
+        std::vector<GItem> owner(n_cells, GItem{0, 0, 0});
         uint32_t rng = 0x12345u;
         for (GItem cur : singles) {
             bool placed = false;
             for (int kick = 0; kick < 500 && !placed; kick++) {
-                const uint32_t c0 = scan2_fpt_gcell(cur.x, cur.b1n, 0), c1 = scan2_fpt_gcell(cur.x, cur.b1n, 1);
+                const uint32_t c0 = scan2_fpt_gcell(cur.x, cur.b1n, 0, flg), c1 = scan2_fpt_gcell(cur.x, cur.b1n, 1, flg);
                 if (t.fpt[c0] == 0) { t.fpt[c0] = cur.val; owner[c0] = cur; placed = true; break; }
                 if (t.fpt[c1] == 0) { t.fpt[c1] = cur.val; owner[c1] = cur; placed = true; break; }
                 rng = rng * 1664525u + 1013904223u;
@@ -211,7 +217,7 @@ void build_scan2_tables(const AcTables& ac, Scan2Tables& t) {
                 std::swap(cur, owner[victim]);                  // the newcomer moves in, the old tenant looks on
                 t.fpt[victim] = owner[victim].val;
             }
-            if (!placed) ambiguous.push_back(scan2_fpt_gcell(cur.x, cur.b1n, 0));
+            if (!placed) ambiguous.push_back(scan2_fpt_gcell(cur.x, cur.b1n, 0, flg));
         }
         // cells that pass everything are set last: whatever lived there passes too
         for (uint32_t c : ambiguous) t.fpt[c] = kScan2FptAmbiguous;

@@ -240,3 +240,21 @@ def test_table_export_import_roundtrip(eng, scan_kernel):
         assert_csr_equal(e2.scan(text, off, fold=True), o.scan(text, off, fold=True))
     finally:
         e2.close()
+
+
+def test_large_dictionary_spill_path(eng):
+    """30 000 terms: more long terms than the LDS fingerprint table holds, so it moves to global memory
+    (kScan2FptLdsItems; BASELINE configs[4] "LDS-tile spill path"); dense matches shrink the work units"""
+    from gofindthem_amd.workload import Workload, make_expressions
+    w = Workload(30000)
+    terms = w.terms()
+    o = both(eng, terms)
+    text, off = w.docs_host(0, 400)
+    assert_csr_equal(eng.scan(text, off, fold=True), o.scan(text, off, fold=True))
+    exprs = make_expressions(terms, 150, inord_fraction=0.4)
+    o.set_expressions(exprs, False)
+    progs, extra = _programs(o, eng, exprs, False)
+    eng.set_programs(progs)
+    want = o.process(text, off, fold=True)
+    assert np.array_equal(eng.process(text, off, fold=True), want)
+    assert np.array_equal(eng.process(text, off, fold=True), want)      # second call: adapted unit size

@@ -79,6 +79,8 @@ struct gft_engine {
     DevBuf d_prog, d_prog_off;            // public postfix words (INORD group subtrees are read from these)
     DevBuf d_fprog, d_fprog_off, d_groups; // fused internal form + INORD group table
     DevBuf d_order, d_blk_deep;            // evaluation order of the programs (gft_set_programs)
+    uint32_t last_solve_group_docs = 64;   // documents per solver group of the last launch (0 = presence matrix in HBM)
+    DevBuf d_fprog_t, d_fblk_off;          // fused programs per sorted block of 64, transposed (read when they do not fit LDS)
     uint32_t fprog_words = 0;
     uint32_t n_inord_groups = 0;           // fused INORD ops: 0 = the solver never reads positions
     DevBuf d_pscratch;                    // HBM presence matrices when n_slots * 8 B does not fit LDS
@@ -515,27 +517,36 @@ int solve_pipeline(gft_engine* e, uint64_t n_docs, const gft_extra_matches* d_ex
     S.fprog = e->d_fprog.as<uint32_t>(); S.fprog_off = e->d_fprog_off.as<uint64_t>();
     S.gprog = e->d_prog.as<uint32_t>(); S.groups = e->d_groups.as<uint32_t>();
     S.order = e->d_order.as<uint32_t>(); S.blk_deep = e->d_blk_deep.as<uint32_t>();
+    S.fprog_t = e->d_fprog_t.as<uint32_t>(); S.fblk_off = e->d_fblk_off.as<uint32_t>();
     S.n_exprs = e->n_exprs;
     S.n_slots = (uint32_t)e->tab.terms.size() + e->n_extra + 1;
     S.tile_words = std::min<uint32_t>(kSolveTileWords, (e->n_exprs + 31) / 32);
     S.bitmap = d_bitmap;
     S.p_scratch = nullptr;
     { const char* dbg = getenv("GFT_SOLVE_DEBUG"); S.dbg = dbg ? (uint32_t)atoi(dbg) : 0; }
-    // presence matrix (8 B per slot) in LDS when it fits next to the output tile, else in HBM (served by L2)
+    // Presence matrix in LDS next to the output tile: G documents per group = G / 8 bytes per slot, the widest G of
+    // 64 / 32 / 16 / 8 that fits (GFT_SOLVE_GROUP_DOCS forces one, for tests); beyond that in HBM (served by L2), G = 64
     S.fprog_words = e->fprog_words;
-    const bool p_in_lds = solve_lds_bytes(S.n_slots, S.tile_words, true, 0, 0, false) + 1024 <= e->lds_max;
+    uint32_t group_docs = 64;
+    bool p_in_lds = false;
+    const char* force_g = getenv("GFT_SOLVE_GROUP_DOCS");
+    for (uint32_t G : {64u, 32u, 16u, 8u}) {
+        if (force_g && (uint32_t)atoi(force_g) != G) continue;
+        if (solve_lds_bytes(S.n_slots, S.tile_words, G, true, 0, 0, false) + 1024 <= e->lds_max) { group_docs = G; p_in_lds = true; break; }
+    }
     // ... and the fused programs too, if there is room left (the interpreter fetches them word after word)
-    const bool prog_in_lds = solve_lds_bytes(S.n_slots, S.tile_words, p_in_lds, S.fprog_words, S.n_exprs, true) + 1024 <= e->lds_max;
-    const uint64_t n_groups = (n_docs + 63) / 64;
-    const size_t lds_need = solve_lds_bytes(S.n_slots, S.tile_words, p_in_lds, S.fprog_words, S.n_exprs, prog_in_lds) + 512;
+    const bool prog_in_lds = solve_lds_bytes(S.n_slots, S.tile_words, group_docs, p_in_lds, S.fprog_words, S.n_exprs, true) + 1024 <= e->lds_max;
+    const uint64_t n_groups = (n_docs + group_docs - 1) / group_docs;
+    const size_t lds_need = solve_lds_bytes(S.n_slots, S.tile_words, group_docs, p_in_lds, S.fprog_words, S.n_exprs, prog_in_lds) + 512;
     const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, e->lds_max / lds_need));
     unsigned grid = (unsigned)std::min<uint64_t>(n_groups, (uint64_t)e->n_cus * per_cu);
     if (!p_in_lds) {
         HIP_TRY(e->d_pscratch.ensure((size_t)grid * S.n_slots * 8), "presence scratch alloc");
         S.p_scratch = e->d_pscratch.as<uint64_t>();
     }
+    e->last_solve_group_docs = p_in_lds ? group_docs : 0;
     ProfScope ps(e, "solve");
-    HIP_TRY(launch_solve(S, p_in_lds, prog_in_lds, grid, e->stream), "solve kernel launch");
+    HIP_TRY(launch_solve(S, group_docs, p_in_lds, prog_in_lds, grid, e->stream), "solve kernel launch");
     return GFT_OK;
 }
 
@@ -610,7 +621,7 @@ void gft_engine_destroy(gft_engine* e) {
         for (auto& kv : e->prof)
             for (auto& p : kv.second.ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
         DevBuf* all[] = {&e->d_byte_class, &e->d_delta, &e->d_out_term, &e->d_out_link, &e->d_term_len, &e->d_prog,
-                         &e->d_prog_off, &e->d_fprog, &e->d_fprog_off, &e->d_groups, &e->d_order, &e->d_blk_deep, &e->d_pscratch, &e->d_s2_filter,
+                         &e->d_prog_off, &e->d_fprog, &e->d_fprog_off, &e->d_groups, &e->d_order, &e->d_blk_deep, &e->d_fprog_t, &e->d_fblk_off, &e->d_pscratch, &e->d_s2_filter,
                          &e->d_s2_slots, &e->d_s2_more, &e->d_s2_cls, &e->d_s2_cls_fold, &e->d_s2_term_blob,
                          &e->d_s2_term_off, &e->d_nmatches, &e->d_dbg, &e->d_s2_short3, &e->d_s2_shorts_packed, &e->d_s2_short3_big, &e->d_s2_fpt,
 &e->d_unit_cnt, &e->d_unit_base, &e->d_units, &e->d_partial, &e->d_cursor,
@@ -919,13 +930,14 @@ int gft_set_programs(gft_engine* e, const uint32_t* prog_words, const uint64_t* 
     std::vector<uint64_t> fo(1, 0);
     for (uint32_t i = 0; i < n_exprs; i++) {
         fdepth.push_back(fuse_program(prog_words + prog_off[i], prog_off[i + 1] - prog_off[i], prog_off[i], fw, groups));
+        while (fw.size() % 4) fw.push_back((uint32_t)kFopNop << 28);       // the interpreter reads 4-word chunks
         fo.push_back(fw.size());
     }
     // Evaluation order: inside every output tile (kSolveTileWords * 32 expressions) the programs are sorted by
     // length, longest first, and handed to the waves 64 at a time, so the lanes of a wave run loops of similar
     // length; programs that nest deeper than the interpreter's register stack come first (their blocks take the
     // general interpreter).  order[i] = expression evaluated at sorted position i; blk_deep[b] = block b needs it.
-    std::vector<uint32_t> order(n_exprs), blk_deep;
+    std::vector<uint32_t> order(n_exprs), blk_deep, fprog_t, fblk_off;
     for (uint32_t i = 0; i < n_exprs; i++) order[i] = i;
     const uint32_t tile_exprs = kSolveTileWords * 32;
     for (uint32_t t0 = 0; t0 < n_exprs; t0 += tile_exprs) {
@@ -937,12 +949,27 @@ int gft_set_programs(gft_engine* e, const uint32_t* prog_words, const uint64_t* 
         });
         for (uint32_t b0 = t0; b0 < t1; b0 += 64) {
             uint32_t deep = 0;
-            for (uint32_t i = b0; i < std::min(t1, b0 + 64); i++) deep |= fdepth[order[i]] > kSolveRegStack;
+            uint64_t maxlen = 0;
+            for (uint32_t i = b0; i < std::min(t1, b0 + 64); i++) {
+                deep |= fdepth[order[i]] > kSolveRegStack;
+                maxlen = std::max(maxlen, fo[order[i] + 1] - fo[order[i]]);
+            }
             blk_deep.push_back(deep);
+            // the block's chunks transposed: words 4c..4c+3 of lane l at off + (c * 64 + l) * 4
+            if (fprog_t.size() + maxlen * 64 > 0xFFFFFFFFull) return fail(e, GFT_E_UNSUPPORTED, "program set too large");
+            fblk_off.push_back((uint32_t)fprog_t.size());
+            fprog_t.resize(fprog_t.size() + maxlen * 64, (uint32_t)kFopNop << 28);
+            for (uint32_t i = b0; i < std::min(t1, b0 + 64); i++) {
+                const uint64_t p0 = fo[order[i]], len = fo[order[i] + 1] - p0;
+                for (uint64_t pc = 0; pc < len; pc++)
+                    fprog_t[fblk_off.back() + ((pc / 4) * 64 + (i - b0)) * 4 + pc % 4] = fw[p0 + pc];
+            }
         }
     }
     if (order.empty()) order.push_back(0);
     if (blk_deep.empty()) blk_deep.push_back(0);
+    if (fblk_off.empty()) fblk_off.push_back(0);
+    if (fprog_t.empty()) fprog_t.push_back(0);
     if (getenv("GFT_SOLVE_DEBUG")) {
         uint64_t hist[16] = {0}, with_rare = 0, maxlen = 0;
         for (uint32_t i = 0; i < n_exprs; i++) {
@@ -963,6 +990,8 @@ int gft_set_programs(gft_engine* e, const uint32_t* prog_words, const uint64_t* 
     if ((rc = upload(e, e->d_groups, groups, "program upload"))) return rc;
     if ((rc = upload(e, e->d_order, order, "program upload"))) return rc;
     if ((rc = upload(e, e->d_blk_deep, blk_deep, "program upload"))) return rc;
+    if ((rc = upload(e, e->d_fprog_t, fprog_t, "program upload"))) return rc;
+    if ((rc = upload(e, e->d_fblk_off, fblk_off, "program upload"))) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream), "program upload");
     e->n_exprs = n_exprs; e->n_extra = n_extra; e->have_programs = true;
     e->scan_valid_docs = ~0ull;          // positions may not have been written for the old program set

@@ -56,7 +56,8 @@ enum FusedOp : uint32_t {     // ops < 8 read one presence row: bit 2 = negate i
     kFopOrPop = 9,    // acc = pop | acc
     kFopNot = 10,     // acc = ~acc (only on top of an INORD group: NOT is pushed down to the leaves otherwise)
     kFopInord = 11,   // acc = documents of acc whose INORD group `operand` has a non-empty position list
-    kFopPush = 12     // push acc
+    kFopPush = 12,    // push acc
+    kFopNop = 13      // padding: every program is a whole number of 4-word chunks
 };
 constexpr uint32_t kSolveRegStack = 2;           // accumulator-stack entries the fast interpreter keeps in registers
 constexpr uint32_t kSolveTileWords = 64;         // bitmap words (x32 expressions) evaluated per LDS output tile
@@ -79,6 +80,8 @@ struct SolveParams {
     const uint32_t* groups;      // [n_groups][2] = offset, length into gprog
     const uint32_t* order;       // [n_exprs] evaluation order inside every output tile (gft_set_programs)
     const uint32_t* blk_deep;    // per 64 sorted programs: 1 = some program nests deeper than kSolveRegStack
+    const uint32_t* fprog_t;     // the same programs per sorted block, transposed by chunk: words 4c..4c+3 of lane l at fblk_off[b] + (c * 64 + l) * 4
+    const uint32_t* fblk_off;    // (read when the programs do not fit LDS: coalesced instead of one stream per lane)
     uint32_t n_exprs, n_slots, tile_words;
     uint32_t fprog_words;        // total words of fprog (staged in LDS when they fit)
     uint32_t dbg;                // GFT_SOLVE_DEBUG bits (timing studies): 1 skip presence build, 2 skip evaluation, 4 skip transpose/output
@@ -242,8 +245,9 @@ hipError_t launch_gather(const uint64_t* d_unit_start, const uint32_t* d_unit_co
                          uint32_t* d_pos, const uint64_t* d_unit_base, uint64_t n_docs, uint64_t* d_match_off,
                          unsigned n_cus, hipStream_t st, const Unit* d_units_to_sort = nullptr,
                          const uint32_t* d_term_len = nullptr, uint32_t pos_end = 0);
-size_t solve_lds_bytes(uint32_t n_slots, uint32_t tile_words, bool p_in_lds, uint32_t prog_words, uint32_t n_exprs,
-                       bool prog_in_lds);
-hipError_t launch_solve(const SolveParams& S, bool p_in_lds, bool prog_in_lds, unsigned grid, hipStream_t st);
+size_t solve_lds_bytes(uint32_t n_slots, uint32_t tile_words, uint32_t group_docs, bool p_in_lds, uint32_t prog_words,
+                       uint32_t n_exprs, bool prog_in_lds);
+// group_docs: documents per group (64, 32, 16 or 8 = bits per presence-matrix element)
+hipError_t launch_solve(const SolveParams& S, uint32_t group_docs, bool p_in_lds, bool prog_in_lds, unsigned grid, hipStream_t st);
 
 }  // namespace gft

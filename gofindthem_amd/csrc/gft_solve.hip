@@ -22,7 +22,6 @@ namespace gft {
 namespace {
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
-constexpr uint32_t kTeam = 16;   // lanes that share one document while the presence matrix is built
 
 // ---- per-document view of the matches (slabs of the scan kernel + caller-supplied matches) -------------------
 struct DocHits {
@@ -155,49 +154,63 @@ __device__ uint64_t inord_docs(const SolveParams& S, uint32_t grp, uint64_t cand
 // programs, so the interpreter is predicated rather than branched: every word costs one presence read and a handful of
 // selects.  DEEP = false keeps the accumulator stack in two registers (programs that nest deeper are sorted into
 // blocks of their own and take DEEP = true: four registers backed by scratch).
-template <bool P_LDS, bool DEEP>
-__device__ __forceinline__ uint64_t run_program(const SolveParams& S, const uint64_t* P, const uint32_t* prog, uint32_t len,
-                                                uint64_t valid, uint64_t d0) {
+template <bool P_LDS, bool DEEP, class PT, class AT>
+__device__ __forceinline__ AT run_program(const SolveParams& S, const PT* P, const uint4* prog, uint32_t stride, uint32_t chunks,
+                                          AT valid, uint64_t d0) {
     // HBM-resident P was written with L2 atomics by other waves: read it past this CU's L1
-    auto ld = [&](uint32_t slot) -> uint64_t {
-        return P_LDS ? P[slot] : __hip_atomic_load(&P[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    auto ld = [&](uint32_t slot) -> AT {
+        return P_LDS ? (AT)P[slot] : (AT)__hip_atomic_load(&P[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
-    uint64_t acc = 0, s0 = 0, s1 = 0, s2 = 0, s3 = 0, deep[DEEP ? kMaxBoolDepth : 1];
+    AT acc = 0, s0 = 0, s1 = 0, s2 = 0, s3 = 0, deep[DEEP ? kMaxBoolDepth : 1];
     uint32_t sp = 0;
-    uint32_t w = len ? prog[0] : 0;
-    for (uint32_t pc = 0; pc < len; pc++) {
-        const uint32_t op = w >> 28, a = w & 0x0FFFFFFFu;
-        if (pc + 1 < len) w = prog[pc + 1];                     // next word in flight
-        const bool is_s = op < kFopAndPop;
-        uint64_t v = ld(is_s ? a : 0);
-        v ^= 0ull - (uint64_t)((op >> 2) & 1);                  // SetN / AndNS / OrNS
-        const uint32_t k = op & 3;
-        const uint64_t t = k == 3 ? (acc | v) : (acc & v);
-        const uint64_t sacc = k == 1 ? v : t;
-        const bool is_pop = (op & 14) == kFopAndPop, is_push = op == kFopPush;
-        const uint64_t pacc = (op & 1) ? (acc | s0) : (acc & s0);
-        const uint64_t before = acc;
-        acc = is_s ? sacc : is_pop ? pacc : acc;
-        if (!DEEP) {
-            const uint64_t n0 = is_push ? before : is_pop ? s1 : s0;
-            s1 = is_push ? s0 : s1;
-            s0 = n0;
-        } else {
-            if (is_push) {
-                if (sp >= 4) deep[sp - 4] = s3;
-                s3 = s2; s2 = s1; s1 = s0; s0 = before;
-                sp++;
-            }
-            if (is_pop) {
-                s0 = s1; s1 = s2; s2 = s3;
-                sp--;
-                if (sp >= 4) s3 = deep[sp - 4];
-            }
+    uint4 nx = chunks ? prog[0] : make_uint4(0, 0, 0, 0);
+    // four words per trip: the next chunk and this chunk's four presence reads are in flight together, so a trip
+    // exposes one memory round trip instead of four (programs are padded to whole chunks with kFopNop)
+    for (uint32_t c = 0; c < chunks; c++) {
+        const uint32_t w[4] = {nx.x, nx.y, nx.z, nx.w};
+        if (c + 1 < chunks) nx = prog[(size_t)(c + 1) * stride];
+        AT pv[4];
+        bool rare = false;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t op = w[q] >> 28;
+            pv[q] = ld(op < kFopAndPop ? (w[q] & 0x0FFFFFFFu) : 0);
+            rare |= op == kFopNot || op == kFopInord;
         }
-        if (__any(op == kFopNot || op == kFopInord)) {          // only around INORD groups
-            if (op == kFopNot) acc = ~acc;
-            // candidates: documents where the group's boolean value is true (rval, expression.go:137)
-            if (op == kFopInord) acc = inord_docs(S, a, acc & valid, d0);
+        const bool any_rare = __any(rare);                      // wave-uniform: only around INORD groups
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t op = w[q] >> 28, a = w[q] & 0x0FFFFFFFu;
+            const bool is_s = op < kFopAndPop;
+            const AT v = pv[q] ^ (AT)(0 - (AT)((op >> 2) & 1)); // SetN / AndNS / OrNS (bits past the group are never stored)
+            const uint32_t k = op & 3;
+            const AT t = k == 3 ? (acc | v) : (acc & v);
+            const AT sacc = k == 1 ? v : t;
+            const bool is_pop = (op & 14) == kFopAndPop, is_push = op == kFopPush;
+            const AT pacc = (op & 1) ? (acc | s0) : (acc & s0);
+            const AT before = acc;
+            acc = is_s ? sacc : is_pop ? pacc : acc;
+            if (!DEEP) {
+                const AT n0 = is_push ? before : is_pop ? s1 : s0;
+                s1 = is_push ? s0 : s1;
+                s0 = n0;
+            } else {
+                if (is_push) {
+                    if (sp >= 4) deep[sp - 4] = s3;
+                    s3 = s2; s2 = s1; s1 = s0; s0 = before;
+                    sp++;
+                }
+                if (is_pop) {
+                    s0 = s1; s1 = s2; s2 = s3;
+                    sp--;
+                    if (sp >= 4) s3 = deep[sp - 4];
+                }
+            }
+            if (any_rare) {
+                if (op == kFopNot) acc = ~acc;
+                // candidates: documents where the group's boolean value is true (rval, expression.go:137)
+                if (op == kFopInord) acc = (AT)inord_docs(S, a, (uint64_t)(acc & valid), d0);
+            }
         }
     }
     return acc;
@@ -205,15 +218,28 @@ __device__ __forceinline__ uint64_t run_program(const SolveParams& S, const uint
 
 // PROG_LDS: the fused programs (and their offsets) are staged in LDS once per workgroup, so the interpreter's
 // dependent word-after-word fetches cost an LDS round trip instead of an L2 one
-template <bool P_LDS, bool PROG_LDS>
+template <int G> struct PType { using type = uint64_t; };
+template <> struct PType<32> { using type = uint32_t; };
+template <> struct PType<16> { using type = uint16_t; };
+template <> struct PType<8> { using type = uint8_t; };
+template <int G> struct AType { using type = uint32_t; };
+template <> struct AType<64> { using type = uint64_t; };
+
+// G = documents per group = bits of a presence-matrix element: 64 when 8 bytes per slot fit LDS, else 32 / 16 / 8 so that
+// large dictionaries still keep P in LDS (the evaluation then covers fewer documents per operation, but P stops being an
+// L2 ping-pong of atomics and random reads)
+template <bool P_LDS, bool PROG_LDS, int G>
 __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const SolveParams S) {
+    using PT = typename PType<G>::type;
+    using AT = typename AType<G>::type;                         // document masks of the evaluation
+    constexpr uint32_t kTeam = kSolveBlockThreads / G;          // lanes that share one document while P is built
     extern __shared__ __align__(16) uint8_t smem[];
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     constexpr uint32_t kWaves = kSolveBlockThreads / 64;
     const uint32_t tile_words = S.tile_words;                   // bitmap words covered by one pass (<= kSolveTileWords)
     const uint32_t bm_words = (S.n_exprs + 31) / 32;
-    uint64_t* P = P_LDS ? reinterpret_cast<uint64_t*>(smem) : S.p_scratch + (size_t)blockIdx.x * S.n_slots;
-    uint32_t* O = reinterpret_cast<uint32_t*>(smem + (P_LDS ? (((size_t)S.n_slots * 8 + 15) & ~(size_t)15) : 0));   // [64][tile_words]
+    PT* P = P_LDS ? reinterpret_cast<PT*>(smem) : reinterpret_cast<PT*>(S.p_scratch + (size_t)blockIdx.x * S.n_slots);
+    uint32_t* O = reinterpret_cast<uint32_t*>(smem + (P_LDS ? (((size_t)S.n_slots * sizeof(PT) + 15) & ~(size_t)15) : 0));   // [64][tile_words]
     uint32_t* Pw = reinterpret_cast<uint32_t*>(P);
     uint64_t* R = reinterpret_cast<uint64_t*>(O + 64 * tile_words);   // [tile_words * 32] results by expression
     uint32_t* lprog = reinterpret_cast<uint32_t*>(R + tile_words * 32);  // [fprog_words] when PROG_LDS
@@ -227,16 +253,16 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
 
     for (uint32_t i = threadIdx.x; i < S.n_slots; i += kSolveBlockThreads) {
         if (P_LDS) P[i] = 0;
-        else __hip_atomic_store(&P[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else __hip_atomic_store(&P[i], (PT)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
 
-    const uint64_t n_groups = (S.n_docs + 63) / 64;
+    const uint64_t n_groups = (S.n_docs + G - 1) / G;
     // unit range + first slab of this thread's document in the NEXT group (consumed by step 1 of that group)
     uint64_t pf_u0 = 0, pf_u1 = 0, pf_s = 0;
     uint32_t pf_n = 0;
     auto prefetch = [&](uint64_t g) {
-        const uint64_t d = g * 64 + threadIdx.x / kTeam;
+        const uint64_t d = g * G + threadIdx.x / kTeam;
         pf_u0 = pf_u1 = 0; pf_n = 0;
         if (g < n_groups && d < S.n_docs) {
             pf_u0 = S.doc_unit_base[d]; pf_u1 = S.doc_unit_base[d + 1];
@@ -245,8 +271,8 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
     };
     prefetch(blockIdx.x);
     for (uint64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
-        const uint64_t d0 = g * 64;
-        const uint32_t nd = (uint32_t)(S.n_docs - d0 < 64 ? S.n_docs - d0 : 64);
+        const uint64_t d0 = g * G;
+        const uint32_t nd = (uint32_t)(S.n_docs - d0 < (uint64_t)G ? S.n_docs - d0 : (uint64_t)G);
 
         // ---- 1. presence matrix ------------------------------------------------------------------------------
         // a team of kTeam lanes per document, all documents of the group at once.  The document's unit range and its
@@ -255,7 +281,6 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
         for (uint32_t j = threadIdx.x / kTeam; j < nd && !(S.dbg & 1); j += kSolveBlockThreads / kTeam) {
             const uint32_t member = threadIdx.x % kTeam;
             const uint64_t d = d0 + j;
-            const uint32_t bit = 1u << (j & 31), half = j >> 5;
             const bool pf = j == threadIdx.x / kTeam;              // first (normally only) document of this team
             const uint64_t u0 = pf ? pf_u0 : S.doc_unit_base[d], u1 = pf ? pf_u1 : S.doc_unit_base[d + 1];
             for (uint64_t u = u0; u < u1; u++) {
@@ -268,17 +293,18 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
 #pragma unroll
                     for (int q = 0; q < 4; q++)
                         if (t[q] != 0xFFFFFFFFu) {
-                            if (P_LDS) __hip_atomic_fetch_or(&Pw[t[q] * 2 + half], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            else atomicOr(&Pw[(size_t)t[q] * 2 + half], bit);
+                            const size_t bp = (size_t)t[q] * G + j;              // bit j of element t
+                            if (P_LDS) __hip_atomic_fetch_or(&Pw[bp >> 5], 1u << (bp & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            else atomicOr(&Pw[bp >> 5], 1u << (bp & 31));
                         }
                 }
             }
             if (S.x_off) {
                 const uint64_t x0 = S.x_off[d], x1 = S.x_off[d + 1];
                 for (uint64_t i = x0 + member; i < x1; i += kTeam) {
-                    const uint32_t t = S.x_slot[i];
-                    if (P_LDS) __hip_atomic_fetch_or(&Pw[t * 2 + half], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    else atomicOr(&Pw[(size_t)t * 2 + half], bit);
+                    const size_t bp = (size_t)S.x_slot[i] * G + j;
+                    if (P_LDS) __hip_atomic_fetch_or(&Pw[bp >> 5], 1u << (bp & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else atomicOr(&Pw[bp >> 5], 1u << (bp & 31));
                 }
             }
         }
@@ -304,10 +330,14 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
                     const uint32_t e = PROG_LDS ? lorder[e0 + i] : S.order[e0 + i];
                     const uint64_t po = PROG_LDS ? loff[e] : S.fprog_off[e];
                     const uint32_t len = (uint32_t)((PROG_LDS ? loff[e + 1] : S.fprog_off[e + 1]) - po);
-                    const uint32_t* prog = (PROG_LDS ? lprog : S.fprog) + po;
+                    // programs in LDS: linear; in global memory: the block's 4-word chunks transposed ([chunk][lane]) so
+                    // that the lanes of a wave read consecutive 16-byte pieces
+                    const uint4* prog = reinterpret_cast<const uint4*>(PROG_LDS ? lprog + po : S.fprog_t + S.fblk_off[(e0 >> 6) + b]) +
+                                        (PROG_LDS ? 0 : lane);
+                    const uint32_t stride = PROG_LDS ? 1u : 64u;
                     const bool deep = S.blk_deep[(e0 >> 6) + b] != 0;              // wave-uniform
-                    R[e - e0] = deep ? run_program<P_LDS, true>(S, P, prog, len, valid, d0)
-                                     : run_program<P_LDS, false>(S, P, prog, len, valid, d0);
+                    R[e - e0] = deep ? run_program<P_LDS, true, PT, AT>(S, P, prog, stride, len / 4, (AT)valid, d0)
+                                     : run_program<P_LDS, false, PT, AT>(S, P, prog, stride, len / 4, (AT)valid, d0);
                 }
             }
             __syncthreads();
@@ -333,7 +363,7 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
         if (P_LDS) {
             // LDS: wiping the whole matrix is a handful of wide stores per lane, no HBM re-read of the matches
             uint4* P4 = reinterpret_cast<uint4*>(P);
-            for (uint32_t i = threadIdx.x; i < (S.n_slots + 1) / 2; i += kSolveBlockThreads) P4[i] = make_uint4(0, 0, 0, 0);
+            for (uint32_t i = threadIdx.x; i < (uint32_t)(((size_t)S.n_slots * sizeof(PT) + 15) / 16); i += kSolveBlockThreads) P4[i] = make_uint4(0, 0, 0, 0);
         } else {
             for (uint32_t j = threadIdx.x / kTeam; j < nd; j += kSolveBlockThreads / kTeam) {
                 const uint32_t member = threadIdx.x % kTeam;
@@ -343,12 +373,12 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
                     const uint64_t s = S.unit_start[u];
                     const uint32_t n = S.unit_count[u];
                     for (uint32_t i = member; i < n; i += kTeam)
-                        __hip_atomic_store(&P[S.term[s + i]], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&P[S.term[s + i]], (PT)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 if (S.x_off) {
                     const uint64_t x0 = S.x_off[d], x1 = S.x_off[d + 1];
                     for (uint64_t i = x0 + member; i < x1; i += kTeam)
-                        __hip_atomic_store(&P[S.x_slot[i]], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&P[S.x_slot[i]], (PT)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
             __threadfence_block();
@@ -359,22 +389,34 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
 
 }  // namespace
 
-size_t solve_lds_bytes(uint32_t n_slots, uint32_t tile_words, bool p_in_lds, uint32_t prog_words, uint32_t n_exprs,
-                       bool prog_in_lds) {
-    return (p_in_lds ? (((size_t)n_slots * 8 + 15) & ~(size_t)15) : 0) + (size_t)64 * tile_words * 4 +
+size_t solve_lds_bytes(uint32_t n_slots, uint32_t tile_words, uint32_t group_docs, bool p_in_lds, uint32_t prog_words,
+                       uint32_t n_exprs, bool prog_in_lds) {
+    return (p_in_lds ? (((size_t)n_slots * (group_docs / 8) + 15) & ~(size_t)15) : 0) + (size_t)64 * tile_words * 4 +
            (size_t)tile_words * 32 * 8 + (prog_in_lds ? ((size_t)prog_words + 2 * (size_t)n_exprs + 1) * 4 : 0);
 }
 
-hipError_t launch_solve(const SolveParams& S, bool p_in_lds, bool prog_in_lds, unsigned grid, hipStream_t st) {
-    if (!S.n_docs || !S.n_exprs) return hipSuccess;
-    const size_t lds = solve_lds_bytes(S.n_slots, S.tile_words, p_in_lds, S.fprog_words, S.n_exprs, prog_in_lds);
+namespace {
+template <int G>
+hipError_t launch_g(const SolveParams& S, bool p_in_lds, bool prog_in_lds, unsigned grid, size_t lds, hipStream_t st) {
     using Kern = void (*)(const SolveParams);
-    const Kern fn = p_in_lds ? (prog_in_lds ? k_solve_groups<true, true> : k_solve_groups<true, false>)
-                             : (prog_in_lds ? k_solve_groups<false, true> : k_solve_groups<false, false>);
+    const Kern fn = p_in_lds ? (prog_in_lds ? k_solve_groups<true, true, G> : k_solve_groups<true, false, G>)
+                             : (prog_in_lds ? k_solve_groups<false, true, 64> : k_solve_groups<false, false, 64>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     fn<<<dim3(grid), dim3(kSolveBlockThreads), lds, st>>>(S);
     return hipGetLastError();
+}
+}  // namespace
+
+hipError_t launch_solve(const SolveParams& S, uint32_t group_docs, bool p_in_lds, bool prog_in_lds, unsigned grid, hipStream_t st) {
+    if (!S.n_docs || !S.n_exprs) return hipSuccess;
+    const size_t lds = solve_lds_bytes(S.n_slots, S.tile_words, group_docs, p_in_lds, S.fprog_words, S.n_exprs, prog_in_lds);
+    switch (p_in_lds ? group_docs : 64) {
+    case 64: return launch_g<64>(S, p_in_lds, prog_in_lds, grid, lds, st);
+    case 32: return launch_g<32>(S, p_in_lds, prog_in_lds, grid, lds, st);
+    case 16: return launch_g<16>(S, p_in_lds, prog_in_lds, grid, lds, st);
+    default: return launch_g<8>(S, p_in_lds, prog_in_lds, grid, lds, st);
+    }
 }
 
 }  // namespace gft

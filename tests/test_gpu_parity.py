@@ -258,3 +258,42 @@ def test_large_dictionary_spill_path(eng):
     want = o.process(text, off, fold=True)
     assert np.array_equal(eng.process(text, off, fold=True), want)
     assert np.array_equal(eng.process(text, off, fold=True), want)      # second call: adapted unit size
+
+
+@pytest.mark.parametrize("group_docs", ["32", "16", "8", "0"])
+def test_solver_group_widths(eng, monkeypatch, group_docs):
+    """the solver's narrower document groups (picked when a large dictionary's presence matrix would not fit LDS at 64
+    documents per group) and, with "0" (no width allowed), the HBM-resident presence matrix; ragged last group"""
+    from gofindthem_amd.workload import Workload, make_expressions
+    monkeypatch.setenv("GFT_SOLVE_GROUP_DOCS", group_docs)
+    w = Workload(1000)
+    terms = w.terms()
+    exprs = make_expressions(terms, 200, inord_fraction=0.4)
+    o = both(eng, terms)
+    o.set_expressions(exprs, case_sensitive=False)
+    progs, _ = _programs(o, eng, exprs, False)
+    eng.set_programs(progs)
+    text, off = w.docs_host(0, 403)
+    want = o.process(text, off, fold=True)
+    assert np.array_equal(eng.process(text, off, fold=True), want)
+    assert np.array_equal(eng.process(text, off, fold=True), want)      # presence matrix wiped between groups and calls
+
+
+@pytest.mark.parametrize("group_docs", [None, "16"])
+def test_many_expressions_programs_in_global_memory(eng, monkeypatch, group_docs):
+    """12 000 expressions: the fused programs exceed LDS, so the interpreter reads the per-block transposed copy from
+    global memory; several output tiles per group"""
+    from gofindthem_amd.workload import Workload, make_expressions
+    if group_docs:
+        monkeypatch.setenv("GFT_SOLVE_GROUP_DOCS", group_docs)
+    w = Workload(2000)
+    terms = w.terms()
+    exprs = make_expressions(terms, 12000, inord_fraction=0.2)
+    o = both(eng, terms)
+    o.set_expressions(exprs, case_sensitive=False)
+    progs, _ = _programs(o, eng, exprs, False)
+    assert sum(len(p) for p in progs) * 4 > 160 * 1024
+    eng.set_programs(progs)
+    text, off = w.docs_host(0, 150)
+    want = o.process(text, off, fold=True)
+    assert np.array_equal(eng.process(text, off, fold=True), want)

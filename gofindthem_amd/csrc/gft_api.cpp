@@ -65,7 +65,7 @@ struct gft_engine {
     // suffix-window scan (gft_scan2.hip); the two-tier DFA kernel above stays as the general fallback
     Scan2Tables s2;
     bool use_scan2 = false;
-    DevBuf d_s2_filter, d_s2_slots, d_s2_more, d_s2_cls, d_s2_cls_fold, d_s2_term_blob, d_s2_term_off, d_nmatches, d_dbg;
+    DevBuf d_s2_filter, d_s2_slots, d_s2_more, d_s2_cls, d_s2_cls_fold, d_s2_term_blob, d_s2_term_off, d_nmatches, d_dbg, d_flags;
     DevBuf d_s2_short3, d_s2_shorts_packed, d_s2_short3_big, d_s2_fpt;
     uint32_t scan2_short3_bytes = 0;
     uint32_t scan2_k2_waves = 0, scan2_cand_cap = 0;    // scan2_plan
@@ -341,6 +341,7 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         for (uint64_t d = 0; d < n_docs; d++) {
             if (h_doc_off[d + 1] < h_doc_off[d]) return fail(e, GFT_E_INVALID, "doc_off is not ascending");
             const uint64_t n = h_doc_off[d + 1] - h_doc_off[d];
+            if (n > 0xFFFFFFFFull) return fail(e, GFT_E_UNSUPPORTED, "a document is longer than 4 GiB - 1 bytes (positions are 32-bit)");
             const uint64_t k = n <= unit_max ? 1 : (n + unit_max - 1) / unit_max;
             hub[d + 1] = hub[d] + k;
             const uint64_t per = (n + k - 1) / k;                 // as k_unit_fill
@@ -355,15 +356,20 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
     } else {
         {
             ProfScope ps(e, "aux");
-            HIP_TRY(launch_unit_count(d_doc_off, n_docs, unit_max, e->d_unit_cnt.as<uint32_t>(), st), "unit_count");
+            HIP_TRY(e->d_flags.ensure(8), "flag alloc");
+            HIP_TRY(hipMemsetAsync(e->d_flags.p, 0, 8, st), "memset");
+            HIP_TRY(launch_unit_count(d_doc_off, n_docs, unit_max, e->d_unit_cnt.as<uint32_t>(), e->d_flags.as<uint32_t>(), st), "unit_count");
             HIP_TRY(launch_exclusive_scan(e->d_unit_cnt.as<uint32_t>(), n_docs, e->d_unit_base.as<uint64_t>(),
                                           e->d_partial.as<uint64_t>(), st), "unit scan");
         }
         HIP_TRY(hipMemcpyAsync(&n_units, e->d_unit_base.as<uint64_t>() + n_docs, 8, hipMemcpyDeviceToHost, st), "readback");
         HIP_TRY(hipMemcpyAsync(&text_lo, d_doc_off, 8, hipMemcpyDeviceToHost, st), "readback");
         HIP_TRY(hipMemcpyAsync(&text_hi, d_doc_off + n_docs, 8, hipMemcpyDeviceToHost, st), "readback");
+        uint32_t bad_doc = 0;
+        HIP_TRY(hipMemcpyAsync(&bad_doc, e->d_flags.p, 4, hipMemcpyDeviceToHost, st), "readback");
         HIP_TRY(hipStreamSynchronize(st), "sync");
         if (text_hi < text_lo) return fail(e, GFT_E_INVALID, "doc_off is not ascending");
+        if (bad_doc) return fail(e, GFT_E_INVALID, "doc_off is not ascending, or a document is longer than 4 GiB - 1 bytes (positions are 32-bit)");
     }
 
     HIP_TRY(e->d_units.ensure(n_units * sizeof(Unit)), "unit alloc");
@@ -623,7 +629,7 @@ void gft_engine_destroy(gft_engine* e) {
         DevBuf* all[] = {&e->d_byte_class, &e->d_delta, &e->d_out_term, &e->d_out_link, &e->d_term_len, &e->d_prog,
                          &e->d_prog_off, &e->d_fprog, &e->d_fprog_off, &e->d_groups, &e->d_order, &e->d_blk_deep, &e->d_fprog_t, &e->d_fblk_off, &e->d_pscratch, &e->d_s2_filter,
                          &e->d_s2_slots, &e->d_s2_more, &e->d_s2_cls, &e->d_s2_cls_fold, &e->d_s2_term_blob,
-                         &e->d_s2_term_off, &e->d_nmatches, &e->d_dbg, &e->d_s2_short3, &e->d_s2_shorts_packed, &e->d_s2_short3_big, &e->d_s2_fpt,
+                         &e->d_s2_term_off, &e->d_nmatches, &e->d_dbg, &e->d_flags, &e->d_s2_short3, &e->d_s2_shorts_packed, &e->d_s2_short3_big, &e->d_s2_fpt,
 &e->d_unit_cnt, &e->d_unit_base, &e->d_units, &e->d_partial, &e->d_cursor,
                          &e->d_pool_term, &e->d_pool_pos, &e->d_unit_start, &e->d_unit_count, &e->d_unit_out,
                          &e->d_term, &e->d_pos, &e->d_match_off, &e->d_text, &e->d_doc_off, &e->d_bitmap, &e->d_xoff,

@@ -34,10 +34,13 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
 // work units
 // ------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_unit_count(const uint64_t* __restrict__ doc_off, uint64_t n_docs,
-                                                    uint32_t unit_max, uint32_t* __restrict__ cnt) {
+                                                    uint32_t unit_max, uint32_t* __restrict__ cnt,
+                                                    uint32_t* __restrict__ bad) {
     uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= n_docs) return;
     uint64_t n = doc_off[d + 1] - doc_off[d];
+    // positions are u32 offsets into the document: longer documents (and descending offsets, which wrap) are refused
+    if (n > 0xFFFFFFFFull) { atomicOr(bad, 1u); n = 0; }
     cnt[d] = n <= unit_max ? 1u : (uint32_t)((n + unit_max - 1) / unit_max);
 }
 
@@ -317,9 +320,9 @@ inline unsigned grid_for(uint64_t n, unsigned per_block, unsigned cap) {
 // launchers
 // ------------------------------------------------------------------------------------------------------
 hipError_t launch_unit_count(const uint64_t* d_doc_off, uint64_t n_docs, uint32_t unit_max, uint32_t* d_cnt,
-                             hipStream_t st) {
+                             uint32_t* d_bad, hipStream_t st) {
     if (!n_docs) return hipSuccess;
-    k_unit_count<<<dim3((unsigned)((n_docs + 255) / 256)), dim3(256), 0, st>>>(d_doc_off, n_docs, unit_max, d_cnt);
+    k_unit_count<<<dim3((unsigned)((n_docs + 255) / 256)), dim3(256), 0, st>>>(d_doc_off, n_docs, unit_max, d_cnt, d_bad);
     return hipGetLastError();
 }
 

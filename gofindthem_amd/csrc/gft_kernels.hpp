@@ -229,8 +229,9 @@ bool scan2_plan(uint32_t filter_words, uint32_t short3_bytes, uint32_t shorts_wo
                 uint32_t* waves, uint32_t* cand_cap);
 hipError_t launch_scan2(const Scan2Params& P, uint32_t waves, unsigned n_cus, hipStream_t st);
 
+// *d_bad |= 1 when a document is longer than 2^32 - 1 bytes (or its offsets descend); such documents get zero units
 hipError_t launch_unit_count(const uint64_t* d_doc_off, uint64_t n_docs, uint32_t unit_max, uint32_t* d_cnt,
-                             hipStream_t st);
+                             uint32_t* d_bad, hipStream_t st);
 hipError_t launch_unit_fill(const uint64_t* d_doc_off, uint64_t n_docs, const uint64_t* d_unit_base, Unit* d_units,
                             hipStream_t st);
 uint64_t scan_partials_needed(uint64_t n);

@@ -297,3 +297,46 @@ def test_many_expressions_programs_in_global_memory(eng, monkeypatch, group_docs
     text, off = w.docs_host(0, 150)
     want = o.process(text, off, fold=True)
     assert np.array_equal(eng.process(text, off, fold=True), want)
+
+
+@pytest.mark.parametrize("pos_mode", [POS_START, POS_END])
+def test_reference_benchmark_shape_single_large_document(eng, pos_mode):
+    """BASELINE configs[0]: ~50 terms, 3 expressions and ONE document of ~100 000 words (~1 MB), the
+    shape benchmarks/benchmark_test.go:66,273,287,449-460 measures; the document spans hundreds of work units, so
+    matches across unit borders, the per-document merge of the units and INORD over 32-bit positions are all exercised.
+    Second batch: the same text cut into empty, large and small documents."""
+    from gofindthem_amd.workload import Workload
+    w = Workload(50)
+    terms = w.terms()
+    text, off = w.docs_host(0, 250)
+    assert 900_000 < int(off[-1]) < 1_300_000
+    o = both(eng, terms, pos_mode)
+    t = [x.decode() for x in terms]
+    exprs = ['"%s" and "%s"' % (t[0], t[1]),
+             'INORD("%s" and "%s") and INORD("%s" and "%s")' % (t[2], t[3], t[3], t[2]),
+             "INORD(" + " and ".join('"%s"' % x for x in t[4:49]) + ")"]
+    o.set_expressions(exprs, case_sensitive=False)
+    progs, extra = _programs(o, eng, exprs, False)
+    assert not extra
+    eng.set_programs(progs)
+    one = np.array([0, off[-1]], dtype=np.uint64)
+    cut = np.array([0, 0, off[100], off[100], off[101], off[-1], off[-1]], dtype=np.uint64)
+    for offsets in (one, cut):
+        want = o.scan(text, offsets, fold=True)
+        assert_csr_equal(eng.scan(text, offsets, fold=True), want)
+        assert np.array_equal(eng.process(text, offsets, fold=True), o.process(text, offsets, fold=True))
+    assert int(o.process(text, one, fold=True)[0, 0]) & 3 == 3          # the plain AND and both orders: all true on 1 MB
+
+
+def test_descending_offsets_are_refused_on_the_device_unit_path(eng):
+    """more documents than the host-side unit table handles (kHostUnitDocs): the unit kernel flags offsets that descend
+    (the same flag refuses documents of 4 GiB and more, whose positions would not fit 32 bits)"""
+    from gofindthem_amd.engine import GftError
+    both(eng, [b"ab", b"abc"])
+    blob, off = docs(["xxabcxx"] * 3000)
+    eng.scan(blob, off)
+    bad = off.copy()
+    bad[1500] = bad[1501] + 3
+    with pytest.raises(GftError):
+        eng.scan(blob, bad)
+    assert_csr_equal(eng.scan(blob, off), Oracle([b"ab", b"abc"], POS_START).scan(blob, off))

@@ -35,79 +35,113 @@ struct DocHits {
     uint32_t nx;
 };
 
-// first position of `slot` that is > theta (theta == -1: any), or INT64_MAX.  A keyword and a regex with the same
-// literal share one map key (finder/finder.go:181-196): the caller maps both onto one slot, both lists are read.
-__device__ int64_t succ_query(const DocHits& M, uint32_t slot, int64_t theta) {
-    int64_t best = INT64_MAX;
-    for (uint64_t u = M.u0; u < M.u1; u++) {
-        const uint64_t s = M.unit_start[u];
-        const uint32_t n = M.unit_count[u];
-        for (uint32_t i = 0; i < n; i++)
-            if (M.term[s + i] == slot) {
-                const int64_t p = M.pos[s + i];
-                if (p > theta && p < best) best = p;
-            }
+constexpr uint32_t kNoSlot = 0xFFFFFFFFu;      // pair that never matches: the empty position list
+constexpr uint32_t kUnitsPerLaneMode = 8;      // documents with at least this many units: one unit per lane
+
+__device__ __forceinline__ int64_t wave_min_i64(int64_t v) {
+#pragma unroll
+    for (int s = 32; s; s >>= 1) {
+        const int64_t o = __shfl_xor(v, s, 64);
+        v = o < v ? o : v;
     }
-    for (uint32_t i = 0; i < M.nx; i++)
-        if (M.xslot[i] == slot) {
-            const int64_t p = M.xpos[i];
-            if (p > theta && p < best) best = p;
-        }
-    return best;
+    // the same value in every lane: tell the compiler, so that what is derived from it stays in scalar registers
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ int64_t readlane_i64(int64_t v, uint32_t l) {
+    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, l), hi = __builtin_amdgcn_readlane((uint32_t)((uint64_t)v >> 32), l);
+    return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
-struct Pair { uint32_t slot; int32_t theta; };
+// The pairs (slot, theta) of an INORD group live one per lane (pair i in lane i; kMaxPairs == 64).  All 64 lanes call
+// this together: min over the pairs [pb, pb + pc) of succ(slot, theta) = the first position of `slot` that is > theta
+// (INT64_MAX if none).  The document's matches are read ONCE per call, spread over the lanes: documents of many units
+// (a 1 MB document is > 100 units) give every lane whole units, small documents are strided inside each unit.  A
+// keyword and a regex with the same literal share one map key (finder/finder.go:181-196): the caller maps both onto
+// one slot, both lists are read.
+__device__ int64_t wave_succ_min(const DocHits& M, uint32_t my_slot, int64_t my_theta, uint32_t pb, uint32_t pc) {
+    const uint32_t lane = lane_id();
+    int64_t best = INT64_MAX;
+    const uint32_t sl0 = __builtin_amdgcn_readlane(my_slot, pb);
+    const int64_t th0 = readlane_i64(my_theta, pb);
+    auto test = [&](uint32_t t, uint32_t p) {
+        if (t == sl0 && (int64_t)p > th0 && (int64_t)p < best) best = p;
+        for (uint32_t k = 1; k < pc; k++) {
+            const uint32_t sl = __builtin_amdgcn_readlane(my_slot, pb + k);
+            const int64_t th = readlane_i64(my_theta, pb + k);
+            if (t == sl && (int64_t)p > th && (int64_t)p < best) best = p;
+        }
+    };
+    if (M.u1 - M.u0 >= kUnitsPerLaneMode) {
+        for (uint64_t u = M.u0 + lane; u < M.u1; u += 64) {
+            const uint64_t s = M.unit_start[u];
+            const uint32_t n = M.unit_count[u];
+            uint32_t i = 0;
+            for (; i + 4 <= n; i += 4) {                         // four matches in flight per lane
+                uint32_t t[4], p[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) { t[q] = M.term[s + i + q]; p[q] = M.pos[s + i + q]; }
+#pragma unroll
+                for (int q = 0; q < 4; q++) test(t[q], p[q]);
+            }
+            for (; i < n; i++) test(M.term[s + i], M.pos[s + i]);
+        }
+    } else {
+        for (uint64_t u = M.u0; u < M.u1; u++) {
+            const uint64_t s = M.unit_start[u];
+            const uint32_t n = M.unit_count[u];
+            for (uint32_t i = lane; i < n; i += 64) test(M.term[s + i], M.pos[s + i]);
+        }
+    }
+    for (uint32_t i = lane; i < M.nx; i += 64) test(M.xslot[i], M.xpos[i]);
+    return wave_min_i64(best);
+}
 
-// Position algebra of one INORD group for one document (dsl/expression.go:87-95,111-116,129-137).  `prog` is the
-// group's subtree in the public postfix form (UNIT/AND/OR words carrying GFT_K_INORD_FLAG).  Returns len(rpos) > 0.
+// Position algebra of one INORD group for one document (dsl/expression.go:87-95,111-116,129-137), evaluated by a whole
+// wave.  `prog` is the group's subtree in the public postfix form (UNIT/AND/OR words carrying GFT_K_INORD_FLAG); control
+// flow is wave-uniform.  Returns len(rpos) > 0.
 //   UNIT t    -> {(t, -1)}
 //   OR        -> union of the pair sets (only minimum and emptiness are ever observed, duplicates are harmless)
 //   AND(L, R) -> m = min over L of succ(t, theta); {} if m = +inf, else {(t, max(theta, m)) : (t, theta) in R}
 //                == rpos[getLowestIdxGTVal(rpos, lpos[0]):]   (expression.go:87-93,175-189)
-__device__ bool inord_group_nonempty(const uint32_t* __restrict__ prog, uint32_t len, const DocHits& M) {
-    Pair pairs[kMaxPairs];
-    uint16_t rbeg[kMaxPairDepth], rcnt[kMaxPairDepth];
-    uint32_t psp = 0;
+// The operand stack is a sequence of adjacent, non-empty pair ranges [.., top): bit b of `starts` = a range starts at
+// pair b.  The empty list is the single pair (kNoSlot, -1), which no match satisfies.
+__device__ bool inord_group_wave(const uint32_t* __restrict__ prog, uint32_t len, const DocHits& M) {
+    const uint32_t lane = lane_id();
+    uint32_t my_slot = kNoSlot;
+    int64_t my_theta = -1;
+    uint64_t starts = 0;
+    uint32_t top = 0;
     for (uint32_t pc = 0; pc < len; pc++) {
         const uint32_t w = prog[pc];
-        switch (w >> 28) {
-        case 1: {  // UNIT
-            const uint32_t b = psp ? rbeg[psp - 1] + rcnt[psp - 1] : 0;
-            pairs[b] = Pair{w & GFT_K_SLOT_MASK, -1};
-            rbeg[psp] = (uint16_t)b; rcnt[psp] = 1; psp++;
-            break;
-        }
-        case 2: {  // AND
-            const uint32_t lb = rbeg[psp - 2], lc = rcnt[psp - 2], rb = rbeg[psp - 1], rc = rcnt[psp - 1];
-            int64_t m = INT64_MAX;
-            for (uint32_t i = 0; i < lc; i++) {
-                const int64_t s = succ_query(M, pairs[lb + i].slot, pairs[lb + i].theta);
-                if (s < m) m = s;
+        const uint32_t op = w >> 28;
+        if (op == 1) {                                           // UNIT
+            if (lane == top) { my_slot = w & GFT_K_SLOT_MASK; my_theta = -1; }
+            starts |= 1ull << top;
+            top++;
+        } else if (op == 2) {                                    // AND
+            const uint32_t rb = 63u - (uint32_t)__builtin_clzll(starts);
+            const uint64_t rest = starts & ~(1ull << rb);
+            const uint32_t lb = 63u - (uint32_t)__builtin_clzll(rest);
+            const uint32_t lc = rb - lb, rc = top - rb;
+            const int64_t m = wave_succ_min(M, my_slot, my_theta, lb, lc);
+            const uint32_t r_slot = __shfl(my_slot, (int)((lane + lc) & 63u), 64);   // R's pairs move down to lb
+            const int64_t r_theta = __shfl(my_theta, (int)((lane + lc) & 63u), 64);
+            if (m == INT64_MAX) {
+                if (lane == lb) { my_slot = kNoSlot; my_theta = -1; }
+                top = lb + 1;
+            } else {
+                if (lane >= lb && lane < lb + rc) { my_slot = r_slot; my_theta = r_theta < m ? m : r_theta; }
+                top = lb + rc;
             }
-            uint32_t nc = 0;
-            if (m != INT64_MAX)
-                for (uint32_t i = 0; i < rc; i++) {
-                    Pair q = pairs[rb + i];
-                    if ((int64_t)q.theta < m) q.theta = (int32_t)m;
-                    pairs[lb + nc++] = q;
-                }
-            psp--;
-            rcnt[psp - 1] = (uint16_t)nc;
-            break;
-        }
-        case 3:  // OR: the two ranges are adjacent, union == concatenation
-            psp--;
-            rcnt[psp - 1] = (uint16_t)(rcnt[psp - 1] + rcnt[psp]);
-            break;
-        default:
-            break;
+            starts = rest;
+        } else if (op == 3) {                                    // OR: the two ranges are adjacent, union == concatenation
+            starts &= ~(1ull << (63u - (uint32_t)__builtin_clzll(starts)));
         }
     }
-    if (!psp) return false;
-    const uint32_t b = rbeg[psp - 1], c = rcnt[psp - 1];
-    for (uint32_t i = 0; i < c; i++)
-        if (succ_query(M, pairs[b + i].slot, pairs[b + i].theta) != INT64_MAX) return true;
-    return false;
+    if (!top) return false;
+    const uint32_t b = 63u - (uint32_t)__builtin_clzll(starts);
+    return wave_succ_min(M, my_slot, my_theta, b, top - b) != INT64_MAX;
 }
 
 // 64 x 64 bit-matrix transpose across a wave: lane i holds row i; afterwards lane j holds column j (bit i = old row
@@ -128,24 +162,37 @@ __device__ __forceinline__ uint64_t wave_transpose64(uint64_t x) {
     return x;
 }
 
-// documents of `cand` (bit j = document d0 + j) whose INORD group `grp` has a non-empty position list
-__device__ uint64_t inord_docs(const SolveParams& S, uint32_t grp, uint64_t cand, uint64_t d0) {
+// INORD words of a wave's current program step.  All 64 lanes call this together; `is_inord` marks the lanes whose word
+// closes a group (operand `grp`), `cand` their candidate documents (bit j = document d0 + j: the documents where the
+// group's boolean value is true, rval of expression.go:137).  The (lane, document) pairs are taken one after the other
+// and each is evaluated by the whole wave, so a large document's matches are scanned 64 wide and a wave with few
+// candidates does not leave 63 lanes idle.  Returns the documents whose position list is non-empty.
+__device__ __forceinline__ uint64_t inord_wave(const SolveParams& S, bool is_inord, uint32_t grp, uint64_t cand, uint64_t d0) {
+    const uint32_t lane = lane_id();
     uint64_t res = 0;
-    const uint32_t goff = S.groups[grp * 2], glen = S.groups[grp * 2 + 1];
-    while (cand) {
-        const uint32_t j = (uint32_t)__builtin_ctzll(cand);
-        cand &= cand - 1;
-        const uint64_t d = d0 + j;
-        DocHits M;
-        M.unit_start = S.unit_start; M.unit_count = S.unit_count;
-        M.term = S.term; M.pos = S.pos;
-        M.u0 = S.doc_unit_base[d]; M.u1 = S.doc_unit_base[d + 1];
-        M.nx = 0; M.xslot = nullptr; M.xpos = nullptr;
-        if (S.x_off) {
-            const uint64_t x0 = S.x_off[d];
-            M.xslot = S.x_slot + x0; M.xpos = S.x_pos + x0; M.nx = (uint32_t)(S.x_off[d + 1] - x0);
+    uint64_t todo = __ballot(is_inord && cand != 0);
+    while (todo) {
+        const uint32_t L = (uint32_t)__builtin_ctzll(todo);
+        todo &= todo - 1;
+        const uint32_t g = __builtin_amdgcn_readlane(grp, L);
+        uint64_t c = (uint64_t)readlane_i64((int64_t)cand, L);
+        const uint32_t goff = S.groups[g * 2], glen = S.groups[g * 2 + 1];
+        while (c) {
+            const uint32_t j = (uint32_t)__builtin_ctzll(c);
+            c &= c - 1;
+            const uint64_t d = d0 + j;
+            DocHits M;
+            M.unit_start = S.unit_start; M.unit_count = S.unit_count;
+            M.term = S.term; M.pos = S.pos;
+            M.u0 = S.doc_unit_base[d]; M.u1 = S.doc_unit_base[d + 1];
+            M.nx = 0; M.xslot = nullptr; M.xpos = nullptr;
+            if (S.x_off) {
+                const uint64_t x0 = S.x_off[d];
+                M.xslot = S.x_slot + x0; M.xpos = S.x_pos + x0; M.nx = (uint32_t)(S.x_off[d + 1] - x0);
+            }
+            const bool r = inord_group_wave(S.gprog + goff, glen, M);
+            if (r && lane == L) res |= 1ull << j;
         }
-        if (inord_group_nonempty(S.gprog + goff, glen, M)) res |= 1ull << j;
     }
     return res;
 }
@@ -154,6 +201,8 @@ __device__ uint64_t inord_docs(const SolveParams& S, uint32_t grp, uint64_t cand
 // programs, so the interpreter is predicated rather than branched: every word costs one presence read and a handful of
 // selects.  DEEP = false keeps the accumulator stack in two registers (programs that nest deeper are sorted into
 // blocks of their own and take DEEP = true: four registers backed by scratch).
+// ALL 64 lanes of a wave call this together (lanes without a program pass chunks = 0): the trip count is the wave's
+// maximum, finished lanes run kFopNop words, so the INORD steps can use the whole wave.
 template <bool P_LDS, bool DEEP, class PT, class AT>
 __device__ __forceinline__ AT run_program(const SolveParams& S, const PT* P, const uint4* prog, uint32_t stride, uint32_t chunks,
                                           AT valid, uint64_t d0) {
@@ -163,11 +212,20 @@ __device__ __forceinline__ AT run_program(const SolveParams& S, const PT* P, con
     };
     AT acc = 0, s0 = 0, s1 = 0, s2 = 0, s3 = 0, deep[DEEP ? kMaxBoolDepth : 1];
     uint32_t sp = 0;
-    uint4 nx = chunks ? prog[0] : make_uint4(0, 0, 0, 0);
+    constexpr uint32_t kNop = (uint32_t)kFopNop << 28;
+    uint4 nx = chunks ? prog[0] : make_uint4(kNop, kNop, kNop, kNop);
+    uint32_t wchunks = chunks;
+#pragma unroll
+    for (int sh = 32; sh; sh >>= 1) {
+        const uint32_t o = __shfl_xor(wchunks, sh, 64);
+        wchunks = o > wchunks ? o : wchunks;
+    }
+    wchunks = __builtin_amdgcn_readfirstlane(wchunks);
     // four words per trip: the next chunk and this chunk's four presence reads are in flight together, so a trip
     // exposes one memory round trip instead of four (programs are padded to whole chunks with kFopNop)
-    for (uint32_t c = 0; c < chunks; c++) {
+    for (uint32_t c = 0; c < wchunks; c++) {
         const uint32_t w[4] = {nx.x, nx.y, nx.z, nx.w};
+        nx = make_uint4(kNop, kNop, kNop, kNop);
         if (c + 1 < chunks) nx = prog[(size_t)(c + 1) * stride];
         AT pv[4];
         bool rare = false;
@@ -178,11 +236,10 @@ __device__ __forceinline__ AT run_program(const SolveParams& S, const PT* P, con
             rare |= op == kFopNot || op == kFopInord;
         }
         const bool any_rare = __any(rare);                      // wave-uniform: only around INORD groups
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const uint32_t op = w[q] >> 28, a = w[q] & 0x0FFFFFFFu;
+        auto step = [&](const uint32_t wq, const AT pvq, const bool with_rare) __attribute__((always_inline)) {
+            const uint32_t op = wq >> 28, a = wq & 0x0FFFFFFFu;
             const bool is_s = op < kFopAndPop;
-            const AT v = pv[q] ^ (AT)(0 - (AT)((op >> 2) & 1)); // SetN / AndNS / OrNS (bits past the group are never stored)
+            const AT v = pvq ^ (AT)(0 - (AT)((op >> 2) & 1));   // SetN / AndNS / OrNS (bits past the group are never stored)
             const uint32_t k = op & 3;
             const AT t = k == 3 ? (acc | v) : (acc & v);
             const AT sacc = k == 1 ? v : t;
@@ -206,10 +263,23 @@ __device__ __forceinline__ AT run_program(const SolveParams& S, const PT* P, con
                     if (sp >= 4) s3 = deep[sp - 4];
                 }
             }
-            if (any_rare) {
+            if (with_rare) {
                 if (op == kFopNot) acc = ~acc;
                 // candidates: documents where the group's boolean value is true (rval, expression.go:137)
-                if (op == kFopInord) acc = (AT)inord_docs(S, a, (uint64_t)(acc & valid), d0);
+                const AT in = (AT)inord_wave(S, op == kFopInord, a, (uint64_t)(acc & valid), d0);
+                if (op == kFopInord) acc = in;
+            }
+        };
+        if (!any_rare) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) step(w[q], pv[q], false);
+        } else {
+            // one copy of the INORD code: the chunk's words one after the other in a rolled loop
+#pragma nounroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t wq = q == 0 ? w[0] : q == 1 ? w[1] : q == 2 ? w[2] : w[3];
+                const AT pvq = q == 0 ? pv[0] : q == 1 ? pv[1] : q == 2 ? pv[2] : pv[3];
+                step(wq, pvq, true);
             }
         }
     }
@@ -326,8 +396,9 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
                 const uint32_t row = wave >> 2, c4 = wave & 3;
                 const uint32_t b = b16 + row * 4 + ((row & 1) ? 3 - c4 : c4);
                 const uint32_t i = b * 64 + lane;
-                if (b < nblk && i < ne) {
-                    const uint32_t e = PROG_LDS ? lorder[e0 + i] : S.order[e0 + i];
+                if (b < nblk) {                                                   // wave-uniform
+                    const bool has = i < ne;                                      // lanes past the tile: no program
+                    const uint32_t e = PROG_LDS ? lorder[e0 + (has ? i : 0)] : S.order[e0 + (has ? i : 0)];
                     const uint64_t po = PROG_LDS ? loff[e] : S.fprog_off[e];
                     const uint32_t len = (uint32_t)((PROG_LDS ? loff[e + 1] : S.fprog_off[e + 1]) - po);
                     // programs in LDS: linear; in global memory: the block's 4-word chunks transposed ([chunk][lane]) so
@@ -336,8 +407,10 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
                                         (PROG_LDS ? 0 : lane);
                     const uint32_t stride = PROG_LDS ? 1u : 64u;
                     const bool deep = S.blk_deep[(e0 >> 6) + b] != 0;              // wave-uniform
-                    R[e - e0] = deep ? run_program<P_LDS, true, PT, AT>(S, P, prog, stride, len / 4, (AT)valid, d0)
-                                     : run_program<P_LDS, false, PT, AT>(S, P, prog, stride, len / 4, (AT)valid, d0);
+                    const uint32_t chunks = has ? len / 4 : 0;
+                    const AT r = deep ? run_program<P_LDS, true, PT, AT>(S, P, prog, stride, chunks, (AT)valid, d0)
+                                      : run_program<P_LDS, false, PT, AT>(S, P, prog, stride, chunks, (AT)valid, d0);
+                    if (has) R[e - e0] = r;
                 }
             }
             __syncthreads();

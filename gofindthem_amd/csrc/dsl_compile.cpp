@@ -197,17 +197,24 @@ std::vector<std::string> RegexRequiredLiterals(const std::string& p, size_t min_
 }
 
 bool IsAscii(const std::string& s) {
-    for (unsigned char c : s) if (c >= 0x80) return false;
-    return true;
+    unsigned char acc = 0;
+    for (unsigned char c : s) acc |= c;
+    return acc < 0x80;
 }
 
 std::string ToLower(const std::string& s) {
     std::string out;
-    out.reserve(s.size());
     if (IsAscii(s)) {
-        for (unsigned char c : s) out.push_back((char)((c >= 'A' && c <= 'Z') ? c + 32 : c));
+        out.resize(s.size());
+        const char* in = s.data();
+        char* o = &out[0];
+        for (size_t i = 0; i < s.size(); i++) {                  // branch-free: vectorises
+            const unsigned char c = (unsigned char)in[i];
+            o[i] = (char)(c + (((unsigned char)(c - 'A') < 26) ? 32 : 0));
+        }
         return out;
     }
+    out.reserve(s.size());
     for (size_t i = 0; i < s.size();) {
         size_t adv;
         int32_t cp = decode_rune(s, i, &adv);

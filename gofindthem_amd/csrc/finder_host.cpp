@@ -130,13 +130,19 @@ bool Finder::prefilter_active() const {
     return rgx_required_.size() == regexes_.size();
 }
 
-std::vector<std::string> Finder::device_dictionary() const {
-    std::vector<std::string> dict = keywords_;
-    if (prefilter_active())
+const std::vector<std::string>& Finder::device_dictionary() const {
+    // rebuilt only when a literal was added or the prefilter switched (both lists only ever grow): ProcessText asks
+    // for it on every call
+    const bool active = prefilter_active();
+    if (dev_dict_ok_ && dev_dict_kw_ == keywords_.size() && dev_dict_rx_ == regexes_.size() && dev_dict_active_ == active) return dev_dict_;
+    dev_dict_ = keywords_;
+    if (active)
         for (const auto& r : rgx_required_)
             for (const auto& lit : r)
-                if (!kw_set_.count(lit) && std::find(dict.begin() + (long)keywords_.size(), dict.end(), lit) == dict.end()) dict.push_back(lit);
-    return dict;
+                if (!kw_set_.count(lit) && std::find(dev_dict_.begin() + (long)keywords_.size(), dev_dict_.end(), lit) == dev_dict_.end())
+                    dev_dict_.push_back(lit);
+    dev_dict_ok_ = true; dev_dict_kw_ = keywords_.size(); dev_dict_rx_ = regexes_.size(); dev_dict_active_ = active;
+    return dev_dict_;
 }
 
 Error Finder::fail_gft(int rc) {
@@ -212,7 +218,7 @@ void Finder::add_matches(const std::vector<Match>& ms, std::vector<Record>& out)
 // (finder/finder.go:146-176).  Matches are appended to `pending` and mapped to slots after sync_device().
 Error Finder::collect(const std::string& text, bool run_sub, std::vector<Record>& out, bool run_rgx) {
     std::vector<Match> all;
-    const std::vector<std::string> dict = gpu_sub_ ? device_dictionary() : keywords_;
+    const std::vector<std::string>& dict = gpu_sub_ ? device_dictionary() : keywords_;
     if (!dict.empty()) {
         if (!updatedSubMachine) {
             Error err = subEng_->BuildEngine(dict, caseSensitive_);
@@ -271,7 +277,13 @@ static bool all_ascii(const uint8_t* p, uint64_t n) {
 Error Finder::ProcessText(const std::string& text_in, std::vector<ExpressionResult>& expRes) {
     expRes.clear();
     last_code_ = 0;
-    const std::string text = caseSensitive_ ? text_in : dsl::ToLower(text_in);
+    // strings.ToLower (finder.go:140-142).  ASCII text that only the device reads (GPU substring engine, no regex terms)
+    // is folded by the scan kernel while it is read; anything else is lower-cased here first (it may change byte lengths)
+    const bool host_engines = !gpu_sub_ || !regexes_.empty();
+    const bool fold_on_device = !caseSensitive_ && !host_engines && all_ascii((const uint8_t*)text_in.data(), text_in.size());
+    std::string lowered;
+    if (!caseSensitive_ && !fold_on_device) lowered = dsl::ToLower(text_in);
+    const std::string& text = (caseSensitive_ || fold_on_device) ? text_in : lowered;
     std::vector<Record> recs;
     Error err = collect(text, !gpu_sub_, recs);
     if (!err.empty()) return err;
@@ -282,7 +294,7 @@ Error Finder::ProcessText(const std::string& text_in, std::vector<ExpressionResu
     gft_extra_matches x{xoff, xs.data(), xp.data()};
     const size_t words = (total_programs() + 31) / 32;        // hidden prefilter programs sit behind the user's
     std::vector<uint32_t> bm(std::max<size_t>(words, 1), 0);
-    int rc = gft_process(gpu_->handle(), (const uint8_t*)text.data(), doff, 1, 0, &x, bm.data());
+    int rc = gft_process(gpu_->handle(), (const uint8_t*)text.data(), doff, 1, fold_on_device ? GFT_FOLD_ASCII : 0, &x, bm.data());
     if (rc) return fail_gft(rc);
     for (size_t i = 0; i < expressions_.size(); i++)
         if (bm[i >> 5] >> (i & 31) & 1)

@@ -137,7 +137,10 @@ private:
     // join the device dictionary.  A batch is then solved once without regex hits, the host regex engine runs only on
     // the documents whose hidden programs fired, and the solver runs again (scan reused) if any of them matched.
     bool prefilter_active() const;
-    std::vector<std::string> device_dictionary() const;     // keywords (+ hidden literals when the prefilter is active)
+    const std::vector<std::string>& device_dictionary() const;   // keywords (+ hidden literals when the prefilter is active)
+    mutable std::vector<std::string> dev_dict_;
+    mutable bool dev_dict_ok_ = false, dev_dict_active_ = false;
+    mutable size_t dev_dict_kw_ = 0, dev_dict_rx_ = 0;
     size_t total_programs() const { return expressions_.size() + (prefilter_active() ? regexes_.size() : 0); }
     std::vector<std::vector<std::string>> rgx_required_;    // per regex: literal runs every match contains
 

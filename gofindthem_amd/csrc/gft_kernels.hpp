@@ -79,6 +79,7 @@ struct SolveParams {
     const uint32_t* gprog;       // public postfix words (INORD group subtrees are interpreted from these)
     const uint32_t* groups;      // [n_groups][2] = offset, length into gprog
     const uint32_t* order;       // [n_exprs] evaluation order inside every output tile (gft_set_programs)
+    const Unit* units;           // the scan's work units (document of every unit)
     const uint32_t* blk_deep;    // per 64 sorted programs: 1 = some program nests deeper than kSolveRegStack
     const uint32_t* fprog_t;     // the same programs per sorted block, transposed by chunk: words 4c..4c+3 of lane l at fblk_off[b] + (c * 64 + l) * 4
     const uint32_t* fblk_off;    // (read when the programs do not fit LDS: coalesced instead of one stream per lane)

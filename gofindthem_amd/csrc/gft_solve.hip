@@ -302,7 +302,7 @@ template <bool P_LDS, bool PROG_LDS, int G>
 __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const SolveParams S) {
     using PT = typename PType<G>::type;
     using AT = typename AType<G>::type;                         // document masks of the evaluation
-    constexpr uint32_t kTeam = kSolveBlockThreads / G;          // lanes that share one document while P is built
+    constexpr uint32_t kTeam = 16, kTeams = kSolveBlockThreads / kTeam;   // lanes that share one unit while P is built
     extern __shared__ __align__(16) uint8_t smem[];
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
     constexpr uint32_t kWaves = kSolveBlockThreads / 64;
@@ -328,15 +328,19 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
     __syncthreads();
 
     const uint64_t n_groups = (S.n_docs + G - 1) / G;
-    // unit range + first slab of this thread's document in the NEXT group (consumed by step 1 of that group)
-    uint64_t pf_u0 = 0, pf_u1 = 0, pf_s = 0;
-    uint32_t pf_n = 0;
+    // The units of a group's documents are consecutive (doc_unit_base), so the presence matrix is built unit by unit:
+    // a team of kTeam lanes per unit, kTeams units at once -- a document of many units (a 1 MB document is > 100) is
+    // spread over the whole workgroup instead of queueing behind one team.  This thread's first unit of the NEXT group
+    // (range of units, slab, count, document) is fetched while the current group is evaluated (pf_*).
+    uint64_t pf_U0 = 0, pf_U1 = 0, pf_s = 0;
+    uint32_t pf_n = 0, pf_doc = 0;
     auto prefetch = [&](uint64_t g) {
-        const uint64_t d = g * G + threadIdx.x / kTeam;
-        pf_u0 = pf_u1 = 0; pf_n = 0;
-        if (g < n_groups && d < S.n_docs) {
-            pf_u0 = S.doc_unit_base[d]; pf_u1 = S.doc_unit_base[d + 1];
-            if (pf_u1 > pf_u0) { pf_s = S.unit_start[pf_u0]; pf_n = S.unit_count[pf_u0]; }
+        pf_U0 = pf_U1 = 0; pf_n = 0;
+        if (g < n_groups) {
+            const uint64_t da = g * G, db = da + G < S.n_docs ? da + G : S.n_docs;
+            pf_U0 = S.doc_unit_base[da]; pf_U1 = S.doc_unit_base[db];
+            const uint64_t u = pf_U0 + threadIdx.x / kTeam;
+            if (u < pf_U1) { pf_s = S.unit_start[u]; pf_n = S.unit_count[u]; pf_doc = S.units[u].doc; }
         }
     };
     prefetch(blockIdx.x);
@@ -345,17 +349,15 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
         const uint32_t nd = (uint32_t)(S.n_docs - d0 < (uint64_t)G ? S.n_docs - d0 : (uint64_t)G);
 
         // ---- 1. presence matrix ------------------------------------------------------------------------------
-        // a team of kTeam lanes per document, all documents of the group at once.  The document's unit range and its
-        // first unit's slab were fetched while the previous group was evaluated (pf_*); four slab entries per lane are
-        // in flight at a time
-        for (uint32_t j = threadIdx.x / kTeam; j < nd && !(S.dbg & 1); j += kSolveBlockThreads / kTeam) {
+        // four slab entries per lane are in flight at a time
+        if (!(S.dbg & 1)) {
             const uint32_t member = threadIdx.x % kTeam;
-            const uint64_t d = d0 + j;
-            const bool pf = j == threadIdx.x / kTeam;              // first (normally only) document of this team
-            const uint64_t u0 = pf ? pf_u0 : S.doc_unit_base[d], u1 = pf ? pf_u1 : S.doc_unit_base[d + 1];
-            for (uint64_t u = u0; u < u1; u++) {
-                const uint64_t s = (pf && u == u0) ? pf_s : S.unit_start[u];
-                const uint32_t n = (pf && u == u0) ? pf_n : S.unit_count[u];
+            const uint64_t U0 = pf_U0, U1 = pf_U1;
+            for (uint64_t u = U0 + threadIdx.x / kTeam; u < U1; u += kTeams) {
+                const bool pf = u < U0 + kTeams;                   // first (normally only) unit of this team
+                const uint64_t s = pf ? pf_s : S.unit_start[u];
+                const uint32_t n = pf ? pf_n : S.unit_count[u];
+                const uint32_t j = (uint32_t)((pf ? pf_doc : S.units[u].doc) - d0);
                 for (uint32_t i = member; i < n; i += 4 * kTeam) {
                     uint32_t t[4];
 #pragma unroll
@@ -370,11 +372,13 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
                 }
             }
             if (S.x_off) {
-                const uint64_t x0 = S.x_off[d], x1 = S.x_off[d + 1];
-                for (uint64_t i = x0 + member; i < x1; i += kTeam) {
-                    const size_t bp = (size_t)S.x_slot[i] * G + j;
-                    if (P_LDS) __hip_atomic_fetch_or(&Pw[bp >> 5], 1u << (bp & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    else atomicOr(&Pw[bp >> 5], 1u << (bp & 31));
+                for (uint32_t j = threadIdx.x / kTeam; j < nd; j += kTeams) {
+                    const uint64_t x0 = S.x_off[d0 + j], x1 = S.x_off[d0 + j + 1];
+                    for (uint64_t i = x0 + member; i < x1; i += kTeam) {
+                        const size_t bp = (size_t)S.x_slot[i] * G + j;
+                        if (P_LDS) __hip_atomic_fetch_or(&Pw[bp >> 5], 1u << (bp & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        else atomicOr(&Pw[bp >> 5], 1u << (bp & 31));
+                    }
                 }
             }
         }

@@ -405,6 +405,7 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         P.cand_cap = e->scan2_cand_cap;
         P.slots = e->d_s2_slots.as<Scan2Slot>(); P.slot_shift = e->s2.slot_shift; P.slot_seed = e->s2.slot_seed;
         P.more = e->d_s2_more.as<Scan2Slot>();
+        P.text_bytes = text_hi;
         P.fold = (flags & GFT_FOLD_ASCII) ? 1 : 0;
         P.cls = P.fold ? e->d_s2_cls_fold.as<uint8_t>() : e->d_s2_cls.as<uint8_t>();
         P.term_blob = e->d_s2_term_blob.as<uint8_t>(); P.term_off = e->d_s2_term_off.as<uint32_t>();
@@ -418,10 +419,11 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         const uint64_t n_waves = (uint64_t)e->n_cus * e->scan2_k2_waves;
         P.slab = (uint32_t)std::min<uint64_t>(kScan2Slab, std::max<uint64_t>(64, e->pool_cap / (2 * n_waves)));
         // the balanced path serves both callers: the solver reads presence / successor positions in any order, and
-        // CSR results are put into emission order by the gather (k_gather_sorted); GFT_SCAN_ORDERED=1 keeps the
-        // in-kernel ordered path for CSR results (the cross-check of the two)
-        e->csr_sorted_in_gather = need_csr && !getenv("GFT_SCAN_ORDERED");
-        P.ordered = (need_csr && !e->csr_sorted_in_gather) ? 1 : 0;
+        // CSR results are put into emission order by the gather (k_gather_sorted).  GFT_SCAN_ORDERED=1 sends every unit
+        // through the kernel's per-lane staging path (normally the fallback for units whose matches overflow the LDS
+        // fifo): a second implementation of the verification, kept as a cross-check
+        e->csr_sorted_in_gather = need_csr;
+        P.ordered = (need_csr && getenv("GFT_SCAN_ORDERED")) ? 1 : 0;
         // presence-only mode: positions are only read by INORD groups (and by CSR callers)
         P.want_pos = (need_csr || e->n_inord_groups > 0) ? 1 : 0;
         const char* dbg = getenv("GFT_SCAN_DEBUG");
@@ -562,7 +564,7 @@ int solve_pipeline(gft_engine* e, uint64_t n_docs, const gft_extra_matches* d_ex
 // ---- compiled tables as one blob (BuildEngine for a large dictionary is paid once) -----------------
 namespace {
 constexpr uint32_t kTablesMagic = 0x54544647u;   // "GFTT"
-constexpr uint32_t kTablesVersion = 4;           // bump when a table layout or a hash function changes
+constexpr uint32_t kTablesVersion = 5;           // bump when a table layout or a hash function changes
 
 struct Writer {
     std::vector<uint8_t> b;

@@ -242,10 +242,12 @@ __global__ void __launch_bounds__(256) k_gather(const uint64_t* __restrict__ uni
 }
 
 // ------------------------------------------------------------------------------------------------------
-// k_gather_sorted: the same for slabs written by the balanced (unordered) path of gft_scan2: a unit's matches are put
-// into the reference's emission order -- end offset ascending, longer term first -- on the way.  One wave per unit;
-// at most kScan2FifoCap matches (larger units were written by the ordered path and are copied as they are).  Rank sort:
-// keys (end - unit.lo) << 18 | (2^18 - 1 - len) sit in LDS, every lane counts the keys below each of its own.
+// k_gather_sorted: the same for slabs written by gft_scan2 (any order inside a unit; every match lies in the unit
+// that holds its end position): a unit's matches are put into the reference's emission order -- end offset
+// ascending, longer term first -- on the way.  One wave per unit.  Rank sort: keys (end - unit.lo) << 18 |
+// (2^18 - 1 - len) are staged in LDS kScan2FifoCap at a time, every lane counts the keys below each of its own (up to
+// kScan2FifoCap own items per pass; units with more matches take several passes).  Keys are distinct: two matches
+// with the same end and length are the same term.
 // ------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_gather_sorted(const Unit* __restrict__ units,
                                                        const uint64_t* __restrict__ unit_start,
@@ -262,41 +264,51 @@ __global__ void __launch_bounds__(256) k_gather_sorted(const Unit* __restrict__ 
     for (uint64_t u = (uint64_t)blockIdx.x * wpb + wave; u < n_units; u += (uint64_t)gridDim.x * wpb) {
         const uint64_t s = unit_start[u], d = unit_out[u];
         const uint32_t n = unit_count[u];
-        if (n > kScan2FifoCap) {                      // already in order
-            for (uint32_t i = lane; i < n; i += kLane) { term_id[d + i] = pool_term[s + i]; pos[d + i] = pool_pos[s + i]; }
-            continue;
-        }
         const uint32_t lo = units[u].lo;
-        uint32_t t[kPer], p[kPer], k[kPer];
+        auto key_of = [&](uint32_t i, uint32_t& t, uint32_t& p) {
+            t = pool_term[s + i];
+            p = pool_pos[s + i];
+            const uint32_t L = term_len[t];
+            const uint32_t end = pos_end ? p : p + L - 1;
+            return (end - lo) << 18 | (0x3FFFFu - (L < 0x3FFFFu ? L : 0x3FFFFu));
+        };
+        for (uint32_t b0 = 0; b0 < n; b0 += kScan2FifoCap) {           // this pass's own items
+            uint32_t t[kPer], p[kPer], k[kPer], rank[kPer];
 #pragma unroll
-        for (uint32_t q = 0; q < kPer; q++) {
-            const uint32_t i = lane + q * kLane;
-            k[q] = 0xFFFFFFFFu;
-            if (i < n) {
-                t[q] = pool_term[s + i];
-                p[q] = pool_pos[s + i];
-                const uint32_t L = term_len[t[q]];
-                const uint32_t end = pos_end ? p[q] : p[q] + L - 1;
-                k[q] = (end - lo) << 18 | (0x3FFFFu - L);
-                keys[i] = k[q];
+            for (uint32_t q = 0; q < kPer; q++) {
+                const uint32_t i = b0 + lane + q * kLane;
+                k[q] = 0xFFFFFFFFu; rank[q] = 0; t[q] = 0; p[q] = 0;
+                if (i < n) k[q] = key_of(i, t[q], p[q]);
             }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        uint32_t rank[kPer];
+            for (uint32_t t0 = 0; t0 < n; t0 += kScan2FifoCap) {       // all keys, a tile at a time
+                __builtin_amdgcn_wave_barrier();
+                if (t0 == b0) {
 #pragma unroll
-        for (uint32_t q = 0; q < kPer; q++) rank[q] = 0;
-        const uint32_t rounds = (n + kLane - 1) / kLane;       // own items in use (wave-uniform)
-        for (uint32_t j = 0; j < n; j++) {
-            const uint32_t kj = keys[j];                        // broadcast read
+                    for (uint32_t q = 0; q < kPer; q++) keys[lane + q * kLane] = k[q];
+                } else {
+#pragma unroll
+                    for (uint32_t q = 0; q < kPer; q++) {
+                        const uint32_t j = t0 + lane + q * kLane;
+                        uint32_t tt, pp;
+                        keys[lane + q * kLane] = j < n ? key_of(j, tt, pp) : 0xFFFFFFFFu;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const uint32_t tn = n - t0 < kScan2FifoCap ? n - t0 : kScan2FifoCap;
+                const uint32_t rounds = (((n - b0 < kScan2FifoCap ? n - b0 : kScan2FifoCap)) + kLane - 1) / kLane;   // own items in use
+                for (uint32_t j = 0; j < tn; j++) {
+                    const uint32_t kj = keys[j];                        // broadcast read
+#pragma unroll
+                    for (uint32_t q = 0; q < kPer; q++)
+                        if (q < rounds) rank[q] += kj < k[q] ? 1u : 0u;
+                }
+            }
 #pragma unroll
             for (uint32_t q = 0; q < kPer; q++)
-                if (q < rounds) rank[q] += kj < k[q] ? 1u : 0u;
+                if (b0 + lane + q * kLane < n) { term_id[d + rank[q]] = t[q]; pos[d + rank[q]] = p[q]; }
         }
-#pragma unroll
-        for (uint32_t q = 0; q < kPer; q++)
-            if (lane + q * kLane < n) { term_id[d + rank[q]] = t[q]; pos[d + rank[q]] = p[q]; }
         __builtin_amdgcn_wave_barrier();
     }
 }

@@ -116,11 +116,18 @@ constexpr uint32_t kGoldDev = 0x9E3779B1u;
 constexpr uint32_t kScan2EmptyKey = 0xFFFFFFFFu;   // never a window key of a term (checked at build time)
 constexpr uint32_t kScan2Multi = 0x80000000u;
 constexpr uint32_t kScan2InlineLen = 24;           // 4 window bytes + 20 front bytes
+// Shifted anchors: the window of a term need not be its LAST four bytes.  Among the windows that end `off` = 0 ..
+// kScan2MaxOff bytes before the term's end the build picks the one that is rarest in text (fewest flagged positions);
+// the bytes behind the window (`tail`) are then checked like the bytes in front of it.  The slot describes the term up
+// to the end of its window (len1 = length - off), keeps off in the top byte of `len`, and stores the tail in front[4]
+// (so a shifted term carries 16 front bytes inline instead of 20).
+constexpr uint32_t kScan2MaxOff = 4;
+constexpr uint32_t kScan2LenMask = 0x00FFFFFFu;    // len word: len1 | off << 24
 struct __attribute__((aligned(32))) Scan2Slot {
     uint32_t key;
     uint32_t info;       // one term: term_id (< 2^31); several: kScan2Multi | index into `more`
-    uint32_t len;        // one term: its length in bytes; several: number of entries
-    uint32_t front[5];
+    uint32_t len;        // one term: len1 | off << 24; several: number of entries
+    uint32_t front[5];   // off > 0: front[4] = the off bytes behind the window, text[p+1 ..] as a little-endian dword
 };
 // short3 record: the (up to three) terms of length <= 3 that end at a 3-window, longest first
 struct Scan2Short {
@@ -220,7 +227,8 @@ struct Scan2Params {
     uint32_t* unit_count;
     uint64_t* n_matches;         // exact number of matches (the cursor includes slab slack)
     uint32_t slab;               // pool entries a wave reserves per global atomic (<= kScan2Slab)
-    uint32_t ordered;            // 1: matches of a unit in text order (CSR results); 0: any order (solver input)
+    uint32_t ordered;            // 1: per-lane staging path for every unit (cross-check); 0: balanced path, staging only on overflow
+    uint64_t text_bytes;         // size of the text blob (loads behind a window must not run past it)
     uint32_t want_pos;           // 0: presence only -- no expression has an INORD group, pool_pos is not written
     uint32_t dbg;                // GFT_SCAN_DEBUG bits (timing studies only): 1 = skip verification, 2 = count flags
     uint64_t* dbg_counters;      // [4] when dbg & 2: flagged positions, table probes, entries compared, -

@@ -75,7 +75,26 @@ struct Ctx {
     uint32_t kp2;              // kp * kp
     bool near0;                // wave-uniform: the document starts within 7 bytes of the blob start
     bool near24;               // ... within 23 bytes
+    uint32_t lo, hi;           // the unit: a match belongs to the unit that holds its END position
+    bool near_end;             // wave-uniform: the unit ends within 4 bytes of the blob end
 };
+
+// the (up to) four bytes behind position p, text[p+1 .. p+4], for the tails of shifted terms; bytes past the blob end
+// read as zero (a tail that reached there would end outside the unit and is dropped by the range check anyway)
+__device__ __forceinline__ uint32_t tail_load(const Ctx& c, uint32_t p) {
+    if (__builtin_expect(c.near_end, 0)) {
+        uint32_t v = 0;
+        for (uint32_t b = 0; b < 4; b++)
+            if (c.doc_abs + p + 1 + b < c.P.text_bytes) v |= (uint32_t)c.dbase[(uint64_t)p + 1 + b] << (8 * b);
+        return v;
+    }
+    return load_u32_unaligned(c.dbase + (uint64_t)p + 1);
+}
+// reported position of a match whose window ends at p (lw = the slot's len word)
+__device__ __forceinline__ uint32_t match_pos(const Scan2Params& P, uint32_t p, uint32_t lw) {
+    const uint32_t off = lw >> 24, L1 = lw & kScan2LenMask;
+    return P.pos_end ? p + off : p + 1 - L1;
+}
 
 // ---- verification of one flagged position p, in three separable steps so that several candidates can have their
 // the cheap LDS-only decisions (stage A) and the L2 bucket probes (stage B) can run as separate, dense passes ------------
@@ -176,29 +195,36 @@ __device__ __forceinline__ bool slot_pick(uint32_t x, const Slot& s0, const Slot
     return use1 || s0.a.x == x;
 }
 
-// does the term described by e end at p?  t = the (folded) bytes in front of the window.  kmax: dwords of `front` to
-// look at (wave-uniform bound, or 5)
-__device__ __forceinline__ bool entry_ok(const Ctx& c, uint32_t p, const Front& t, const Slot& e, uint32_t kmax) {
+// does the term described by e have its window end at p (and its own end inside the unit)?  t = the (folded) bytes in
+// front of the window, tl = the raw bytes behind it.  kmax: dwords of `front` to look at (wave-uniform bound, or 5)
+__device__ __forceinline__ bool entry_ok(const Ctx& c, uint32_t p, const Front& t, uint32_t tl, const Slot& e, uint32_t kmax) {
     const Scan2Params& P = c.P;
-    const uint32_t L = e.a.z;
+    const uint32_t L = e.a.z & kScan2LenMask, off = e.a.z >> 24;      // L: the term up to the end of its window
     const int32_t nfront = (int32_t)L - 4;
     uint32_t diff = 0;
 #pragma unroll
     for (int k = 0; k < 5; k++) {
         if ((uint32_t)k < kmax) {
-            const int32_t nb = min(max(nfront - 4 * k, 0), 4);                     // bytes of this dword the term owns
+            int32_t nb = min(max(nfront - 4 * k, 0), 4);                           // bytes of this dword the term owns
+            if (k == 4 && off) nb = 0;                                             // front[4] holds the tail instead
             const uint32_t mask = (uint32_t)(0xFFFFFFFF00000000ull >> (8 * nb));   // ... the ones next to the window
             const uint32_t fk = k == 0 ? e.a.w : k == 1 ? e.b.x : k == 2 ? e.b.y : k == 3 ? e.b.z : e.b.w;
             diff |= (t.f[k] ^ fk) & mask;
         }
     }
-    bool ok = L <= p + 1 && diff == 0;
-    if (ok && L > kScan2InlineLen) {
-        // the first L-24 bytes of the term against text[p+1-L .. p-24], four bytes at a time from the end; term_blob
+    if (off) {
+        const uint32_t tv = P.fold ? fold4(tl) : tl;
+        diff |= (tv ^ e.b.w) & (0xFFFFFFFFu >> (8 * (4 - off)));
+    }
+    const uint32_t pe = p + off;                                                   // where the term ends
+    bool ok = L <= p + 1 && diff == 0 && pe >= c.lo && pe < c.hi;
+    const uint32_t inl = off ? kScan2InlineLen - 4 : kScan2InlineLen;
+    if (ok && L > inl) {
+        // the first L-inl bytes of the term against text[p+1-L .. p-inl], four bytes at a time from the end; term_blob
         // carries 4 bytes of slack in front of every term, the text side needs 3 bytes of slack before the match
         const uint8_t* tb = P.term_blob + P.term_off[e.a.y];
         const uint8_t* tp = c.dbase + (int64_t)p + 1 - L;
-        const uint32_t n = L - kScan2InlineLen;
+        const uint32_t n = L - inl;
         if (c.doc_abs + p + 1 - L >= 3) {
             uint32_t d2 = 0;
             for (uint32_t j = 0; j * 4 < n; j++) {
@@ -240,8 +266,8 @@ template <int MODE>
 __device__ __forceinline__ void cand_finish(const Ctx& c, const Cand& k, uint32_t& cnt, uint2* stage, uint64_t out_base) {
     const Scan2Params& P = c.P;
     const uint32_t p = k.p;
-    auto emit = [&](uint32_t term, uint32_t L) {
-        const uint32_t pos = P.pos_end ? p : p + 1 - L;
+    auto emit = [&](uint32_t term, uint32_t lw) {
+        const uint32_t pos = match_pos(P, p, lw);
         if (MODE == 0) {
             if (cnt < kScan2StageCap) stage[cnt * 64] = make_uint2(term, pos);
         } else {
@@ -255,6 +281,7 @@ __device__ __forceinline__ void cand_finish(const Ctx& c, const Cand& k, uint32_
         const Slot s0 = slot_load(&P.slots[scan2_slot_hash(k.x, 0, P.slot_shift, P.slot_seed)]);
         const Slot s1 = slot_load(&P.slots[scan2_slot_hash(k.x, 1, P.slot_shift, P.slot_seed)]);
         Front t = front_load(c, p, k.tw);
+        const uint32_t tl = tail_load(c, p);
         if (P.fold) front_fold(t);
         Slot e;
         if (slot_pick(k.x, s0, s1, e)) {
@@ -265,7 +292,7 @@ __device__ __forceinline__ void cand_finish(const Ctx& c, const Cand& k, uint32_
                 e = slot_load(&P.more[more_at]);
             }
             for (uint32_t j = 0;;) {
-                if (entry_ok(c, p, t, e, 5)) emit(e.a.y, e.a.z);
+                if (entry_ok(c, p, t, tl, e, 5)) emit(e.a.y, e.a.z);
                 if (++j >= n_ent) break;
                 e = slot_load(&P.more[more_at + j]);
             }
@@ -325,7 +352,7 @@ struct Deferred { uint2* list; uint32_t cap, n; };
 // s0, s1: the key's two candidate slots; t: the bytes in front of the window, not yet folded.  One-term buckets are
 // verified here; the entries of multi-term buckets are deferred (or, if the list is full, verified in place).
 __device__ __forceinline__ void finish_long(const Ctx& c, bool on, uint32_t rel, const Cand& k, const Slot& s0, const Slot& s1,
-                                            Front t, uint2* fifo, uint32_t& nf, Deferred& d) {
+                                            Front t, uint32_t tl, uint2* fifo, uint32_t& nf, Deferred& d) {
     const Scan2Params& P = c.P;
     Slot e;
     const bool have = slot_pick(k.x, s0, s1, e) && on;
@@ -334,10 +361,10 @@ __device__ __forceinline__ void finish_long(const Ctx& c, bool on, uint32_t rel,
     uint32_t folded = 0;
     {   // one-term buckets
         const bool act = have && !multi;
-        const uint32_t kmax = wave_kmax(act ? e.a.z : 0);
+        const uint32_t kmax = wave_kmax(act ? e.a.z & kScan2LenMask : 0);
         if (P.fold) front_fold_upto(t, folded, kmax);
-        const bool ok = act && entry_ok(c, k.p, t, e, kmax);
-        fifo_append(ok, e.a.y, P.pos_end ? k.p : k.p + 1 - e.a.z, fifo, nf);
+        const bool ok = act && entry_ok(c, k.p, t, tl, e, kmax);
+        fifo_append(ok, e.a.y, match_pos(P, k.p, e.a.z), fifo, nf);
     }
     if (!__any(multi)) return;
     const uint32_t n_ent = multi ? e.a.z : 0, more_at = e.a.y & ~kScan2Multi;
@@ -361,10 +388,10 @@ __device__ __forceinline__ void finish_long(const Ctx& c, bool on, uint32_t rel,
         const bool act = j < n_ent;
         Slot nxt = cur;
         if (j + 1 < n_ent) nxt = slot_load(&P.more[more_at + j + 1]);      // in flight during the compare
-        const uint32_t kmax = wave_kmax(act ? cur.a.z : 0);
+        const uint32_t kmax = wave_kmax(act ? cur.a.z & kScan2LenMask : 0);
         if (P.fold) front_fold_upto(t, folded, kmax);
-        const bool ok = act && entry_ok(c, k.p, t, cur, kmax);
-        fifo_append(ok, cur.a.y, P.pos_end ? k.p : k.p + 1 - cur.a.z, fifo, nf);
+        const bool ok = act && entry_ok(c, k.p, t, tl, cur, kmax);
+        fifo_append(ok, cur.a.y, match_pos(P, k.p, cur.a.z), fifo, nf);
         cur = nxt;
     }
 }
@@ -383,11 +410,12 @@ __device__ __forceinline__ void drain_deferred(const Ctx& c, uint32_t unit_lo, u
         const Slot e = slot_load(&P.more[it.y]);
         const Text8 t8 = cand_load(c, p);
         Front t = front_load(c, p, t8.tw);
-        const uint32_t kmax = wave_kmax(on ? e.a.z : 0);
+        const uint32_t tl = tail_load(c, p);
+        const uint32_t kmax = wave_kmax(on ? e.a.z & kScan2LenMask : 0);
         uint32_t folded = 0;
         if (P.fold) front_fold_upto(t, folded, kmax);
-        const bool ok = on && entry_ok(c, p, t, e, kmax);
-        fifo_append(ok, e.a.y, P.pos_end ? p : p + 1 - e.a.z, fifo, nf);
+        const bool ok = on && entry_ok(c, p, t, tl, e, kmax);
+        fifo_append(ok, e.a.y, match_pos(P, p, e.a.z), fifo, nf);
     }
     d.n = 0;
     __builtin_amdgcn_wave_barrier();
@@ -397,20 +425,23 @@ template <int MODE, bool FPT_LDS>
 __device__ __forceinline__ void verify(const Ctx& c, uint32_t p, uint32_t& cnt, uint2* stage, uint64_t out_base) {
     Cand k;
     cand_text<FPT_LDS>(c, p, k);
+    if (p < c.lo) k.sid = 0;            // a position in front of the unit: only terms that end inside it
     if (k.go_long || k.sid) cand_finish<MODE>(c, k, cnt, stage, out_base);
 }
 
 template <int MODE, bool FPT_LDS>
-__device__ __forceinline__ void verify_masks(const Ctx& c, uint32_t my_lo, uint32_t m0, uint32_t m1, uint32_t m2,
+__device__ __forceinline__ void verify_masks(const Ctx& c, uint32_t my_lo, uint32_t mb, uint32_t m0, uint32_t m1, uint32_t m2,
                                              uint32_t m3, uint32_t& cnt, uint2* stage, uint64_t out_base) {
-    // one copy of the (large) verification body: the 32-position block index k is a scalar loop variable
-    for (uint32_t k = 0; k < 4; k++) {
-        uint32_t mk = k == 0 ? m0 : k == 1 ? m1 : k == 2 ? m2 : m3;
+    // one copy of the (large) verification body: the 32-position block index k is a scalar loop variable; block 0 =
+    // the positions in front of the unit (mb: bit i = position lo - kScan2MaxOff + i, lane 0 only)
+    for (uint32_t k = 0; k < 5; k++) {
+        uint32_t mk = k == 0 ? mb : k == 1 ? m0 : k == 2 ? m1 : k == 3 ? m2 : m3;
+        const uint32_t at = k == 0 ? c.lo - kScan2MaxOff : my_lo + 32 * (k - 1);
         while (__any(mk != 0)) {
             if (mk) {
                 const uint32_t i = __builtin_ctz(mk);
                 mk &= mk - 1;
-                verify<MODE, FPT_LDS>(c, my_lo + 32 * k + i, cnt, stage, out_base);
+                verify<MODE, FPT_LDS>(c, at + i, cnt, stage, out_base);
             }
         }
     }
@@ -466,7 +497,12 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
         if (more_units) un_n = P.units[u + stride];
         const Ctx c{P, cls, filt, P.short3_bytes ? short3 : nullptr, fpt, lrec, P.text + doc_abs, doc_abs, kp2,
                     __builtin_amdgcn_readfirstlane((uint32_t)(doc_abs < 7)) != 0,
-                    __builtin_amdgcn_readfirstlane((uint32_t)(doc_abs < 23)) != 0};
+                    __builtin_amdgcn_readfirstlane((uint32_t)(doc_abs < 23)) != 0, un.lo, un.hi,
+                    __builtin_amdgcn_readfirstlane((uint32_t)(doc_abs + un.hi + 4 > P.text_bytes)) != 0};
+        // A term whose window ends up to kScan2MaxOff bytes before the unit may itself end inside it: those positions
+        // (units that continue a document only) join the candidates unconditionally, for such terms only
+        const uint32_t nborder = un.lo < kScan2MaxOff ? un.lo : kScan2MaxOff;
+        const uint32_t ubase = un.lo - kScan2MaxOff;               // candidate lists hold p - ubase (may wrap; p never does)
         const uint32_t own = un.hi - un.lo;
         const uint32_t C = ((own + 63) / 64 + 3) & ~3u;            // bytes per lane (multiple of 4, <= 128)
         const uint32_t my_lo = un.lo + lane * C;
@@ -548,7 +584,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
         // ---- phase 2, unordered fast path (the solver does not need text order): balance the flagged positions over
         // the lanes through an LDS candidate list, append matches to an LDS fifo, flush the fifo coalesced ----------------
         if (!ORDERED) {
-            const uint32_t f = __popc(m0) + __popc(m1) + __popc(m2) + __popc(m3);
+            const uint32_t f = __popc(m0) + __popc(m1) + __popc(m2) + __popc(m3) + (lane == 0 ? nborder : 0);
             const uint32_t fincl = wave_incl_scan(f);
             const uint32_t ftotal = __shfl(fincl, 63, 64);
             bool done = ftotal == 0;
@@ -564,7 +600,9 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
                     const uint32_t ptotal = __shfl(fincl, (int)l1 - 1, 64) - before;
                     if (lane >= l0 && lane < l1) {
                         uint32_t wpos = fincl - f - before;
-                        const uint32_t rel = lane * C;
+                        const uint32_t rel = lane * C + kScan2MaxOff;
+                        if (lane == 0)
+                            for (uint32_t i = 0; i < nborder; i++) cand[wpos++] = (uint16_t)(kScan2MaxOff - nborder + i);
                         uint32_t mm[4] = {m0, m1, m2, m3};
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
@@ -596,7 +634,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
                             n_rel[q] = cand[n_on[q] ? i : 0];
                         }
 #pragma unroll
-                        for (int q = 0; q < kStageAWays; q++) n_tx[q] = cand_load(c, un.lo + n_rel[q]);
+                        for (int q = 0; q < kStageAWays; q++) n_tx[q] = cand_load(c, ubase + n_rel[q]);
                     };
                     fetch(0);
                     for (uint32_t i0 = 0; i0 < ptotal; i0 += 64 * kStageAWays) {
@@ -608,12 +646,13 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
                         for (int q = 0; q < kStageAWays; q++) { on[q] = n_on[q]; rel[q] = n_rel[q]; tx[q] = n_tx[q]; }
                         if (i0 + 64 * kStageAWays < ptotal) fetch(i0 + 64 * kStageAWays);
 #pragma unroll
-                        for (int q = 0; q < kStageAWays; q++) cand_keys(c, un.lo + rel[q], tx[q], k[q]);
+                        for (int q = 0; q < kStageAWays; q++) cand_keys(c, ubase + rel[q], tx[q], k[q]);
 #pragma unroll
                         for (int q = 0; q < kStageAWays; q++) cand_decide<FPT_LDS>(c, k[q]);
 #pragma unroll
                         for (int q = 0; q < kStageAWays; q++)
-                            if (i0 + 64 * q < ptotal) finish_short(c, k[q].p, on[q] ? k[q].sid : 0, k[q].x3, fifo, nf);
+                            if (i0 + 64 * q < ptotal)              // (positions in front of the unit: long terms only)
+                                finish_short(c, k[q].p, on[q] && rel[q] >= kScan2MaxOff ? k[q].sid : 0, k[q].x3, fifo, nf);
                         // all reads of this trip are done (every read index >= every write index below)
                         const uint64_t below = (1ull << lane) - 1;
 #pragma unroll
@@ -637,16 +676,17 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
                     for (uint32_t i0 = 0; i0 < ns; i0 += 64) {
                         const bool on = i0 + lane < ns;
                         const uint32_t rel = cand[on ? i0 + lane : 0];
-                        const uint32_t p = un.lo + rel;
+                        const uint32_t p = ubase + rel;
                         const Text8 t8 = cand_load(c, p);
                         const Front fr = front_load(c, p, t8.tw);
+                        const uint32_t tl = tail_load(c, p);
                         Cand k;
                         cand_keys(c, p, t8, k);
                         const Slot s0 = slot_load(&P.slots[scan2_slot_hash(k.x, 0, P.slot_shift, P.slot_seed)]);
                         const Slot s1 = slot_load(&P.slots[scan2_slot_hash(k.x, 1, P.slot_shift, P.slot_seed)]);
-                        finish_long(c, on, rel, k, s0, s1, fr, fifo, nf, dfr);
+                        finish_long(c, on, rel, k, s0, s1, fr, tl, fifo, nf, dfr);
                     }
-                    if (dfr.n) drain_deferred(c, un.lo, fifo, nf, dfr);
+                    if (dfr.n) drain_deferred(c, ubase, fifo, nf, dfr);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -681,7 +721,8 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
         }
 
         // ---- phase 2, ordered path: every lane verifies its own positions in text order, stages matches in LDS ---------
-        verify_masks<0, FPT_LDS>(c, my_lo, m0, m1, m2, m3, cnt, stage, 0);
+        const uint32_t mb = lane == 0 ? ((1u << nborder) - 1) << (kScan2MaxOff - nborder) : 0;
+        verify_masks<0, FPT_LDS>(c, my_lo, mb, m0, m1, m2, m3, cnt, stage, 0);
 
         // ---- output -------------------------------------------------------------------------------------------------
         const uint32_t incl = wave_incl_scan(cnt);
@@ -713,7 +754,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
             const bool over = cnt > kScan2StageCap;
             if (__any(over)) {
                 uint32_t c2 = 0;
-                verify_masks<1, FPT_LDS>(c, my_lo, over ? m0 : 0, over ? m1 : 0, over ? m2 : 0, over ? m3 : 0, c2, stage, mine);
+                verify_masks<1, FPT_LDS>(c, my_lo, over ? mb : 0, over ? m0 : 0, over ? m1 : 0, over ? m2 : 0, over ? m3 : 0, c2, stage, mine);
             }
         }
     }

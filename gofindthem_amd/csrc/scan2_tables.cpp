@@ -1,6 +1,7 @@
 #include "scan2_tables.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <unordered_map>
@@ -25,8 +26,33 @@ void build_scan2_tables(const AcTables& ac, Scan2Tables& t) {
     for (const auto& s : ac.terms) any_short |= !s.empty() && s.size() < kWin;
     if (any_short && kp3 > kScan2Short3Max) { t.why_not = "terms shorter than 4 bytes over a large alphabet"; return; }
 
-    // ---- terms of length >= 4: buckets keyed by their last four classes ------------------------------------------
-    struct Ent { uint32_t term_id, len; };
+    // ---- terms of length >= 4: buckets keyed by the four classes of their window ----------------------------------
+    // The window ends `off` bytes before the term's end (gft_kernels.hpp, kScan2MaxOff).  Every text position whose last
+    // four classes equal a window costs a stage-A check, and one that also matches the bytes in front of it costs a
+    // bucket-table probe, so the build picks the window with the least expected cost under a unigram model of the text
+    // (class frequencies of the dictionary itself: dictionaries and the text they are run on share an alphabet).
+    std::vector<double> logp(kp, 0.0);
+    {
+        std::vector<uint64_t> cnt(kp, 0);
+        uint64_t tot = 0;
+        for (const auto& s : ac.terms) for (unsigned char ch : s) { cnt[ac.byte_class[ch]]++; tot++; }
+        for (uint32_t cl = 0; cl < kp; cl++) logp[cl] = std::log(((double)cnt[cl] + 0.5) / ((double)tot + 0.5 * kp));
+    }
+    auto pick_off = [&](const std::string& s) -> uint32_t {
+        const uint32_t L = (uint32_t)s.size();
+        uint32_t best = 0;
+        double best_cost = 0;
+        for (uint32_t off = 0; off <= kScan2MaxOff && off + kWin <= L; off++) {
+            const uint32_t L1 = L - off;
+            double w = 0, f = 0;
+            for (uint32_t i = L1 - kWin; i < L1; i++) w += logp[ac.byte_class[(uint8_t)s[i]]];
+            for (uint32_t i = 0; i < 3 && i + kWin < L1; i++) f += logp[ac.byte_class[(uint8_t)s[L1 - kWin - 1 - i]]];
+            const double cost = std::exp(w) * (1.0 + 3.0 * std::max(std::exp(f), 1.0 / 32));
+            if (off == 0 || cost < best_cost * 0.999) { best = off; best_cost = cost; }
+        }
+        return best;
+    };
+    struct Ent { uint32_t term_id, len, off; };   // len = len1: the term up to the end of its window
     std::unordered_map<uint32_t, std::vector<Ent>> buckets;
     buckets.reserve(ac.terms.size() * 2);
     std::vector<std::vector<uint32_t>> content;   // per 3-window: short terms ending there
@@ -41,11 +67,13 @@ void build_scan2_tables(const AcTables& ac, Scan2Tables& t) {
         t.term_blob.insert(t.term_blob.end(), s.begin(), s.end());
         const uint32_t L = (uint32_t)s.size();
         if (L == 0) continue;   // the empty keyword never matches
-        uint32_t tail = 0;      // radix value of the term's last min(L, 4) classes
-        const uint32_t m = std::min(L, kWin);
-        for (uint32_t i = L - m; i < L; i++) tail = tail * kp + ac.byte_class[(uint8_t)s[i]];
+        if (L > kScan2LenMask) { t.why_not = "term longer than 16 MiB"; return; }
+        const uint32_t off = L >= kWin ? pick_off(s) : 0, L1 = L - off;
+        uint32_t tail = 0;      // radix value of the window's classes (the whole term when it is shorter)
+        const uint32_t m = std::min(L1, kWin);
+        for (uint32_t i = L1 - m; i < L1; i++) tail = tail * kp + ac.byte_class[(uint8_t)s[i]];
         if (L >= kWin) {
-            buckets[tail].push_back(Ent{(uint32_t)id, L});
+            buckets[tail].push_back(Ent{(uint32_t)id, L1, off});
         } else {
             // a short term ends every 3-window whose last L classes are the term
             uint32_t scale = 1, combos = 1;
@@ -103,13 +131,14 @@ void build_scan2_tables(const AcTables& ac, Scan2Tables& t) {
     // ---- bucket table (32-byte slots, two-choice placement) + fingerprint items ------------------------------------
     auto make_slot = [&](uint32_t key, const Ent& e) {
         const std::string& s = ac.terms[e.term_id];
-        const int L = (int)s.size();
-        Scan2Slot r{key, e.term_id, e.len, {0, 0, 0, 0, 0}};
-        for (int k = 0; k < 5; k++)
+        const int L = (int)e.len;                              // the window ends at byte L - 1 of the term
+        Scan2Slot r{key, e.term_id, e.len | e.off << 24, {0, 0, 0, 0, 0}};
+        for (int k = 0; k < (e.off ? 4 : 5); k++)
             for (int b = 0; b < 4; b++) {
                 const int idx = L - 8 - 4 * k + b;             // term byte under text[p-7-4k+b]
                 if (idx >= 0) r.front[k] |= (uint32_t)(uint8_t)s[idx] << (8 * b);
             }
+        for (uint32_t b = 0; b < e.off; b++) r.front[4] |= (uint32_t)(uint8_t)s[L + b] << (8 * b);   // text[p+1+b]
         return r;
     };
     std::vector<Scan2Slot> items;        // one per key: the term itself, or the header of a multi-term bucket
@@ -171,7 +200,7 @@ void build_scan2_tables(const AcTables& ac, Scan2Tables& t) {
             const uint32_t x = kv.first, xm = scan2_fpt_xmix(x);
             for (const Ent& e : kv.second) {
                 const std::string& s = ac.terms[e.term_id];
-                const int L = (int)s.size();
+                const int L = (int)e.len;
                 if (L == 4) {
                     const uint32_t c = scan2_fpt_xcell(x, flg);
                     const uint8_t v = (uint8_t)scan2_fpt_xbyte(xm);

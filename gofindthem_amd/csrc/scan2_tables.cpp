@@ -38,18 +38,35 @@ void build_scan2_tables(const AcTables& ac, Scan2Tables& t) {
         for (const auto& s : ac.terms) for (unsigned char ch : s) { cnt[ac.byte_class[ch]]++; tot++; }
         for (uint32_t cl = 0; cl < kp; cl++) logp[cl] = std::log(((double)cnt[cl] + 0.5) / ((double)tot + 0.5 * kp));
     }
+    auto window_key = [&](const std::string& s, uint32_t L1) {
+        uint32_t key = 0;
+        for (uint32_t i = L1 - kWin; i < L1; i++) key = key * kp + ac.byte_class[(uint8_t)s[i]];
+        return key;
+    };
+    // ... and, among windows of similar cost, one that no other term has taken: a bucket with a single term is verified
+    // in the same trip that finds it, the entries of a shared bucket need another round of loads
+    std::unordered_map<uint32_t, uint32_t> taken;                // window key -> terms anchored there so far
     auto pick_off = [&](const std::string& s) -> uint32_t {
         const uint32_t L = (uint32_t)s.size();
-        uint32_t best = 0;
-        double best_cost = 0;
-        for (uint32_t off = 0; off <= kScan2MaxOff && off + kWin <= L; off++) {
+        double cost[kScan2MaxOff + 1], best_cost = 0;
+        uint32_t n = 0;
+        for (uint32_t off = 0; off <= kScan2MaxOff && off + kWin <= L; off++, n++) {
             const uint32_t L1 = L - off;
             double w = 0, f = 0;
             for (uint32_t i = L1 - kWin; i < L1; i++) w += logp[ac.byte_class[(uint8_t)s[i]]];
             for (uint32_t i = 0; i < 3 && i + kWin < L1; i++) f += logp[ac.byte_class[(uint8_t)s[L1 - kWin - 1 - i]]];
-            const double cost = std::exp(w) * (1.0 + 3.0 * std::max(std::exp(f), 1.0 / 32));
-            if (off == 0 || cost < best_cost * 0.999) { best = off; best_cost = cost; }
+            cost[off] = std::exp(w) * (1.0 + 3.0 * std::max(std::exp(f), 1.0 / 32));
+            if (off == 0 || cost[off] < best_cost) best_cost = cost[off];
         }
+        uint32_t best = 0;
+        double best_eff = 0;
+        for (uint32_t off = 0; off < n; off++) {
+            auto it = taken.find(window_key(s, L - off));
+            // sharing a bucket is worth avoiding unless the free window is several times more frequent in text
+            const double eff = cost[off] * (it == taken.end() ? 1.0 : 4.0) * (off == 0 ? 0.999 : 1.0);
+            if (off == 0 || eff < best_eff) { best = off; best_eff = eff; }
+        }
+        taken[window_key(s, L - best)]++;
         return best;
     };
     struct Ent { uint32_t term_id, len, off; };   // len = len1: the term up to the end of its window

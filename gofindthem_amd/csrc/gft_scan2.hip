@@ -31,10 +31,11 @@ struct __attribute__((packed, aligned(1))) U128u { uint32_t x, y, z, w; };
 struct __attribute__((packed, aligned(1))) U64u { uint32_t lo, hi; };
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
-// a * b + c on 24-bit operands: one full-rate instruction (the compiler's own choice is v_mul_lo_u32 / v_mad_u64_u32)
-__device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) {
+// a * b + c on 24-bit operands: one full-rate instruction (the compiler's own choice is v_mul_lo_u32 / v_mad_u64_u32);
+// the wave-uniform multiplier comes straight from a scalar register (no v_mov to materialise it)
+__device__ __forceinline__ uint32_t mad24s(uint32_t a, uint32_t sb, uint32_t c) {
     uint32_t d;
-    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(sb), "v"(c));
     return d;
 }
 // LDS tables at fixed addresses (the kernel's only LDS object is the dynamic array, which starts at 0; checked at
@@ -131,9 +132,9 @@ __device__ __forceinline__ void cand_keys(const Ctx& c, uint32_t p, const Text8 
     k.p = p;
     k.tw = t.tw;        // raw: the fingerprint ignores the case bit, the bucket compare folds when asked to
     const uint32_t c0 = c.cls[w & 0xFF], c1 = c.cls[(w >> 8) & 0xFF], c2 = c.cls[(w >> 16) & 0xFF];
-    const uint32_t lo = mad24(c2, kp, c.cls[w >> 24]);           // key = (c0 kp + c1) kp^2 + (c2 kp + c3)
-    const uint32_t x3 = mad24(c1, c.kp2, lo);
-    k.x = mad24(mad24(c0, kp, c1), c.kp2, lo);
+    const uint32_t lo = mad24s(c2, kp, c.cls[w >> 24]);          // key = (c0 kp + c1) kp^2 + (c2 kp + c3)
+    const uint32_t x3 = mad24s(c1, c.kp2, lo);
+    k.x = mad24s(mad24s(c0, kp, c1), c.kp2, lo);
     k.x3 = x3;
     k.sid = c.short3 ? c.short3[x3] : 0;
 }
@@ -476,7 +477,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
     uint2* fifo = reinterpret_cast<uint2*>(wave_lds);
     uint2* stage = fifo + lane;                                   // ordered path: entry k of this lane is stage[k * 64]
     uint16_t* cand = reinterpret_cast<uint16_t*>(wave_lds + kScan2FifoCap * 8);
-    const uint32_t kp = P.kp, kp2 = kp * kp;
+    const uint32_t kp = __builtin_amdgcn_readfirstlane(P.kp), kp2 = __builtin_amdgcn_readfirstlane(kp * kp);
     lds_u8* lcls = (lds_u8*)0;
     lds_u32* lfilt = (lds_u32*)256;
     if ((uint32_t)(uintptr_t)(lds_u8*)smem != 0) __builtin_trap();   // see lds_u8
@@ -503,7 +504,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
         // (units that continue a document only) join the candidates unconditionally, for such terms only
         const uint32_t nborder = un.lo < kScan2MaxOff ? un.lo : kScan2MaxOff;
         const uint32_t ubase = un.lo - kScan2MaxOff;               // candidate lists hold p - ubase (may wrap; p never does)
-        const uint32_t own = un.hi - un.lo;
+        const uint32_t own = __builtin_amdgcn_readfirstlane(un.hi - un.lo);   // wave-uniform: says so to the compiler
         const uint32_t C = ((own + 63) / 64 + 3) & ~3u;            // bytes per lane (multiple of 4, <= 128)
         const uint32_t my_lo = un.lo + lane * C;
         const uint32_t my_hi = my_lo + C < un.hi ? my_lo + C : un.hi;
@@ -524,7 +525,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
                 nxt = *reinterpret_cast<const U128u*>(src);
                 const uint32_t k1 = my_lo >= 1 ? lcls[hist >> 24] : P.pad_class, k2 = my_lo >= 2 ? lcls[(hist >> 16) & 0xFF] : P.pad_class,
                                k3 = my_lo >= 3 ? lcls[(hist >> 8) & 0xFF] : P.pad_class;
-                cp = k1; pm1 = mad24(k2, kp, k1); pm2 = mad24(k3, kp, k2);
+                cp = k1; pm1 = mad24s(k2, kp, k1); pm2 = mad24s(k3, kp, k2);
             }
             uint32_t acc = 0;
             const uint32_t ndw = C >> 2;                         // dwords per lane (wave-uniform, <= 32)
@@ -540,8 +541,8 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
 #pragma unroll
                         for (int b = 0; b < 4; b++) {
                             const uint32_t cl = lcls[(w[d] >> (8 * b)) & 0xFF];
-                            const uint32_t pair = mad24(cp, kp, cl);
-                            const uint32_t x = mad24(pm2, kp2, pair);
+                            const uint32_t pair = mad24s(cp, kp, cl);
+                            const uint32_t x = mad24s(pm2, kp2, pair);
                             pm2 = pm1; pm1 = pair; cp = cl;
                             const uint32_t fi = HASHED ? (x * kGoldDev) >> P.hash_shift : x;
                             const uint32_t fw = lfilt[fi >> 5];

@@ -44,6 +44,19 @@ typedef __attribute__((address_space(3))) const uint8_t lds_u8;
 typedef __attribute__((address_space(3))) const uint32_t lds_u32;
 __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t* p) { return reinterpret_cast<const U32u*>(p)->v; }
 
+// Kernel arguments that are needed once per unit or less (output buffers, tables of the rare paths) are read from the
+// kernarg segment where they are used instead of living in scalar registers for the whole kernel: the unit loop keeps
+// more values alive than there are SGPRs, and every spilled one costs VALU slots (v_writelane / v_readlane).  The asm
+// makes the address opaque, so the load can be neither merged with the preloaded arguments nor hoisted.
+typedef __attribute__((address_space(4))) const uint8_t karg_u8;
+template <class T>
+__device__ __forceinline__ T karg_field(uint32_t off) {
+    karg_u8* ka = (karg_u8*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    return *(__attribute__((address_space(4))) const T*)(ka + off);
+}
+#define KARG(field) karg_field<decltype(Scan2Params::field)>((uint32_t)offsetof(Scan2Params, field))
+
 // ASCII lower-casing of four packed bytes (finder/finder.go:140-142 for ASCII text)
 __device__ __forceinline__ uint32_t fold4(uint32_t w) {
     const uint32_t h = w & 0x7F7F7F7Fu;
@@ -223,7 +236,7 @@ __device__ __forceinline__ bool entry_ok(const Ctx& c, uint32_t p, const Front& 
     if (ok && L > inl) {
         // the first L-inl bytes of the term against text[p+1-L .. p-inl], four bytes at a time from the end; term_blob
         // carries 4 bytes of slack in front of every term, the text side needs 3 bytes of slack before the match
-        const uint8_t* tb = P.term_blob + P.term_off[e.a.y];
+        const uint8_t* tb = KARG(term_blob) + KARG(term_off)[e.a.y];
         const uint8_t* tp = c.dbase + (int64_t)p + 1 - L;
         const uint32_t n = L - inl;
         if (c.doc_abs + p + 1 - L >= 3) {
@@ -252,11 +265,11 @@ __device__ __forceinline__ bool entry_ok(const Ctx& c, uint32_t p, const Front& 
 __device__ __forceinline__ void short_record(const Ctx& c, uint32_t sid, uint32_t x3, uint32_t (&r)[3]) {
     // two separate accesses (an LDS read, and -- rarely -- a global one): a pointer that may be either would turn both
     // into flat loads, which wait on the vector-memory AND the LDS counters
-    const bool big = sid == 255 && c.P.short3_big != nullptr;
+    const bool big = sid == 255 && KARG(short3_big) != nullptr;
     const uint32_t* src = c.lrec + 3 * (big ? 0 : sid);
     r[0] = src[0]; r[1] = src[1]; r[2] = src[2];
     if (__builtin_expect(big, 0)) {
-        const uint32_t* g = c.P.shorts_packed + 3 * (size_t)c.P.short3_big[x3];
+        const uint32_t* g = KARG(shorts_packed) + 3 * (size_t)KARG(short3_big)[x3];
         r[0] = g[0]; r[1] = g[1]; r[2] = g[2];
     }
 }
@@ -272,8 +285,8 @@ __device__ __forceinline__ void cand_finish(const Ctx& c, const Cand& k, uint32_
         if (MODE == 0) {
             if (cnt < kScan2StageCap) stage[cnt * 64] = make_uint2(term, pos);
         } else {
-            P.pool_term[out_base + cnt] = term;
-            if (P.want_pos) P.pool_pos[out_base + cnt] = pos;
+            KARG(pool_term)[out_base + cnt] = term;
+            if (P.want_pos) KARG(pool_pos)[out_base + cnt] = pos;
         }
         cnt++;
     };
@@ -576,8 +589,8 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
                 uint32_t mx = f;
                 for (int s = 32; s; s >>= 1) { f += __shfl_xor(f, s, 64); uint32_t o = __shfl_xor(mx, s, 64); mx = o > mx ? o : mx; }
                 if (lane == 0) {
-                    atomicAdd(reinterpret_cast<unsigned long long*>(P.dbg_counters), (unsigned long long)f);
-                    atomicAdd(reinterpret_cast<unsigned long long*>(P.dbg_counters + 1), (unsigned long long)mx);
+                    atomicAdd(reinterpret_cast<unsigned long long*>(KARG(dbg_counters)), (unsigned long long)f);
+                    atomicAdd(reinterpret_cast<unsigned long long*>(KARG(dbg_counters) + 1), (unsigned long long)mx);
                 }
             }
             if (P.dbg & 1) m0 = m1 = m2 = m3 = 0;
@@ -667,7 +680,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    if (P.dbg & 2) { if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(P.dbg_counters + 2), (unsigned long long)ns); }
+                    if (P.dbg & 2) { if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(KARG(dbg_counters) + 2), (unsigned long long)ns); }
                     // stage B: the survivors, densely packed over the lanes, go to the L2 bucket table; the room behind
                     // them in the candidate list parks the entries of multi-term buckets
                     Deferred dfr;
@@ -696,9 +709,9 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
                 const uint32_t nh = nf;
                 if (nh <= kScan2FifoCap) {
                     if (nh > slab_left) {
-                        const uint32_t want = nh > P.slab ? nh : P.slab;
+                        const uint32_t want = nh > KARG(slab) ? nh : KARG(slab);
                         uint64_t nb = 0;
-                        if (lane == 0) nb = atomicAdd(reinterpret_cast<unsigned long long*>(P.cursor), (unsigned long long)want);
+                        if (lane == 0) nb = atomicAdd(reinterpret_cast<unsigned long long*>(KARG(cursor)), (unsigned long long)want);
                         slab_next = __shfl(nb, 0, 64);
                         slab_left = want;
                     }
@@ -706,18 +719,18 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
                     slab_next += nh;
                     slab_left -= nh;
                     wave_matches += nh;
-                    if (lane == 0) { P.unit_start[u] = base; P.unit_count[u] = nh; }
-                    if (base + nh <= P.pool_cap)
+                    if (lane == 0) { KARG(unit_start)[u] = base; KARG(unit_count)[u] = nh; }
+                    if (base + nh <= KARG(pool_cap))
                         for (uint32_t i = lane; i < nh; i += 64) {
                             const uint2 r = fifo[i];
-                            P.pool_term[base + i] = r.x;
-                            if (P.want_pos) P.pool_pos[base + i] = r.y;
+                            KARG(pool_term)[base + i] = r.x;
+                            if (P.want_pos) KARG(pool_pos)[base + i] = r.y;
                         }
                     done = true;
                 }
                 __builtin_amdgcn_wave_barrier();
             }
-            if (ftotal == 0 && lane == 0) { P.unit_start[u] = slab_next; P.unit_count[u] = 0; }
+            if (ftotal == 0 && lane == 0) { KARG(unit_start)[u] = slab_next; KARG(unit_count)[u] = 0; }
             if (done) continue;
         }
 
@@ -729,9 +742,9 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
         const uint32_t incl = wave_incl_scan(cnt);
         const uint32_t total = __shfl(incl, 63, 64);
         if (total > slab_left) {          // wave-uniform: take a new slab
-            const uint32_t want = total > P.slab ? total : P.slab;
+            const uint32_t want = total > KARG(slab) ? total : KARG(slab);
             uint64_t nb = 0;
-            if (lane == 0) nb = atomicAdd(reinterpret_cast<unsigned long long*>(P.cursor), (unsigned long long)want);
+            if (lane == 0) nb = atomicAdd(reinterpret_cast<unsigned long long*>(KARG(cursor)), (unsigned long long)want);
             slab_next = __shfl(nb, 0, 64);
             slab_left = want;
         }
@@ -739,16 +752,16 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
         slab_next += total;
         slab_left -= total;
         wave_matches += total;
-        if (lane == 0) { P.unit_start[u] = base; P.unit_count[u] = total; }
-        if (total && base + total <= P.pool_cap) {
+        if (lane == 0) { KARG(unit_start)[u] = base; KARG(unit_count)[u] = total; }
+        if (total && base + total <= KARG(pool_cap)) {
             const uint64_t mine = base + incl - cnt;
             if (cnt <= kScan2StageCap) {
 #pragma unroll
                 for (uint32_t k = 0; k < kScan2StageCap; k++)
                     if (k < cnt) {
                         const uint2 r = stage[k * 64];
-                        P.pool_term[mine + k] = r.x;
-                        if (P.want_pos) P.pool_pos[mine + k] = r.y;
+                        KARG(pool_term)[mine + k] = r.x;
+                        if (P.want_pos) KARG(pool_pos)[mine + k] = r.y;
                     }
             }
             // lanes whose matches did not fit the staging area run the verification again, writing directly
@@ -760,7 +773,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
         }
     }
     if (lane == 0 && wave_matches)
-        atomicAdd(reinterpret_cast<unsigned long long*>(P.n_matches), (unsigned long long)wave_matches);
+        atomicAdd(reinterpret_cast<unsigned long long*>(KARG(n_matches)), (unsigned long long)wave_matches);
 }
 
 }  // namespace

@@ -343,13 +343,20 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
             if (u < pf_U1) { pf_s = S.unit_start[u]; pf_n = S.unit_count[u]; pf_doc = S.units[u].doc; }
         }
     };
+    // ... and, once those have arrived (after the evaluation), the first four slab entries of that unit
+    uint32_t pf_t[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    auto prefetch_terms = [&]() {
+        const uint32_t member = threadIdx.x % kTeam;
+#pragma unroll
+        for (int q = 0; q < 4; q++) pf_t[q] = member + q * kTeam < pf_n ? S.term[pf_s + member + q * kTeam] : 0xFFFFFFFFu;
+    };
     prefetch(blockIdx.x);
+    prefetch_terms();
     for (uint64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
         const uint64_t d0 = g * G;
         const uint32_t nd = (uint32_t)(S.n_docs - d0 < (uint64_t)G ? S.n_docs - d0 : (uint64_t)G);
 
         // ---- 1. presence matrix ------------------------------------------------------------------------------
-        // four slab entries per lane are in flight at a time
         if (!(S.dbg & 1)) {
             const uint32_t member = threadIdx.x % kTeam;
             const uint64_t U0 = pf_U0, U1 = pf_U1;
@@ -358,12 +365,15 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
                 const uint64_t s = pf ? pf_s : S.unit_start[u];
                 const uint32_t n = pf ? pf_n : S.unit_count[u];
                 const uint32_t j = (uint32_t)((pf ? pf_doc : S.units[u].doc) - d0);
-                for (uint32_t i = member; i < n; i += 4 * kTeam) {
-                    uint32_t t[4];
+                // twelve slab entries per lane are in flight at a time (the first four came with the prefetch): a unit of
+                // up to 192 matches is one round trip
+                for (uint32_t i = member; i < n; i += 12 * kTeam) {
+                    uint32_t t[12];
 #pragma unroll
-                    for (int q = 0; q < 4; q++) t[q] = i + q * kTeam < n ? S.term[s + i + q * kTeam] : 0xFFFFFFFFu;
+                    for (int q = 0; q < 12; q++)
+                        t[q] = (q < 4 && pf && i == member) ? pf_t[q] : i + q * kTeam < n ? S.term[s + i + q * kTeam] : 0xFFFFFFFFu;
 #pragma unroll
-                    for (int q = 0; q < 4; q++)
+                    for (int q = 0; q < 12; q++)
                         if (t[q] != 0xFFFFFFFFu) {
                             const size_t bp = (size_t)t[q] * G + j;              // bit j of element t
                             if (P_LDS) __hip_atomic_fetch_or(&Pw[bp >> 5], 1u << (bp & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -427,21 +437,25 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
                 O[lane * tile_words + r * 2] = (uint32_t)mine;
                 if (r * 2 + 1 < tw) O[lane * tile_words + r * 2 + 1] = (uint32_t)(mine >> 32);
             }
+            // ---- 3. (LDS) the last tile's evaluation was the last reader of P: wipe it for the next group in the same
+            // phase -- a handful of wide stores per lane, no re-read of the matches
+            if (P_LDS && w0 + tile_words >= bm_words) {
+                uint4* P4 = reinterpret_cast<uint4*>(P);
+                for (uint32_t i = threadIdx.x; i < (uint32_t)(((size_t)S.n_slots * sizeof(PT) + 15) / 16); i += kSolveBlockThreads) P4[i] = make_uint4(0, 0, 0, 0);
+            }
             __syncthreads();
-            // rows of the tile -> global bitmap
+            // rows of the tile -> global bitmap.  No barrier behind it: O is written again only after the barrier that
+            // follows the next evaluation, and the next group's presence build touches P alone
             for (uint32_t i = threadIdx.x; i < nd * tw; i += kSolveBlockThreads) {
                 const uint32_t j = i / tw, c = i - j * tw;
                 S.bitmap[(d0 + j) * bm_words + w0 + c] = O[j * tile_words + c];
             }
-            __syncthreads();
         }
 
-        // ---- 3. clear the touched entries of P for the next group ---------------------------------------------------
-        if (P_LDS) {
-            // LDS: wiping the whole matrix is a handful of wide stores per lane, no HBM re-read of the matches
-            uint4* P4 = reinterpret_cast<uint4*>(P);
-            for (uint32_t i = threadIdx.x; i < (uint32_t)(((size_t)S.n_slots * sizeof(PT) + 15) / 16); i += kSolveBlockThreads) P4[i] = make_uint4(0, 0, 0, 0);
-        } else {
+        prefetch_terms();
+
+        // ---- 3. (HBM) clear the touched entries of P for the next group ----------------------------------------------
+        if (!P_LDS) {
             for (uint32_t j = threadIdx.x / kTeam; j < nd; j += kSolveBlockThreads / kTeam) {
                 const uint32_t member = threadIdx.x % kTeam;
                 const uint64_t d = d0 + j;
@@ -459,8 +473,8 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
                 }
             }
             __threadfence_block();
+            __syncthreads();
         }
-        __syncthreads();
     }
 }
 

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Per-call latency of the reference-shaped entry points (one document per call), host memory in, results out:
+Finder.ProcessText and GpuEngine.FindSubstrings at a few document sizes.  Not part of the bench contract.
+
+    python tools/bench_latency.py [--terms T] [--exprs E] [--reps N]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gofindthem_amd.finder import EmptyRgxEngine, Finder, GpuEngine  # noqa: E402
+from gofindthem_amd.workload import Workload, make_expressions  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--terms", type=int, default=10000)
+ap.add_argument("--exprs", type=int, default=1000)
+ap.add_argument("--reps", type=int, default=100)
+args = ap.parse_args()
+
+w = Workload(args.terms)
+exprs = make_expressions(w.terms(), args.exprs, cover=True)
+f = Finder(GpuEngine(), EmptyRgxEngine(), False)
+f.AddExpressions(exprs)
+blob, off = w.docs_host(0, 260)
+full = blob.tobytes()
+one_doc = full[int(off[0]):int(off[1])]
+out = {"terms": args.terms, "exprs": args.exprs, "ProcessText_us": {}, "FindSubstrings_us": {}}
+for name, text in (("one ~4 KB document", one_doc), ("64 KB", full[:65536]), ("1 MB", full[:1 << 20])):
+    f.ProcessText(text)
+    f.ProcessText(text)
+    t0 = time.perf_counter()
+    for _ in range(args.reps):
+        f.ProcessText(text)
+    out["ProcessText_us"][name] = (time.perf_counter() - t0) / args.reps * 1e6
+eng = GpuEngine()
+eng.BuildEngine([t.decode() for t in w.terms()], False)
+for name, text in (("one ~4 KB document", one_doc), ("1 MB", full[:1 << 20])):
+    s = text.decode()
+    eng.FindSubstrings(s)
+    t0 = time.perf_counter()
+    for _ in range(max(args.reps // 4, 5)):
+        m = eng.FindSubstrings(s)
+    out["FindSubstrings_us"][name] = (time.perf_counter() - t0) / max(args.reps // 4, 5) * 1e6
+    out.setdefault("FindSubstrings_matches", {})[name] = len(m)
+print(json.dumps(out))

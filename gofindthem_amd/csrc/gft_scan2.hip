@@ -67,14 +67,20 @@ __device__ __forceinline__ uint32_t fold4(uint32_t w) {
 }
 __device__ __forceinline__ uint32_t fold1(uint32_t b) { return (b - 'A' < 26u) ? b + 32 : b; }
 
+// inclusive prefix sum over the 64 lanes with DPP moves (row shifts inside the four rows of 16 lanes, then the row
+// totals are broadcast into the rows behind them): ten VALU instructions, no LDS traffic, no index arithmetic
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
-    const uint32_t l = lane_id();
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) {
-        uint32_t o = __shfl_up(v, s, 64);
-        if ((int)l >= s) v += o;
-    }
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);    // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);    // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);    // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);    // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2 and 3
     return v;
+}
+// value of lane l (wave-uniform l) -- a scalar read instead of an LDS permute
+__device__ __forceinline__ uint32_t lane_value(uint32_t v, uint32_t l) {
+    return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(l));
 }
 
 struct Ctx {
@@ -382,8 +388,7 @@ __device__ __forceinline__ void finish_long(const Ctx& c, bool on, uint32_t rel,
     }
     if (!__any(multi)) return;
     const uint32_t n_ent = multi ? e.a.z : 0, more_at = e.a.y & ~kScan2Multi;
-    uint32_t tot = n_ent;
-    for (int sh = 32; sh; sh >>= 1) tot += __shfl_xor(tot, sh, 64);
+    const uint32_t tot = lane_value(wave_incl_scan(n_ent), 63);
     if (tot <= d.cap - d.n) {
         // park every entry: lanes take consecutive cells, entry after entry
         for (uint32_t j = 0; __any(j < n_ent); j++) {
@@ -600,18 +605,18 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
         if (!ORDERED) {
             const uint32_t f = __popc(m0) + __popc(m1) + __popc(m2) + __popc(m3) + (lane == 0 ? nborder : 0);
             const uint32_t fincl = wave_incl_scan(f);
-            const uint32_t ftotal = __shfl(fincl, 63, 64);
+            const uint32_t ftotal = lane_value(fincl, 63);
             bool done = ftotal == 0;
             if (ftotal) {
                 uint32_t nf = 0;                                   // matches in the fifo (wave-uniform)
                 // passes over lane ranges whose flagged positions fit the LDS list (one pass for a typical unit)
                 for (uint32_t l0 = 0; l0 < 64;) {
-                    const uint32_t before = l0 ? __shfl(fincl, (int)l0 - 1, 64) : 0;
+                    const uint32_t before = l0 ? lane_value(fincl, l0 - 1) : 0;
                     const bool fits = lane >= l0 && fincl - before <= P.cand_cap;
                     const uint64_t fm = __ballot(fits) >> l0;
                     const uint32_t nl = fm == ~0ull >> l0 ? 64 - l0 : (uint32_t)__builtin_ctzll(~fm);   // lanes in this pass (>= 1)
                     const uint32_t l1 = l0 + nl;
-                    const uint32_t ptotal = __shfl(fincl, (int)l1 - 1, 64) - before;
+                    const uint32_t ptotal = lane_value(fincl, l1 - 1) - before;
                     if (lane >= l0 && lane < l1) {
                         uint32_t wpos = fincl - f - before;
                         const uint32_t rel = lane * C + kScan2MaxOff;
@@ -740,7 +745,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
 
         // ---- output -------------------------------------------------------------------------------------------------
         const uint32_t incl = wave_incl_scan(cnt);
-        const uint32_t total = __shfl(incl, 63, 64);
+        const uint32_t total = lane_value(incl, 63);
         if (total > slab_left) {          // wave-uniform: take a new slab
             const uint32_t want = total > KARG(slab) ? total : KARG(slab);
             uint64_t nb = 0;

@@ -201,6 +201,23 @@ __device__ __forceinline__ uint64_t inord_wave(const SolveParams& S, bool is_ino
 // programs, so the interpreter is predicated rather than branched: every word costs one presence read and a handful of
 // selects.  DEEP = false keeps the accumulator stack in two registers (programs that nest deeper are sorted into
 // blocks of their own and take DEEP = true: four registers backed by scratch).
+// maximum over the 64 lanes with DPP moves: running maximum along the four rows of 16 lanes, row results broadcast into
+// the rows behind them, lane 63 ends up with the maximum of all (no LDS permutes, no index arithmetic)
+template <int CTRL, int ROWS, bool ZERO_FILL>
+__device__ __forceinline__ uint32_t dpp_max_step(uint32_t v) {
+    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWS, 0xF, ZERO_FILL);
+    return o > v ? o : v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    v = dpp_max_step<0x111, 0xF, true>(v);      // row_shr:1
+    v = dpp_max_step<0x112, 0xF, true>(v);      // row_shr:2
+    v = dpp_max_step<0x114, 0xF, true>(v);      // row_shr:4
+    v = dpp_max_step<0x118, 0xF, true>(v);      // row_shr:8
+    v = dpp_max_step<0x142, 0xA, false>(v);     // row_bcast:15 -> rows 1 and 3
+    v = dpp_max_step<0x143, 0xC, false>(v);     // row_bcast:31 -> rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 // ALL 64 lanes of a wave call this together (lanes without a program pass chunks = 0): the trip count is the wave's
 // maximum, finished lanes run kFopNop words, so the INORD steps can use the whole wave.
 template <bool P_LDS, bool DEEP, class PT, class AT>
@@ -214,13 +231,7 @@ __device__ __forceinline__ AT run_program(const SolveParams& S, const PT* P, con
     uint32_t sp = 0;
     constexpr uint32_t kNop = (uint32_t)kFopNop << 28;
     uint4 nx = chunks ? prog[0] : make_uint4(kNop, kNop, kNop, kNop);
-    uint32_t wchunks = chunks;
-#pragma unroll
-    for (int sh = 32; sh; sh >>= 1) {
-        const uint32_t o = __shfl_xor(wchunks, sh, 64);
-        wchunks = o > wchunks ? o : wchunks;
-    }
-    wchunks = __builtin_amdgcn_readfirstlane(wchunks);
+    const uint32_t wchunks = wave_max_u32(chunks);
     // four words per trip: the next chunk and this chunk's four presence reads are in flight together, so a trip
     // exposes one memory round trip instead of four (programs are padded to whole chunks with kFopNop)
     for (uint32_t c = 0; c < wchunks; c++) {

@@ -20,6 +20,8 @@
 // automaton, not a contraction).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "gft_kernels.hpp"
 
 namespace gft {
@@ -790,7 +792,10 @@ static size_t scan2_fixed_lds(uint32_t filter_words, uint32_t short3_bytes, uint
 bool scan2_plan(uint32_t filter_words, uint32_t short3_bytes, uint32_t shorts_words, uint32_t fpt_lds_bytes, size_t lds_max,
                 uint32_t* waves, uint32_t* cand_cap) {
     const size_t fixed = scan2_fixed_lds(filter_words, short3_bytes, shorts_words, fpt_lds_bytes);
+    const char* cap_env = getenv("GFT_SCAN_MAX_WAVES");        // timing studies: fewer waves per workgroup
+    const uint32_t w_cap = cap_env ? (uint32_t)atoi(cap_env) : 16u;
     for (uint32_t w : {16u, 12u, 8u, 4u}) {
+        if (w > w_cap && w > 4) continue;
         if (fixed + (size_t)w * (kScan2FifoCap * 8 + kScan2CandCapMin * 2) > lds_max) continue;
         size_t per = ((lds_max - fixed) / w) & ~(size_t)15;
         size_t cap = (per - kScan2FifoCap * 8) / 2;

@@ -6,18 +6,21 @@
 //            256-byte LDS table and probes the LDS-resident 4-window filter once per byte.  Neighbouring bytes are
 //            independent (the depth-4 automaton is 4-local), so there is no dependent lookup chain; the per-byte flag
 //            is shifted into a lane-private bit mask with v_alignbit.
-//   phase 2  VERIFY  flagged positions (~12 % of the text) are listed in LDS and dealt densely to the lanes.  Stage A:
+//   phase 2  VERIFY  flagged positions (~8 % of the text) are listed in LDS and dealt densely to the lanes.  Stage A:
 //            LDS-only checks -- terms of length <= 3 from the short3 records, and the per-term fingerprint table (keyed by
-//            the window and the byte in front of it) decides whether a longer term can end here at all.  Stage B: the
-//            survivors (~1.3 %) go to the L2-resident bucket table: both candidate 32-byte slots of the window key are
+//            the window and the byte in front of it) decides whether a longer term can be anchored here at all.  Stage B:
+//            the survivors (~1.3 %) go to the L2-resident bucket table: both candidate 32-byte slots of the window key are
 //            loaded at once, a slot holds a whole term up to 24 bytes, so a lookup is two loads deep (text, slot).
-//   output   balanced path (solver input and, through k_gather_sorted, CSR results): matches are appended to a per-wave
-//            LDS fifo (ballot + mbcnt) and flushed coalesced; ordered path (fallback when a unit's matches overflow the
-//            fifo): matches are staged per lane, a wave prefix sum gives every lane its offset.  The wave takes its room
-//            from a private slab (one global atomic per ~4 K matches).  Nothing is ever truncated: the host re-runs with
-//            a larger pool if the cursor overran.
+//            A term's window is not necessarily its last four bytes (shifted anchors, gft_kernels.hpp): the bytes behind
+//            the window are compared together with the bytes in front of it, and a match belongs to the unit that holds
+//            its END -- a unit that continues a document also verifies the four positions in front of it.
+//   output   matches are appended to a per-wave LDS fifo (ballot + mbcnt) and flushed coalesced, in any order (the solver
+//            does not care; CSR results are sorted per unit by k_gather_sorted).  Units whose matches overflow the fifo
+//            take the staging path: matches are staged per lane, a DPP prefix sum gives every lane its offset.  The wave
+//            takes its room from a private slab (one global atomic per ~4 K matches).  Nothing is ever truncated: the
+//            host re-runs with a larger pool if the cursor overran.
 // HBM traffic: text once + 8 B per match (4 B in presence-only mode); tables are LDS / L2 resident.  No MFMA (byte
-// automaton, not a contraction).
+// automaton, not a contraction).  The kernel is VALU-issue bound (profiles/r1_sq_counters.json).
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>

@@ -1,19 +1,21 @@
 // Host-side compiler for the "suffix-window" scan kernel (gft_scan2.hip).
 //
-// The Aho-Corasick automaton truncated at depth 4 is a 4-local machine: which dictionary terms can END at text
-// position p is a function of the last four byte classes only.  That function is tabulated:
-//   * filter   one bit per 4-class window (direct-indexed, or hashed when the alphabet is large): "some term may end
-//              here".  LDS, probed once per text byte, no dependent chain between bytes.
+// The Aho-Corasick automaton truncated at depth 4 is a 4-local machine: which dictionary terms can have a given one of
+// their 4-byte windows END at text position p is a function of the last four byte classes only.  That function is
+// tabulated:
+//   * filter   one bit per 4-class window (direct-indexed, or hashed when the alphabet is large): "some term may be
+//              anchored here".  LDS, probed once per text byte, no dependent chain between bytes.
 //   * short3   byte per 3-class window: which terms of length <= 3 end here (id of a small record holding up to three
 //              terms, longest first).  LDS; answers the bulk of all matches without leaving the CU.
 //   * fpt      byte per TERM of length >= 4 (cuckoo placement), keyed by (window key, byte in front of the window):
-//              how many more front bytes the cell covers and a 5-bit fingerprint of them; terms of length exactly 4 are
-//              keyed by the window alone.  LDS; rejects most positions where the window matches but the bytes in front do
-//              not, before any L2 access -- also for windows shared by several terms.
-//   * slots    window -> the terms of length >= 4 that end with exactly that window, longest first == the reference's
-//              emission order (node, then its dictionary-suffix chain).  L2, 32-byte slots, two-choice placement; a slot
-//              carries the term's bytes in front of the window (up to 24-byte terms inline), so every match is found from
-//              its own END position and no failure links are needed.
+//              how many more front bytes the cell covers and a 5-bit fingerprint of them; terms whose window is their
+//              first four bytes are keyed by the window alone.  LDS; rejects most positions where the window matches
+//              but the bytes in front do not, before any L2 access -- also for windows shared by several terms.
+//   * slots    window -> the terms of length >= 4 anchored at exactly that window, longest first.  Normally one: the
+//              build shifts a term's window up to kScan2MaxOff bytes away from its end to the rarest, untaken one
+//              (pick_off).  L2, 32-byte slots, two-choice placement; a slot carries the term's bytes in front of the
+//              window and behind it (terms up to 24 bytes inline, 20 when shifted), so every match is found from one
+//              fixed position inside it and no failure links are needed.
 // Same inputs as NewStringMatcher (finder/substringEngine.go:103); same outputs as MatchAll (:111-116).
 #pragma once
 #include <cstdint>

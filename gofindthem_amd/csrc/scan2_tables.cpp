@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <unordered_map>
@@ -205,7 +206,8 @@ void build_scan2_tables(const AcTables& ac, Scan2Tables& t) {
         size_t n_items = 0;
         for (const auto& kv : buckets) n_items += kv.second.size();
         t.fpt_lg = 0;
-        if (n_items > kScan2FptLdsItems) { t.fpt_lg = 15; while (((size_t)1 << t.fpt_lg) * 2 < n_items * 5 && t.fpt_lg < 28) t.fpt_lg++; }
+        const bool force_global = getenv("GFT_SCAN_FPT_GLOBAL") != nullptr;     // timing studies
+        if (n_items > kScan2FptLdsItems || force_global) { t.fpt_lg = 15; while (((size_t)1 << t.fpt_lg) * 2 < n_items * 5 && t.fpt_lg < 28) t.fpt_lg++; }
         const uint32_t flg = t.fpt_lg;
         const size_t n_cells = flg ? (size_t)1 << flg : kScan2FptSize;
         t.fpt.assign(n_cells, 0);

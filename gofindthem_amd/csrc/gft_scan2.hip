@@ -493,7 +493,8 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
     for (uint32_t i = threadIdx.x; i < P.shorts_words; i += blockDim.x) lrec[i] = P.shorts_packed[i];
     __syncthreads();
 
-    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    // (the wave index is the same in all lanes: as a scalar, the unit bookkeeping below stays off the vector ALU)
+    const uint32_t lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t kWaves = blockDim.x >> 6;
     // per-wave LDS region: [fifo / ordered staging: kScan2FifoCap x 8 B][candidate list: cand_cap x 2 B]
     uint8_t* wave_lds = wave_lds_all + (size_t)wave * (kScan2FifoCap * 8 + P.cand_cap * 2);
@@ -515,19 +516,20 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
     uint64_t abs_n = 0;
     if (u < P.n_units) { un_n = P.units[u]; abs_n = P.doc_off[un_n.doc]; }
     for (; u < P.n_units; u += stride) {
-        const Unit un = un_n;
-        const uint64_t doc_abs = abs_n;
+        // the unit's record is the same in all lanes: in scalar registers the bookkeeping below costs no VALU slots
+        const Unit un{(uint32_t)__builtin_amdgcn_readfirstlane(un_n.doc), (uint32_t)__builtin_amdgcn_readfirstlane(un_n.lo),
+                      (uint32_t)__builtin_amdgcn_readfirstlane(un_n.hi)};
+        const uint64_t doc_abs = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(abs_n >> 32)) << 32 |
+                                 (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)abs_n);
         const bool more_units = u + stride < P.n_units;
         if (more_units) un_n = P.units[u + stride];
         const Ctx c{P, cls, filt, P.short3_bytes ? short3 : nullptr, fpt, lrec, P.text + doc_abs, doc_abs, kp2,
-                    __builtin_amdgcn_readfirstlane((uint32_t)(doc_abs < 7)) != 0,
-                    __builtin_amdgcn_readfirstlane((uint32_t)(doc_abs < 23)) != 0, un.lo, un.hi,
-                    __builtin_amdgcn_readfirstlane((uint32_t)(doc_abs + un.hi + 4 > P.text_bytes)) != 0};
+                    doc_abs < 7, doc_abs < 23, un.lo, un.hi, doc_abs + un.hi + 4 > P.text_bytes};
         // A term whose window ends up to kScan2MaxOff bytes before the unit may itself end inside it: those positions
         // (units that continue a document only) join the candidates unconditionally, for such terms only
         const uint32_t nborder = un.lo < kScan2MaxOff ? un.lo : kScan2MaxOff;
         const uint32_t ubase = un.lo - kScan2MaxOff;               // candidate lists hold p - ubase (may wrap; p never does)
-        const uint32_t own = __builtin_amdgcn_readfirstlane(un.hi - un.lo);   // wave-uniform: says so to the compiler
+        const uint32_t own = un.hi - un.lo;
         const uint32_t C = ((own + 63) / 64 + 3) & ~3u;            // bytes per lane (multiple of 4, <= 128)
         const uint32_t my_lo = un.lo + lane * C;
         const uint32_t my_hi = my_lo + C < un.hi ? my_lo + C : un.hi;

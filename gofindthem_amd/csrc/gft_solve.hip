@@ -315,7 +315,7 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
     using AT = typename AType<G>::type;                         // document masks of the evaluation
     constexpr uint32_t kTeam = 16, kTeams = kSolveBlockThreads / kTeam;   // lanes that share one unit while P is built
     extern __shared__ __align__(16) uint8_t smem[];
-    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+    const uint32_t lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: the same in all lanes
     constexpr uint32_t kWaves = kSolveBlockThreads / 64;
     const uint32_t tile_words = S.tile_words;                   // bitmap words covered by one pass (<= kSolveTileWords)
     const uint32_t bm_words = (S.n_exprs + 31) / 32;

@@ -128,11 +128,13 @@ typedef struct gft_extra_matches {
  * document d, words = ceil(n_exprs / 32).  `extra` may be NULL. */
 int gft_process(gft_engine* e, const uint8_t* text_blob, const uint64_t* doc_off, uint64_t n_docs, uint32_t flags,
                 const gft_extra_matches* extra, uint32_t* hit_bitmap);
-/* Device-resident variant (all pointers are device pointers, bitmap written in HBM). */
 /* Solve again over the documents of the LAST gft_process call on this engine (same n_docs), with other caller-supplied
  * matches: the scan results are still in the engine, only the solver kernel runs.  The finder's regex prefilter uses it:
  * first pass without regex hits, host regex engine on the candidate documents only, second pass with their hits. */
 int gft_process_again(gft_engine* e, uint64_t n_docs, const gft_extra_matches* extra, uint32_t* hit_bitmap);
+/* Device-resident variant of gft_process (all pointers are device pointers, bitmap written in HBM).  As for
+ * gft_scan_device, d_text_blob must be readable for 64 bytes past doc_off[n_docs] (vector loads); documents of 4 GiB
+ * and more, and offsets that descend, are refused with GFT_E_INVALID. */
 int gft_process_device(gft_engine* e, const uint8_t* d_text_blob, const uint64_t* d_doc_off, uint64_t n_docs,
                        uint32_t flags, const gft_extra_matches* d_extra, uint32_t* d_hit_bitmap);
 

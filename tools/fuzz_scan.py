@@ -25,7 +25,7 @@ ALPHAS = [b"ab", b"abc", b"abcdefgh", b"abcdefghijklmnopqrstuvwxyz ", b"abcdefgh
           bytes(range(1, 120)), bytes(range(256))]
 
 
-def run(iters, seed, budget_s, eng=None):
+def run(iters, seed, budget_s, eng=None, progress=False):
     """-> (iterations done, None) or (iterations done, description of the first difference)"""
     own = eng is None
     if own:
@@ -41,6 +41,8 @@ def run(iters, seed, budget_s, eng=None):
             if err:
                 return done, err
             done += 1
+            if progress and done % 50 == 0:
+                print("fuzz_scan: %d iterations, %.0f s" % (done, time.time() - t_start), flush=True)
     finally:
         for k, v in saved.items():
             if v is None:
@@ -172,7 +174,7 @@ if __name__ == "__main__":
     ap.add_argument("--budget-s", type=float, default=240.0)
     args = ap.parse_args()
     t0 = time.time()
-    n, err = run(args.iters, args.seed, args.budget_s)
+    n, err = run(args.iters, args.seed, args.budget_s, progress=True)
     if err:
         print("MISMATCH", err)
         sys.exit(1)

@@ -25,6 +25,24 @@ def split_docs(n_docs, world):
     return out
 
 
+def split_docs_by_bytes(doc_off, world):
+    """strong scaling over a real corpus: contiguous document ranges with near-equal TEXT BYTES rather
+    than near-equal document counts, so that a few very long documents do not make one rank the straggler.
+    doc_off = the batch's n_docs + 1 ascending offsets -> list of (first, n) per rank, covering every document once."""
+    import numpy as np
+    off = np.asarray(doc_off, dtype=np.uint64)
+    n_docs = len(off) - 1
+    if n_docs <= 0:
+        return [(0, 0)] * world
+    rel = (off - off[0]).astype(np.float64)
+    total = rel[-1]
+    # rank r starts at the first document whose start offset reaches r / world of the bytes
+    cuts = [int(np.searchsorted(rel[:-1], total * r / world, side="left")) for r in range(world)] + [n_docs]
+    for r in range(1, world + 1):
+        cuts[r] = max(cuts[r], cuts[r - 1])
+    return [(cuts[r], cuts[r + 1] - cuts[r]) for r in range(world)]
+
+
 class BitmapGather:
     """rank 0 receives every rank's [docs, words] int32 bitmap; buffers are allocated once and reused per step.
 

@@ -97,3 +97,23 @@ def test_split_docs():
     assert split_docs(10, 4) == [(0, 3), (3, 3), (6, 2), (8, 2)]
     assert split_docs(0, 2) == [(0, 0), (0, 0)]
     assert shard_range(3, 8, 1000) == (3000, 1000)
+
+
+def test_split_docs_by_bytes():
+    """contiguous ranges, every document exactly once, byte-balanced: one huge document does not drag its neighbours along"""
+    import numpy as np
+    from gofindthem_amd.sharding import split_docs_by_bytes
+    lens = [10] * 50 + [5000] + [10] * 49
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    for world in (1, 2, 3, 4, 8):
+        parts = split_docs_by_bytes(off, world)
+        assert len(parts) == world
+        assert parts[0][0] == 0 and sum(n for _, n in parts) == 100
+        for (a, n), (b, _) in zip(parts, parts[1:]):
+            assert a + n == b
+    two = split_docs_by_bytes(off, 2)
+    assert two[0] == (0, 50) or two[0] == (0, 51)                      # the 5 000-byte document is the border
+    eq = split_docs_by_bytes(np.arange(0, 4100 * 1001, 4100, dtype=np.uint64), 4)
+    assert [n for _, n in eq] == [250, 250, 250, 250]
+    assert split_docs_by_bytes(np.array([7], dtype=np.uint64), 3) == [(0, 0)] * 3
+    assert split_docs_by_bytes(np.array([0, 0, 0], dtype=np.uint64), 2)[0][0] == 0

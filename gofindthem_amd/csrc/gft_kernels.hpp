@@ -141,16 +141,18 @@ constexpr uint32_t kScan2FptSize = 20480;        // cells (one byte each) of the
 constexpr uint32_t kScan2FptLdsItems = 11000;    // more terms of length >= 4 than this: the table moves to global memory (L2),
                                                  // 2^fpt_lg cells at load <= 0.4 -- the LDS-spill path of large dictionaries
 constexpr uint32_t kScan2FptAmbiguous = 0xFF;    // always go to the bucket table
-// Fingerprint table: the LDS-only answer to "can a term of length >= 4 end here at all?" for a position whose window
-// passed the filter.  One cell per TERM (cuckoo placement at build time):
-//   * a term of length exactly 4 is its window: it owns the cell x-hash(key), byte = 5 << 5 | fp5(key);
-//   * a longer term is keyed by (window key, the byte in front of the window): it owns one of the two cells
-//     g-hash_{0,1}(key, b1), byte = code << 5 | fp5(key, b1, the next code - 1 bytes further to the front), code 1..4.
-//     Terms that share a window almost always differ in b1, so multi-term buckets get real fingerprints too; two terms
-//     with the same (key, b1) take both cells, three or more make the cell kScan2FptAmbiguous.
-// 0 = empty cell.  Front bytes as loaded from the text: tw = text[p-7..p-4] (little endian, p-4 on top), case bit cleared
-// on both sides so the same table serves exact and ASCII-folded scans (the bucket table does the exact compare).
-// A position passes if its x-cell or either g-cell passes.  All hashing is 24-bit multiplies (v_mul_u32_u24: full rate).
+// Fingerprint table: the LDS-only answer to "can a term of length >= 4 be anchored here at all?" for a position whose
+// window passed the filter.  One cell per (window, byte in front of it) that some term has (cuckoo placement at build
+// time):
+//   * a term whose window is its first four bytes has no byte in front: it owns the cell x-hash(key);
+//   * any other term is keyed by (window key, b1 = the byte in front of the window): it owns one of the two cells
+//     g-hash_{0,1}(key, b1).  Terms that share a window almost always differ in b1; those that do not share the cell.
+// The cell byte is a 7-bit tag of the window key (1..128), so the cell index proves b1 and the byte proves the window;
+// 0 = empty cell, kScan2FptAmbiguous = pass everything (placement failures).  b1 is taken with its case bit cleared on
+// both sides so the same table serves exact and ASCII-folded scans (the bucket table does the exact compare).
+// A position passes if its x-cell or either g-cell carries its tag.  All hashing is 24-bit multiplies (v_mul_u32_u24:
+// full rate).  (A longer fingerprint -- five bits over up to three more front bytes -- rejected 5 more positions per
+// 4 KB document before the bucket table but cost twice the instructions in stage A: measured slower.)
 // low 32 bits of (a mod 2^24) * (C mod 2^24).  On the device this must be v_mul_u32_u24 (full rate); the compiler
 // tends to pick the quarter-rate v_mul_lo_u32 for the generic form, hence the explicit instruction.
 template <uint32_t C>
@@ -179,22 +181,12 @@ GFT_HD inline uint32_t scan2_fpt_gcell(uint32_t x, uint32_t b1n, int which, uint
                                  : scan2_mul24c<0xC2B2AFu>(x) + scan2_mul24c<0x27D4EBu>(b1n), fpt_lg);
 }
 GFT_HD inline uint32_t scan2_fpt_xmix(uint32_t x) { return scan2_mul24c<0xD4EB2Fu>(x); }
-GFT_HD inline uint32_t scan2_fpt_xbyte(uint32_t xmix) { return 5u << 5 | xmix >> 27; }
-// twn = tw & 0xDFDFDFDF; code 1..4 covers b1 plus 0..3 more bytes (p-5, p-6, p-7)
-GFT_HD inline uint32_t scan2_fpt_gbyte(uint32_t code, uint32_t xmix, uint32_t twn) {
-    const uint32_t rest = twn & 0x00FFFFFFu;
-    const uint32_t a = code == 1 ? 0u : rest >> ((32u - 8u * code) & 31u);
-    const uint32_t h = scan2_mul24c<0xEBCA6Bu>(a ^ (a >> 11)) + xmix + scan2_mul24c<0x5BD1E9u>(twn >> 24);
-    return code << 5 | h >> 27;
-}
+GFT_HD inline uint32_t scan2_fpt_xbyte(uint32_t xmix) { return 1u + (xmix >> 25); }   // 1..128: never empty, never ambiguous
 GFT_HD inline bool scan2_fpt_pass(uint32_t cx, uint32_t cg0, uint32_t cg1, uint32_t xmix, uint32_t tw) {
-    // no early outs: lanes of a wave hold different cells, straight-line code with selects is cheaper than branches
-    const uint32_t twn = tw & 0xDFDFDFDFu;
-    const uint32_t k0 = cg0 >> 5, k1 = cg1 >> 5;
-    const bool g0 = (k0 - 1u < 4u) & (scan2_fpt_gbyte(k0, xmix, twn) == cg0);
-    const bool g1 = (k1 - 1u < 4u) & (scan2_fpt_gbyte(k1, xmix, twn) == cg1);
+    (void)tw;
+    const uint32_t tag = scan2_fpt_xbyte(xmix);
     const bool amb = (cx == kScan2FptAmbiguous) | (cg0 == kScan2FptAmbiguous) | (cg1 == kScan2FptAmbiguous);
-    return (cx == scan2_fpt_xbyte(xmix)) | g0 | g1 | amb;
+    return (cx == tag) | (cg0 == tag) | (cg1 == tag) | amb;
 }
 
 struct Scan2Params {

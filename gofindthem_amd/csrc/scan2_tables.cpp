@@ -214,42 +214,25 @@ void build_scan2_tables(const AcTables& ac, Scan2Tables& t) {
         struct GItem { uint32_t x, b1n; uint8_t val; };
         std::vector<uint32_t> ambiguous;                       // cells that must pass everything
         std::vector<uint8_t> pinned(n_cells, 0);
-        std::map<std::pair<uint32_t, uint32_t>, std::vector<uint8_t>> groups;   // (key, b1n) -> distinct cell bytes
+        std::map<std::pair<uint32_t, uint32_t>, uint8_t> groups;   // (key, b1n) -> the window's tag
         for (const auto& kv : buckets) {
-            const uint32_t x = kv.first, xm = scan2_fpt_xmix(x);
+            const uint32_t x = kv.first;
+            const uint8_t tag = (uint8_t)scan2_fpt_xbyte(scan2_fpt_xmix(x));
             for (const Ent& e : kv.second) {
                 const std::string& s = ac.terms[e.term_id];
                 const int L = (int)e.len;
-                if (L == 4) {
+                if (L == 4) {                                  // no byte in front of the window: keyed by the window alone
                     const uint32_t c = scan2_fpt_xcell(x, flg);
-                    const uint8_t v = (uint8_t)scan2_fpt_xbyte(xm);
-                    if (t.fpt[c] != 0 && t.fpt[c] != v) ambiguous.push_back(c);
-                    t.fpt[c] = v;
+                    if (t.fpt[c] != 0 && t.fpt[c] != tag) ambiguous.push_back(c);
+                    t.fpt[c] = tag;
                     pinned[c] = 1;
                     continue;
                 }
-                uint32_t tw = 0;                               // text[p-7..p-4] under this term
-                for (int k = 0; k < 4; k++)
-                    if (L - 8 + k >= 0) tw |= (uint32_t)(uint8_t)s[L - 8 + k] << (8 * k);
-                const uint32_t twn = tw & 0xDFDFDFDFu;
-                const uint32_t code = (uint32_t)std::min(L - 5, 3) + 1;
-                auto& g = groups[{x, twn >> 24}];
-                const uint8_t v = (uint8_t)scan2_fpt_gbyte(code, xm, twn);
-                if (std::find(g.begin(), g.end(), v) == g.end()) g.push_back(v);
+                groups[{x, (uint32_t)((uint8_t)s[L - 5] & 0xDFu)}] = tag;
             }
         }
         std::vector<GItem> singles;
-        for (const auto& kv : groups) {
-            const uint32_t x = kv.first.first, b1n = kv.first.second;
-            const uint32_t c0 = scan2_fpt_gcell(x, b1n, 0, flg), c1 = scan2_fpt_gcell(x, b1n, 1, flg);
-            if (kv.second.size() == 1) { singles.push_back(GItem{x, b1n, kv.second[0]}); continue; }
-            if (kv.second.size() == 2 && c0 != c1 && t.fpt[c0] == 0 && t.fpt[c1] == 0) {
-                t.fpt[c0] = kv.second[0]; t.fpt[c1] = kv.second[1];
-                pinned[c0] = pinned[c1] = 1;
-            } else {
-                ambiguous.push_back(c0);
-            }
-        }
+        for (const auto& kv : groups) singles.push_back(GItem{kv.first.first, kv.first.second, kv.second});
         std::vector<GItem> owner(n_cells, GItem{0, 0, 0});
         uint32_t rng = 0x12345u;
         for (GItem cur : singles) {

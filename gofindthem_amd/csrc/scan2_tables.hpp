@@ -7,10 +7,10 @@
 //              anchored here".  LDS, probed once per text byte, no dependent chain between bytes.
 //   * short3   byte per 3-class window: which terms of length <= 3 end here (id of a small record holding up to three
 //              terms, longest first).  LDS; answers the bulk of all matches without leaving the CU.
-//   * fpt      byte per TERM of length >= 4 (cuckoo placement), keyed by (window key, byte in front of the window):
-//              how many more front bytes the cell covers and a 5-bit fingerprint of them; terms whose window is their
-//              first four bytes are keyed by the window alone.  LDS; rejects most positions where the window matches
-//              but the bytes in front do not, before any L2 access -- also for windows shared by several terms.
+//   * fpt      byte per (window, byte in front of the window) that some term of length >= 4 has (cuckoo placement): a
+//              7-bit tag of the window key; terms whose window is their first four bytes are keyed by the window alone.
+//              LDS; rejects most positions where the window matches but the byte in front does not, before any L2
+//              access -- also for windows shared by several terms.
 //   * slots    window -> the terms of length >= 4 anchored at exactly that window, longest first.  Normally one: the
 //              build shifts a term's window up to kScan2MaxOff bytes away from its end to the rarest, untaken one
 //              (pick_off).  L2, 32-byte slots, two-choice placement; a slot carries the term's bytes in front of the

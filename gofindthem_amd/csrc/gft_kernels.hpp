@@ -80,6 +80,7 @@ struct SolveParams {
     const uint32_t* groups;      // [n_groups][2] = offset, length into gprog
     const uint32_t* order;       // [n_exprs] evaluation order inside every output tile (gft_set_programs)
     const Unit* units;           // the scan's work units (document of every unit)
+    uint32_t has_inord;          // some program has an INORD group (0: the kernel variant without the position algebra)
     const uint32_t* blk_deep;    // per 64 sorted programs: 1 = some program nests deeper than kSolveRegStack
     const uint32_t* fprog_t;     // the same programs per sorted block, transposed by chunk: words 4c..4c+3 of lane l at fblk_off[b] + (c * 64 + l) * 4
     const uint32_t* fblk_off;    // (read when the programs do not fit LDS: coalesced instead of one stream per lane)

@@ -220,7 +220,7 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 
 // ALL 64 lanes of a wave call this together (lanes without a program pass chunks = 0): the trip count is the wave's
 // maximum, finished lanes run kFopNop words, so the INORD steps can use the whole wave.
-template <bool P_LDS, bool DEEP, class PT, class AT>
+template <bool P_LDS, bool DEEP, bool INORD, class PT, class AT>
 __device__ __forceinline__ AT run_program(const SolveParams& S, const PT* P, const uint4* prog, uint32_t stride, uint32_t chunks,
                                           AT valid, uint64_t d0) {
     // HBM-resident P was written with L2 atomics by other waves: read it past this CU's L1
@@ -231,13 +231,15 @@ __device__ __forceinline__ AT run_program(const SolveParams& S, const PT* P, con
     uint32_t sp = 0;
     constexpr uint32_t kNop = (uint32_t)kFopNop << 28;
     uint4 nx = chunks ? prog[0] : make_uint4(kNop, kNop, kNop, kNop);
+    uint4 nx2 = chunks > 1 ? prog[stride] : make_uint4(kNop, kNop, kNop, kNop);     // two chunks ahead (programs in L2)
     const uint32_t wchunks = wave_max_u32(chunks);
-    // four words per trip: the next chunk and this chunk's four presence reads are in flight together, so a trip
+    // four words per trip: the next two chunks and this chunk's four presence reads are in flight together, so a trip
     // exposes one memory round trip instead of four (programs are padded to whole chunks with kFopNop)
     for (uint32_t c = 0; c < wchunks; c++) {
         const uint32_t w[4] = {nx.x, nx.y, nx.z, nx.w};
-        nx = make_uint4(kNop, kNop, kNop, kNop);
-        if (c + 1 < chunks) nx = prog[(size_t)(c + 1) * stride];
+        nx = nx2;
+        nx2 = make_uint4(kNop, kNop, kNop, kNop);
+        if (c + 2 < chunks) nx2 = prog[(size_t)(c + 2) * stride];
         AT pv[4];
         bool rare = false;
 #pragma unroll
@@ -246,7 +248,8 @@ __device__ __forceinline__ AT run_program(const SolveParams& S, const PT* P, con
             pv[q] = ld(op < kFopAndPop ? (w[q] & 0x0FFFFFFFu) : 0);
             rare |= op == kFopNot || op == kFopInord;
         }
-        const bool any_rare = __any(rare);                      // wave-uniform: only around INORD groups
+        const bool any_rare = INORD && __any(rare);             // wave-uniform: only around INORD groups (INORD = false:
+                                                                // the program set has none, the path is compiled out)
         auto step = [&](const uint32_t wq, const AT pvq, const bool with_rare) __attribute__((always_inline)) {
             const uint32_t op = wq >> 28, a = wq & 0x0FFFFFFFu;
             const bool is_s = op < kFopAndPop;
@@ -309,7 +312,7 @@ template <> struct AType<64> { using type = uint64_t; };
 // G = documents per group = bits of a presence-matrix element: 64 when 8 bytes per slot fit LDS, else 32 / 16 / 8 so that
 // large dictionaries still keep P in LDS (the evaluation then covers fewer documents per operation, but P stops being an
 // L2 ping-pong of atomics and random reads)
-template <bool P_LDS, bool PROG_LDS, int G>
+template <bool P_LDS, bool PROG_LDS, int G, bool INORD>
 __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const SolveParams S) {
     using PT = typename PType<G>::type;
     using AT = typename AType<G>::type;                         // document masks of the evaluation
@@ -433,8 +436,8 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
                     const uint32_t stride = PROG_LDS ? 1u : 64u;
                     const bool deep = S.blk_deep[(e0 >> 6) + b] != 0;              // wave-uniform
                     const uint32_t chunks = has ? len / 4 : 0;
-                    const AT r = deep ? run_program<P_LDS, true, PT, AT>(S, P, prog, stride, chunks, (AT)valid, d0)
-                                      : run_program<P_LDS, false, PT, AT>(S, P, prog, stride, chunks, (AT)valid, d0);
+                    const AT r = deep ? run_program<P_LDS, true, INORD, PT, AT>(S, P, prog, stride, chunks, (AT)valid, d0)
+                                      : run_program<P_LDS, false, INORD, PT, AT>(S, P, prog, stride, chunks, (AT)valid, d0);
                     if (has) R[e - e0] = r;
                 }
             }
@@ -501,8 +504,11 @@ namespace {
 template <int G>
 hipError_t launch_g(const SolveParams& S, bool p_in_lds, bool prog_in_lds, unsigned grid, size_t lds, hipStream_t st) {
     using Kern = void (*)(const SolveParams);
-    const Kern fn = p_in_lds ? (prog_in_lds ? k_solve_groups<true, true, G> : k_solve_groups<true, false, G>)
-                             : (prog_in_lds ? k_solve_groups<false, true, 64> : k_solve_groups<false, false, 64>);
+    const bool io = S.has_inord != 0;
+    const Kern fn = p_in_lds ? (prog_in_lds ? (io ? k_solve_groups<true, true, G, true> : k_solve_groups<true, true, G, false>)
+                                            : (io ? k_solve_groups<true, false, G, true> : k_solve_groups<true, false, G, false>))
+                             : (prog_in_lds ? (io ? k_solve_groups<false, true, 64, true> : k_solve_groups<false, true, 64, false>)
+                                            : (io ? k_solve_groups<false, false, 64, true> : k_solve_groups<false, false, 64, false>));
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     fn<<<dim3(grid), dim3(kSolveBlockThreads), lds, st>>>(S);

@@ -65,7 +65,10 @@ struct gft_engine {
     // suffix-window scan (gft_scan2.hip); the two-tier DFA kernel above stays as the general fallback
     Scan2Tables s2;
     bool use_scan2 = false;
-    DevBuf d_s2_filter, d_s2_slots, d_s2_more, d_s2_cls, d_s2_cls_fold, d_s2_term_blob, d_s2_term_off, d_nmatches, d_dbg, d_flags;
+    DevBuf d_s2_filter, d_s2_slots, d_s2_more, d_s2_cls, d_s2_cls_fold, d_s2_term_blob, d_s2_term_off, d_dbg;
+    // control block (64 B): [0] u32 bad-offsets flag, [8] u64 pool cursor, [16] u64 exact match count, [32] u64 n_units,
+    // [40] u64 first text offset, [48] u64 last text offset -- one memset per batch, one read-back per synchronisation
+    DevBuf d_ctl;
     DevBuf d_s2_short3, d_s2_shorts_packed, d_s2_short3_big, d_s2_fpt;
     uint32_t scan2_short3_bytes = 0;
     uint32_t scan2_k2_waves = 0, scan2_cand_cap = 0;    // scan2_plan
@@ -86,7 +89,7 @@ struct gft_engine {
     DevBuf d_pscratch;                    // HBM presence matrices when n_slots * 8 B does not fit LDS
 
     // workspace
-    DevBuf d_unit_cnt, d_unit_base, d_units, d_partial, d_cursor, d_pool_term, d_pool_pos, d_unit_start,
+    DevBuf d_unit_cnt, d_unit_base, d_units, d_partial, d_pool_term, d_pool_pos, d_unit_start,
         d_unit_count, d_unit_out, d_term, d_pos, d_match_off;
     uint64_t pool_cap = 0;
     // staging for the host-buffer entry points
@@ -327,6 +330,8 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
     const uint32_t unit_max = e->use_scan2 ? e->scan2_unit_max : kTextBuf - warm;
 
     // 1. work units
+    HIP_TRY(e->d_ctl.ensure(64), "control alloc");
+    HIP_TRY(hipMemsetAsync(e->d_ctl.p, 0, 24, st), "memset");     // flag, cursor, match count
     HIP_TRY(e->d_unit_cnt.ensure(n_docs * 4), "unit alloc");
     HIP_TRY(e->d_unit_base.ensure((n_docs + 1) * 8), "unit alloc");
     HIP_TRY(e->d_partial.ensure(scan_partials_needed(n_docs) * 8), "unit alloc");
@@ -356,18 +361,16 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
     } else {
         {
             ProfScope ps(e, "aux");
-            HIP_TRY(e->d_flags.ensure(8), "flag alloc");
-            HIP_TRY(hipMemsetAsync(e->d_flags.p, 0, 8, st), "memset");
-            HIP_TRY(launch_unit_count(d_doc_off, n_docs, unit_max, e->d_unit_cnt.as<uint32_t>(), e->d_flags.as<uint32_t>(), st), "unit_count");
+            HIP_TRY(launch_unit_count(d_doc_off, n_docs, unit_max, e->d_unit_cnt.as<uint32_t>(), e->d_ctl.as<uint32_t>(), st), "unit_count");
             HIP_TRY(launch_exclusive_scan(e->d_unit_cnt.as<uint32_t>(), n_docs, e->d_unit_base.as<uint64_t>(),
                                           e->d_partial.as<uint64_t>(), st), "unit scan");
+            HIP_TRY(launch_pack_ctl(e->d_unit_base.as<uint64_t>(), d_doc_off, n_docs, e->d_ctl.as<uint64_t>() + 4, st), "unit scan");
         }
-        HIP_TRY(hipMemcpyAsync(&n_units, e->d_unit_base.as<uint64_t>() + n_docs, 8, hipMemcpyDeviceToHost, st), "readback");
-        HIP_TRY(hipMemcpyAsync(&text_lo, d_doc_off, 8, hipMemcpyDeviceToHost, st), "readback");
-        HIP_TRY(hipMemcpyAsync(&text_hi, d_doc_off + n_docs, 8, hipMemcpyDeviceToHost, st), "readback");
-        uint32_t bad_doc = 0;
-        HIP_TRY(hipMemcpyAsync(&bad_doc, e->d_flags.p, 4, hipMemcpyDeviceToHost, st), "readback");
+        uint64_t rb[7] = {0, 0, 0, 0, 0, 0, 0};
+        HIP_TRY(hipMemcpyAsync(rb, e->d_ctl.p, sizeof rb, hipMemcpyDeviceToHost, st), "readback");
         HIP_TRY(hipStreamSynchronize(st), "sync");
+        n_units = rb[4]; text_lo = rb[5]; text_hi = rb[6];
+        const uint32_t bad_doc = (uint32_t)rb[0];
         if (text_hi < text_lo) return fail(e, GFT_E_INVALID, "doc_off is not ascending");
         if (bad_doc) return fail(e, GFT_E_INVALID, "doc_off is not ascending, or a document is longer than 4 GiB - 1 bytes (positions are 32-bit)");
     }
@@ -377,7 +380,6 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
     HIP_TRY(e->d_unit_count.ensure(n_units * 4), "unit alloc");
     HIP_TRY(e->d_unit_out.ensure((n_units + 1) * 8), "unit alloc");
     HIP_TRY(e->d_partial.ensure(scan_partials_needed(std::max(n_units, n_docs)) * 8), "unit alloc");
-    HIP_TRY(e->d_cursor.ensure(8), "cursor alloc");
     {
         ProfScope ps(e, "aux");
         if (host_units) {
@@ -392,8 +394,7 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
     if (rc) return rc;
     uint64_t total = 0;
     for (int attempt = 0; attempt < 3 && e->use_scan2; attempt++) {
-        HIP_TRY(hipMemsetAsync(e->d_cursor.p, 0, 8, st), "memset");
-        HIP_TRY(hipMemsetAsync(e->d_nmatches.p, 0, 8, st), "memset");
+        if (attempt) HIP_TRY(hipMemsetAsync(e->d_ctl.as<uint8_t>() + 8, 0, 16, st), "memset");
         Scan2Params P;
         P.text = d_text; P.doc_off = d_doc_off; P.units = e->d_units.as<Unit>(); P.n_units = n_units;
         P.filter = e->d_s2_filter.as<uint32_t>(); P.filter_words = (uint32_t)e->s2.filter.size();
@@ -411,10 +412,10 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         P.term_blob = e->d_s2_term_blob.as<uint8_t>(); P.term_off = e->d_s2_term_off.as<uint32_t>();
         P.kp = e->s2.kp; P.pad_class = e->s2.pad_class;
         P.pos_end = (e->build_flags & GFT_POS_END) ? 1 : 0;
-        P.cursor = e->d_cursor.as<uint64_t>(); P.pool_cap = e->pool_cap;
+        P.cursor = e->d_ctl.as<uint64_t>() + 1; P.pool_cap = e->pool_cap;
         P.pool_term = e->d_pool_term.as<uint32_t>(); P.pool_pos = e->d_pool_pos.as<uint32_t>();
         P.unit_start = e->d_unit_start.as<uint64_t>(); P.unit_count = e->d_unit_count.as<uint32_t>();
-        P.n_matches = e->d_nmatches.as<uint64_t>();
+        P.n_matches = e->d_ctl.as<uint64_t>() + 2;
         // slab slack is at most one slab per resident wave: keep it below half the pool
         const uint64_t n_waves = (uint64_t)e->n_cus * e->scan2_k2_waves;
         P.slab = (uint32_t)std::min<uint64_t>(kScan2Slab, std::max<uint64_t>(64, e->pool_cap / (2 * n_waves)));
@@ -439,10 +440,11 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
             // gft_scan2 serves both paths (ordered for CSR results, unordered + balanced for the solver)
             HIP_TRY(launch_scan2(P, e->scan2_k2_waves, e->n_cus, st), "scan kernel launch");
         }
-        uint64_t cursor = 0;
-        HIP_TRY(hipMemcpyAsync(&cursor, e->d_cursor.p, 8, hipMemcpyDeviceToHost, st), "readback");
-        HIP_TRY(hipMemcpyAsync(&total, e->d_nmatches.p, 8, hipMemcpyDeviceToHost, st), "readback");
+        uint64_t ct[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(ct, e->d_ctl.as<uint8_t>() + 8, 16, hipMemcpyDeviceToHost, st), "readback");
         HIP_TRY(hipStreamSynchronize(st), "scan kernel");
+        const uint64_t cursor = ct[0];
+        total = ct[1];
         if (P.dbg & 2) {
             uint64_t c4[4] = {0, 0, 0, 0};
             HIP_TRY(hipMemcpy(c4, e->d_dbg.p, 32, hipMemcpyDeviceToHost), "debug readback");
@@ -465,7 +467,7 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         if (rc) return rc;
     }
     for (int attempt = 0; attempt < 3 && !e->use_scan2; attempt++) {
-        HIP_TRY(hipMemsetAsync(e->d_cursor.p, 0, 8, st), "memset");
+        if (attempt) HIP_TRY(hipMemsetAsync(e->d_ctl.as<uint8_t>() + 8, 0, 16, st), "memset");
         ScanParams P;
         P.text = d_text; P.doc_off = d_doc_off; P.units = e->d_units.as<Unit>(); P.n_units = n_units;
         P.byte_class = e->d_byte_class.as<uint8_t>(); P.delta = e->d_delta.as<uint32_t>();
@@ -475,14 +477,14 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         P.max_term_len = e->tab.max_term_len;
         P.pos_end = (e->build_flags & GFT_POS_END) ? 1 : 0;
         P.fold = (flags & GFT_FOLD_ASCII) ? 1 : 0;
-        P.cursor = e->d_cursor.as<uint64_t>(); P.pool_cap = e->pool_cap;
+        P.cursor = e->d_ctl.as<uint64_t>() + 1; P.pool_cap = e->pool_cap;
         P.pool_term = e->d_pool_term.as<uint32_t>(); P.pool_pos = e->d_pool_pos.as<uint32_t>();
         P.unit_start = e->d_unit_start.as<uint64_t>(); P.unit_count = e->d_unit_count.as<uint32_t>();
         {
             ProfScope ps(e, "scan");
             HIP_TRY(launch_scan_units(P, e->n_cus, st), "scan kernel launch");
         }
-        HIP_TRY(hipMemcpyAsync(&total, e->d_cursor.p, 8, hipMemcpyDeviceToHost, st), "readback");
+        HIP_TRY(hipMemcpyAsync(&total, e->d_ctl.as<uint8_t>() + 8, 8, hipMemcpyDeviceToHost, st), "readback");
         HIP_TRY(hipStreamSynchronize(st), "scan kernel");
         if (total <= e->pool_cap) break;
         if (attempt == 2) return fail(e, GFT_E_HIP, "match pool overflow persisted");
@@ -633,8 +635,8 @@ void gft_engine_destroy(gft_engine* e) {
         DevBuf* all[] = {&e->d_byte_class, &e->d_delta, &e->d_out_term, &e->d_out_link, &e->d_term_len, &e->d_prog,
                          &e->d_prog_off, &e->d_fprog, &e->d_fprog_off, &e->d_groups, &e->d_order, &e->d_blk_deep, &e->d_fprog_t, &e->d_fblk_off, &e->d_pscratch, &e->d_s2_filter,
                          &e->d_s2_slots, &e->d_s2_more, &e->d_s2_cls, &e->d_s2_cls_fold, &e->d_s2_term_blob,
-                         &e->d_s2_term_off, &e->d_nmatches, &e->d_dbg, &e->d_flags, &e->d_s2_short3, &e->d_s2_shorts_packed, &e->d_s2_short3_big, &e->d_s2_fpt,
-&e->d_unit_cnt, &e->d_unit_base, &e->d_units, &e->d_partial, &e->d_cursor,
+                         &e->d_s2_term_off, &e->d_ctl, &e->d_dbg, &e->d_s2_short3, &e->d_s2_shorts_packed, &e->d_s2_short3_big, &e->d_s2_fpt,
+&e->d_unit_cnt, &e->d_unit_base, &e->d_units, &e->d_partial,
                          &e->d_pool_term, &e->d_pool_pos, &e->d_unit_start, &e->d_unit_count, &e->d_unit_out,
                          &e->d_term, &e->d_pos, &e->d_match_off, &e->d_text, &e->d_doc_off, &e->d_bitmap, &e->d_xoff,
                          &e->d_xslot, &e->d_xpos};
@@ -717,7 +719,6 @@ static int install_tables(gft_engine* e, uint32_t flags) {
         if ((rc = upload(e, e->d_s2_term_blob, e->s2.term_blob, "table upload"))) return rc;
         if ((rc = upload(e, e->d_s2_term_off, e->s2.term_off, "table upload"))) return rc;
     }
-    HIP_TRY(e->d_nmatches.ensure(8), "table upload");
     HIP_TRY(hipStreamSynchronize(e->stream), "table upload");
     e->built = true;
     e->scan_valid_docs = ~0ull;

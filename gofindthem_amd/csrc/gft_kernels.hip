@@ -44,6 +44,14 @@ __global__ void __launch_bounds__(256) k_unit_count(const uint64_t* __restrict__
     cnt[d] = n <= unit_max ? 1u : (uint32_t)((n + unit_max - 1) / unit_max);
 }
 
+// one thread: what the host wants to know after the unit prefix sum, side by side, so that it is ONE small copy
+__global__ void k_pack_ctl(const uint64_t* __restrict__ unit_base, const uint64_t* __restrict__ doc_off, uint64_t n_docs,
+                           uint64_t* __restrict__ out) {
+    out[0] = unit_base[n_docs];
+    out[1] = doc_off[0];
+    out[2] = doc_off[n_docs];
+}
+
 __global__ void __launch_bounds__(256) k_unit_fill(const uint64_t* __restrict__ doc_off, uint64_t n_docs,
                                                    const uint64_t* __restrict__ unit_base, Unit* __restrict__ units) {
     uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -335,6 +343,11 @@ hipError_t launch_unit_count(const uint64_t* d_doc_off, uint64_t n_docs, uint32_
                              uint32_t* d_bad, hipStream_t st) {
     if (!n_docs) return hipSuccess;
     k_unit_count<<<dim3((unsigned)((n_docs + 255) / 256)), dim3(256), 0, st>>>(d_doc_off, n_docs, unit_max, d_cnt, d_bad);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_ctl(const uint64_t* d_unit_base, const uint64_t* d_doc_off, uint64_t n_docs, uint64_t* d_out, hipStream_t st) {
+    k_pack_ctl<<<dim3(1), dim3(1), 0, st>>>(d_unit_base, d_doc_off, n_docs, d_out);
     return hipGetLastError();
 }
 

@@ -234,6 +234,8 @@ hipError_t launch_scan2(const Scan2Params& P, uint32_t waves, unsigned n_cus, hi
 // *d_bad |= 1 when a document is longer than 2^32 - 1 bytes (or its offsets descend); such documents get zero units
 hipError_t launch_unit_count(const uint64_t* d_doc_off, uint64_t n_docs, uint32_t unit_max, uint32_t* d_cnt,
                              uint32_t* d_bad, hipStream_t st);
+// d_out[0..2] = number of units, first and last text offset (read back by the host in one copy)
+hipError_t launch_pack_ctl(const uint64_t* d_unit_base, const uint64_t* d_doc_off, uint64_t n_docs, uint64_t* d_out, hipStream_t st);
 hipError_t launch_unit_fill(const uint64_t* d_doc_off, uint64_t n_docs, const uint64_t* d_unit_base, Unit* d_units,
                             hipStream_t st);
 uint64_t scan_partials_needed(uint64_t n);

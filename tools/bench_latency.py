@@ -18,6 +18,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--terms", type=int, default=10000)
 ap.add_argument("--exprs", type=int, default=1000)
 ap.add_argument("--reps", type=int, default=100)
+ap.add_argument("--batch-docs", type=int, default=0, help="also time ProcessTexts on this many documents from host memory")
 args = ap.parse_args()
 
 w = Workload(args.terms)
@@ -45,4 +46,12 @@ for name, text in (("one ~4 KB document", one_doc), ("1 MB", full[:1 << 20])):
         m = eng.FindSubstrings(s)
     out["FindSubstrings_us"][name] = (time.perf_counter() - t0) / max(args.reps // 4, 5) * 1e6
     out.setdefault("FindSubstrings_matches", {})[name] = len(m)
+if args.batch_docs:
+    bb, bo = w.docs_host(0, args.batch_docs)
+    f.ProcessTexts(blob=bb, doc_off=bo)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        f.ProcessTexts(blob=bb, doc_off=bo)
+    dt = (time.perf_counter() - t0) / 3
+    out["ProcessTexts_host_memory"] = {"docs": args.batch_docs, "docs_per_s": args.batch_docs / dt, "text_GB_per_s": int(bo[-1]) / dt / 1e9}
 print(json.dumps(out))

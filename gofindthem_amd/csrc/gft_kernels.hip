@@ -252,11 +252,13 @@ __global__ void __launch_bounds__(256) k_gather(const uint64_t* __restrict__ uni
 // ------------------------------------------------------------------------------------------------------
 // k_gather_sorted: the same for slabs written by gft_scan2 (any order inside a unit; every match lies in the unit
 // that holds its end position): a unit's matches are put into the reference's emission order -- end offset
-// ascending, longer term first -- on the way.  One wave per unit.  Rank sort: keys (end - unit.lo) << 18 |
-// (2^18 - 1 - len) are staged in LDS kScan2FifoCap at a time, every lane counts the keys below each of its own (up to
-// kScan2FifoCap own items per pass; units with more matches take several passes).  Keys are distinct: two matches
-// with the same end and length are the same term.
+// ascending, longer term first -- on the way.  One wave per unit.  Keys (end - unit.lo) << 18 | (2^18 - 1 - len) are
+// distinct: two matches with the same end and length are the same term.  Units of up to kScan2FifoCap matches (the
+// rule): bucketed rank sort, see below.  Larger units: plain rank sort, keys staged in LDS kScan2FifoCap at a time,
+// every lane counts the keys below each of its own (several passes).
 // ------------------------------------------------------------------------------------------------------
+constexpr uint32_t kSortBins = 256;
+
 __global__ void __launch_bounds__(256) k_gather_sorted(const Unit* __restrict__ units,
                                                        const uint64_t* __restrict__ unit_start,
                                                        const uint32_t* __restrict__ unit_count,
@@ -266,8 +268,11 @@ __global__ void __launch_bounds__(256) k_gather_sorted(const Unit* __restrict__ 
                                                        const uint32_t* __restrict__ term_len, uint32_t pos_end,
                                                        uint32_t* __restrict__ term_id, uint32_t* __restrict__ pos) {
     __shared__ uint32_t keys_all[4][kScan2FifoCap];
+    __shared__ uint32_t bins_all[4][2 * kSortBins];                  // per wave: count per bin, then start per bin
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     uint32_t* keys = keys_all[wave];
+    uint32_t* bcnt = bins_all[wave];
+    uint32_t* bstart = bins_all[wave] + kSortBins;
     constexpr uint32_t kPer = kScan2FifoCap / kLane;
     for (uint64_t u = (uint64_t)blockIdx.x * wpb + wave; u < n_units; u += (uint64_t)gridDim.x * wpb) {
         const uint64_t s = unit_start[u], d = unit_out[u];
@@ -280,6 +285,71 @@ __global__ void __launch_bounds__(256) k_gather_sorted(const Unit* __restrict__ 
             const uint32_t end = pos_end ? p : p + L - 1;
             return (end - lo) << 18 | (0x3FFFFu - (L < 0x3FFFFu ? L : 0x3FFFFu));
         };
+        if (n <= kScan2FifoCap) {
+            // The common case, at most four matches per lane.  Bucketed rank sort: the end offsets of a unit span at most
+            // 8 KiB, so 256 bins by end offset hold a few matches each; a match's rank = the start of its bin (histogram
+            // + prefix sum) + the number of smaller keys inside the bin (a loop over the largest bin only, instead of over
+            // all n keys).
+            const uint32_t own = units[u].hi - lo;
+            uint32_t shift = 0;
+            while ((own >> shift) > kSortBins) shift++;
+            uint32_t t[kPer], p[kPer], k[kPer], bin[kPer], slot[kPer];
+            for (uint32_t i = lane; i < kSortBins; i += kLane) bcnt[i] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (uint32_t q = 0; q < kPer; q++) {
+                const uint32_t i = lane + q * kLane;
+                k[q] = 0xFFFFFFFFu; t[q] = 0; p[q] = 0; bin[q] = 0; slot[q] = 0;
+                if (i < n) {
+                    k[q] = key_of(i, t[q], p[q]);
+                    bin[q] = (k[q] >> 18) >> shift;
+                    if (bin[q] >= kSortBins) bin[q] = kSortBins - 1;
+                    slot[q] = atomicAdd(&bcnt[bin[q]], 1u);              // arrival order inside the bin
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // exclusive prefix sum over the bins: four consecutive bins per lane, a wave scan over the lane sums
+            constexpr uint32_t kBinsPerLane = kSortBins / kLane;
+            uint32_t c[kBinsPerLane], mine = 0, cmax = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < kBinsPerLane; j++) {
+                c[j] = bcnt[lane * kBinsPerLane + j];
+                mine += c[j];
+                cmax = c[j] > cmax ? c[j] : cmax;
+            }
+            uint32_t run = wave_incl_scan(mine) - mine;
+#pragma unroll
+            for (uint32_t j = 0; j < kBinsPerLane; j++) { bstart[lane * kBinsPerLane + j] = run; run += c[j]; }
+            for (int sh = 32; sh; sh >>= 1) { const uint32_t o = __shfl_xor(cmax, sh, 64); cmax = o > cmax ? o : cmax; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            uint32_t base[kPer], cnt_b[kPer], rank[kPer];
+#pragma unroll
+            for (uint32_t q = 0; q < kPer; q++) {
+                base[q] = bstart[bin[q]];
+                cnt_b[q] = bcnt[bin[q]];
+                rank[q] = 0;
+                if (lane + q * kLane < n) keys[base[q] + slot[q]] = k[q];       // keys grouped by bin
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (uint32_t j = 0; j < cmax; j++) {
+#pragma unroll
+                for (uint32_t q = 0; q < kPer; q++)
+                    if (j < cnt_b[q] && lane + q * kLane < n) rank[q] += keys[base[q] + j] < k[q] ? 1u : 0u;
+            }
+#pragma unroll
+            for (uint32_t q = 0; q < kPer; q++)
+                if (lane + q * kLane < n) { term_id[d + base[q] + rank[q]] = t[q]; pos[d + base[q] + rank[q]] = p[q]; }
+            __builtin_amdgcn_wave_barrier();
+            continue;
+        }
         for (uint32_t b0 = 0; b0 < n; b0 += kScan2FifoCap) {           // this pass's own items
             uint32_t t[kPer], p[kPer], k[kPer], rank[kPer];
 #pragma unroll

@@ -51,6 +51,14 @@ def test_no_device_fails_loudly():
     assert ei.value.code == _lib.GFT_E_HIP
 
 
+def test_missing_library_fails_loudly(monkeypatch):
+    """... and without libgft.so the package does not fall back to anything either"""
+    monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libgft.so")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.load()
+
+
 # ---- dsl/scanner_test.go ------------------------------------------------------------------------------------
 @pytest.mark.parametrize("case", load_golden("scanner.json")["cases"], ids=lambda c: c["message"])
 def test_scanner(case):

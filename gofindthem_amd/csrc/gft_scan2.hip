@@ -536,6 +536,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
         const uint32_t nvalid = my_lo < un.hi ? my_hi - my_lo : 0;
 
         // ---- phase 1: filter ------------------------------------------------------------------------------
+        if (P.prio == 1) __builtin_amdgcn_s_setprio(2); else if (P.prio >= 2) __builtin_amdgcn_s_setprio(0);
         uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
         if (own) {
             // running window key: x(i) = pair(i-2) * kp^2 + pair(i), pair(i) = class(i-1) * kp + class(i)
@@ -591,6 +592,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
             m3 = nvalid >= 128 ? m3 : (nvalid > 96 ? m3 & ((1u << (nvalid - 96)) - 1) : 0);
         }
 
+        if (P.prio == 1) __builtin_amdgcn_s_setprio(0); else if (P.prio >= 2) __builtin_amdgcn_s_setprio(2);
         if (more_units) abs_n = P.doc_off[un_n.doc];
 
         // ---- phase 2: verify flagged positions, stage matches in LDS ----------------------------------------
@@ -693,6 +695,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     if (P.dbg & 2) { if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(KARG(dbg_counters) + 2), (unsigned long long)ns); }
+                    if (P.prio == 3) __builtin_amdgcn_s_setprio(3);
                     // stage B: the survivors, densely packed over the lanes, go to the L2 bucket table; the room behind
                     // them in the candidate list parks the entries of multi-term buckets
                     Deferred dfr;

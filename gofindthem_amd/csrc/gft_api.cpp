@@ -429,9 +429,9 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         P.want_pos = (need_csr || e->n_inord_groups > 0) ? 1 : 0;
         const char* dbg = getenv("GFT_SCAN_DEBUG");
         P.dbg = dbg ? (uint32_t)atoi(dbg) : 0;
-        // wave priorities: the latency-bound verification stages overtake the filter phase of the other waves (3.6 % on
+        // wave priorities: the latency-bound verification stages overtake the filter phase of the other waves (5 % on
         // the benchmark; GFT_SCAN_PRIO=0 switches it off)
-        { const char* pr = getenv("GFT_SCAN_PRIO"); P.prio = pr ? (uint32_t)atoi(pr) : 3; }
+        { const char* pr = getenv("GFT_SCAN_PRIO"); P.prio = pr ? (atoi(pr) ? 1u : 0u) : 1u; }
         P.dbg_counters = nullptr;
         if (P.dbg & 2) {
             HIP_TRY(e->d_dbg.ensure(32), "debug alloc");

@@ -222,8 +222,8 @@ struct Scan2Params {
     uint32_t slab;               // pool entries a wave reserves per global atomic (<= kScan2Slab)
     uint32_t ordered;            // 1: per-lane staging path for every unit (cross-check); 0: balanced path, staging only on overflow
     uint64_t text_bytes;         // size of the text blob (loads behind a window must not run past it)
-    uint32_t prio;               // wave priority scheme (s_setprio): 0 none, 1 filter phase high, 2 verification high,
-                                 // 3 (default) filter 0 < list + stage A 2 < stage B 3
+    uint32_t prio;               // 1 (default): graded wave priorities (s_setprio) -- filter 0 < list build 1 < stage A 2 <
+                                 // stage B 3; 0: off
     uint32_t want_pos;           // 0: presence only -- no expression has an INORD group, pool_pos is not written
     uint32_t dbg;                // GFT_SCAN_DEBUG bits (timing studies only): 1 = skip verification, 2 = count flags
     uint64_t* dbg_counters;      // [4] when dbg & 2: flagged positions, table probes, entries compared, -

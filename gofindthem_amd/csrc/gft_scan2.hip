@@ -536,7 +536,10 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
         const uint32_t nvalid = my_lo < un.hi ? my_hi - my_lo : 0;
 
         // ---- phase 1: filter ------------------------------------------------------------------------------
-        if (P.prio == 1) __builtin_amdgcn_s_setprio(2); else if (P.prio >= 2) __builtin_amdgcn_s_setprio(0);
+        // wave priorities, graded by how latency-bound a stage is: filter 0 < list build 1 < stage A 2 < stage B and flush 3.
+        // A wave that waits for L2 in the verification stages issues the moment its data arrives; the other waves' filter
+        // loops fill the remaining slots.
+        if (P.prio) __builtin_amdgcn_s_setprio(0);
         uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
         if (own) {
             // running window key: x(i) = pair(i-2) * kp^2 + pair(i), pair(i) = class(i-1) * kp + class(i)
@@ -592,7 +595,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
             m3 = nvalid >= 128 ? m3 : (nvalid > 96 ? m3 & ((1u << (nvalid - 96)) - 1) : 0);
         }
 
-        if (P.prio == 1) __builtin_amdgcn_s_setprio(0); else if (P.prio >= 2) __builtin_amdgcn_s_setprio(2);
+        if (P.prio) __builtin_amdgcn_s_setprio(1);
         if (more_units) abs_n = P.doc_off[un_n.doc];
 
         // ---- phase 2: verify flagged positions, stage matches in LDS ----------------------------------------
@@ -649,6 +652,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
                     // end a term of length >= 4 are compacted in place to the front of the list (write index <= read index)
                     // (kStageAWays candidates per lane and trip: their loads and table lookups are in flight together;
                     // lanes past the end of the list work on a copy of entry 0 and stay silent)
+                    if (P.prio) __builtin_amdgcn_s_setprio(2);
                     uint32_t ns = 0;
                     // (the list entries and text of trip t + 1 are fetched while trip t is worked on)
                     bool n_on[kStageAWays];
@@ -695,7 +699,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     if (P.dbg & 2) { if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(KARG(dbg_counters) + 2), (unsigned long long)ns); }
-                    if (P.prio == 3) __builtin_amdgcn_s_setprio(3);
+                    if (P.prio) __builtin_amdgcn_s_setprio(3);
                     // stage B: the survivors, densely packed over the lanes, go to the L2 bucket table; the room behind
                     // them in the candidate list parks the entries of multi-term buckets
                     Deferred dfr;

@@ -18,6 +18,7 @@
 #include "ac_tables.hpp"
 #include "gft_kernels.hpp"
 #include "scan2_tables.hpp"
+#include "scan3_tables.hpp"
 
 using namespace gft;
 
@@ -66,6 +67,12 @@ struct gft_engine {
     Scan2Tables s2;
     bool use_scan2 = false;
     DevBuf d_s2_filter, d_s2_slots, d_s2_more, d_s2_cls, d_s2_cls_fold, d_s2_term_blob, d_s2_term_off, d_dbg;
+    // stride-2 suffix-window scan (gft_scan3.hip): the default kernel
+    Scan3Tables s3;
+    bool use_scan3 = false;
+    DevBuf d_s3_filter, d_s3_short3, d_s3_srec, d_s3_short3_big, d_s3_srec_big, d_s3_bloom, d_s3_slots, d_s3_more, d_s3_cls,
+        d_s3_cls_fold, d_s3_term_blob, d_s3_term_off;
+    uint32_t scan3_waves = 0, scan3_cand_cap = 0;
     // control block (64 B): [0] u32 bad-offsets flag, [8] u64 pool cursor, [16] u64 exact match count, [32] u64 n_units,
     // [40] u64 first text offset, [48] u64 last text offset -- one memset per batch, one read-back per synchronisation
     DevBuf d_ctl;
@@ -75,6 +82,8 @@ struct gft_engine {
     uint64_t scan_valid_docs = ~0ull;                   // documents of the last gft_process scan still in the pool (~0: none)
     bool csr_sorted_in_gather = false;                  // this call: balanced scan + sort in the gather
     uint32_t scan2_unit_max = kScan2UnitMax;            // bytes per work unit (adapts to the match density)
+    uint32_t opt_scan_dbg = 0;                          // GFT_SCAN_DEBUG, read once at gft_engine_create (timing studies)
+    uint32_t opt_scan_prio = 1;                         // graded wave priorities in the scan kernels (GFT_SCAN_PRIO=0: off)
 
     // programs
     bool have_programs = false;
@@ -327,7 +336,7 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
     const uint32_t warm = e->tab.max_term_len ? e->tab.max_term_len - 1 : 0;
     // gft_scan2: a unit's matches should fit the wave's LDS fifo (kScan2FifoCap), so the unit size follows the match
     // density the previous call saw (dense dictionaries -> smaller units); results do not depend on it
-    const uint32_t unit_max = e->use_scan2 ? e->scan2_unit_max : kTextBuf - warm;
+    const uint32_t unit_max = e->use_scan3 ? kScan3UnitMax : e->use_scan2 ? e->scan2_unit_max : kTextBuf - warm;
 
     // 1. work units
     HIP_TRY(e->d_ctl.ensure(64), "control alloc");
@@ -393,7 +402,51 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
     int rc = ensure_pool(e, std::max<uint64_t>(1u << 20, (text_hi - text_lo) / 16));
     if (rc) return rc;
     uint64_t total = 0;
-    for (int attempt = 0; attempt < 3 && e->use_scan2; attempt++) {
+    for (int attempt = 0; attempt < 3 && e->use_scan3; attempt++) {
+        if (attempt) HIP_TRY(hipMemsetAsync(e->d_ctl.as<uint8_t>() + 8, 0, 16, st), "memset");
+        Scan3Params P;
+        P.text = d_text; P.doc_off = d_doc_off; P.units = e->d_units.as<Unit>(); P.n_units = n_units; P.text_bytes = text_hi;
+        P.fold = (flags & GFT_FOLD_ASCII) ? 1 : 0;
+        P.cls = P.fold ? e->d_s3_cls_fold.as<uint8_t>() : e->d_s3_cls.as<uint8_t>();
+        P.filter = e->d_s3_filter.as<uint32_t>(); P.filter_words = (uint32_t)e->s3.filter.size();
+        P.short3 = e->d_s3_short3.as<uint8_t>(); P.short3_bytes = (uint32_t)e->s3.short3.size();
+        P.srec = e->d_s3_srec.as<uint32_t>(); P.srec_words = (uint32_t)e->s3.srec.size();
+        P.short3_big = e->s3.short3_big.empty() ? nullptr : e->d_s3_short3_big.as<uint32_t>();
+        P.srec_big = e->d_s3_srec_big.as<uint32_t>();
+        P.bloom = e->d_s3_bloom.as<uint32_t>(); P.bloom_lg = e->s3.bloom_lg; P.bloom_lds = e->s3.bloom_lg <= kScan3BloomLdsLg ? 1 : 0;
+        P.slots = e->d_s3_slots.as<Scan2Slot>(); P.slot_shift = e->s3.slot_shift; P.slot_seed = e->s3.slot_seed;
+        P.more = e->d_s3_more.as<Scan2Slot>();
+        P.term_blob = e->d_s3_term_blob.as<uint8_t>(); P.term_off = e->d_s3_term_off.as<uint32_t>();
+        P.G = e->s3.G; P.grouped = e->s3.grouped ? 1 : 0;
+        P.pos_end = (e->build_flags & GFT_POS_END) ? 1 : 0;
+        // presence-only mode: positions are only read by INORD groups (and by CSR callers)
+        P.want_pos = (need_csr || e->n_inord_groups > 0) ? 1 : 0;
+        P.prio = e->opt_scan_prio;
+        P.dbg = e->opt_scan_dbg;
+        P.cand_cap = e->scan3_cand_cap;
+        P.cursor = e->d_ctl.as<uint64_t>() + 1; P.pool_cap = e->pool_cap;
+        P.pool_term = e->d_pool_term.as<uint32_t>(); P.pool_pos = e->d_pool_pos.as<uint32_t>();
+        P.unit_start = e->d_unit_start.as<uint64_t>(); P.unit_count = e->d_unit_count.as<uint32_t>();
+        P.n_matches = e->d_ctl.as<uint64_t>() + 2;
+        // slab slack is at most one slab per resident wave: keep it below half the pool
+        const uint64_t n_waves = (uint64_t)e->n_cus * e->scan3_waves;
+        P.slab = (uint32_t)std::min<uint64_t>(kScan2Slab, std::max<uint64_t>(2 * kScan3MinRoom, e->pool_cap / (2 * n_waves)));
+        e->csr_sorted_in_gather = need_csr;
+        {
+            ProfScope ps(e, "scan");
+            HIP_TRY(launch_scan3(P, e->scan3_waves, e->n_cus, st), "scan kernel launch");
+        }
+        uint64_t ct[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(ct, e->d_ctl.as<uint8_t>() + 8, 16, hipMemcpyDeviceToHost, st), "readback");
+        HIP_TRY(hipStreamSynchronize(st), "scan kernel");
+        const uint64_t cursor = ct[0];
+        total = ct[1];
+        if (cursor <= e->pool_cap) break;
+        if (attempt == 2) return fail(e, GFT_E_HIP, "match pool overflow persisted");
+        rc = ensure_pool(e, cursor + cursor / 16);
+        if (rc) return rc;
+    }
+    for (int attempt = 0; attempt < 3 && e->use_scan2 && !e->use_scan3; attempt++) {
         if (attempt) HIP_TRY(hipMemsetAsync(e->d_ctl.as<uint8_t>() + 8, 0, 16, st), "memset");
         Scan2Params P;
         P.text = d_text; P.doc_off = d_doc_off; P.units = e->d_units.as<Unit>(); P.n_units = n_units;
@@ -469,7 +522,7 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         rc = ensure_pool(e, cursor + cursor / 16);
         if (rc) return rc;
     }
-    for (int attempt = 0; attempt < 3 && !e->use_scan2; attempt++) {
+    for (int attempt = 0; attempt < 3 && !e->use_scan2 && !e->use_scan3; attempt++) {
         if (attempt) HIP_TRY(hipMemsetAsync(e->d_ctl.as<uint8_t>() + 8, 0, 16, st), "memset");
         ScanParams P;
         P.text = d_text; P.doc_off = d_doc_off; P.units = e->d_units.as<Unit>(); P.n_units = n_units;
@@ -509,7 +562,7 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
                               e->d_unit_out.as<uint64_t>(), n_units, e->d_pool_term.as<uint32_t>(),
                               e->d_pool_pos.as<uint32_t>(), e->d_term.as<uint32_t>(), e->d_pos.as<uint32_t>(),
                               e->d_unit_base.as<uint64_t>(), n_docs, e->d_match_off.as<uint64_t>(), e->n_cus, st,
-                              (e->use_scan2 && e->csr_sorted_in_gather) ? e->d_units.as<Unit>() : nullptr,
+                              ((e->use_scan2 || e->use_scan3) && e->csr_sorted_in_gather) ? e->d_units.as<Unit>() : nullptr,
                               e->d_term_len.as<uint32_t>(), (e->build_flags & GFT_POS_END) ? 1u : 0u),
                 "gather");
     }
@@ -624,6 +677,8 @@ int gft_engine_create(gft_engine** out, int device) {
     // (torch's default stream, plain hipMemcpy) produces the device buffers it hands to *_device entry points
     if (hipStreamCreateWithFlags(&e->stream, hipStreamDefault) == hipSuccess) e->own_stream = true;
     else e->stream = nullptr;
+    { const char* pr = getenv("GFT_SCAN_PRIO"); if (pr) e->opt_scan_prio = atoi(pr) ? 1u : 0u; }
+    { const char* dbg = getenv("GFT_SCAN_DEBUG"); if (dbg) e->opt_scan_dbg = (uint32_t)atoi(dbg); }
     *out = e;
     return GFT_OK;
 }
@@ -639,6 +694,8 @@ void gft_engine_destroy(gft_engine* e) {
                          &e->d_prog_off, &e->d_fprog, &e->d_fprog_off, &e->d_groups, &e->d_order, &e->d_blk_deep, &e->d_fprog_t, &e->d_fblk_off, &e->d_pscratch, &e->d_s2_filter,
                          &e->d_s2_slots, &e->d_s2_more, &e->d_s2_cls, &e->d_s2_cls_fold, &e->d_s2_term_blob,
                          &e->d_s2_term_off, &e->d_ctl, &e->d_dbg, &e->d_s2_short3, &e->d_s2_shorts_packed, &e->d_s2_short3_big, &e->d_s2_fpt,
+                         &e->d_s3_filter, &e->d_s3_short3, &e->d_s3_srec, &e->d_s3_short3_big, &e->d_s3_srec_big, &e->d_s3_bloom, &e->d_s3_slots,
+                         &e->d_s3_more, &e->d_s3_cls, &e->d_s3_cls_fold, &e->d_s3_term_blob, &e->d_s3_term_off,
 &e->d_unit_cnt, &e->d_unit_base, &e->d_units, &e->d_partial,
                          &e->d_pool_term, &e->d_pool_pos, &e->d_unit_start, &e->d_unit_count, &e->d_unit_out,
                          &e->d_term, &e->d_pos, &e->d_match_off, &e->d_text, &e->d_doc_off, &e->d_bitmap, &e->d_xoff,
@@ -697,6 +754,37 @@ static int install_tables(gft_engine* e, uint32_t flags) {
                                                         e->s2.fpt_lg ? 0u : kScan2FptSize, e->lds_max - 512,
                                                         &e->scan2_k2_waves, &e->scan2_cand_cap);
     e->use_scan2 = k2_fits && !(force && std::string(force) == "dfa");
+    // Kernel choice: the suffix-window kernel (scan2) where its direct tables apply -- small alphabets, the benchmark's
+    // shape --, the stride-2 kernel (scan3: any alphabet, merged filter groups) everywhere else; the DFA kernel only as
+    // a cross-check.  GFT_SCAN_KERNEL=scan2 / scan3 / dfa forces one (read here, i.e. by gft_build / gft_import_tables)
+    const uint32_t bloom_lds_bytes = e->s3.supported && e->s3.bloom_lg <= kScan3BloomLdsLg ? 4u << e->s3.bloom_lg : 0u;
+    const bool k3_fits = e->s3.supported && scan3_plan((uint32_t)e->s3.filter.size(), (uint32_t)e->s3.short3.size(), (uint32_t)e->s3.srec.size(),
+                                                        bloom_lds_bytes, e->lds_max - 512, &e->scan3_waves, &e->scan3_cand_cap);
+    const std::string forced = force ? force : "";
+    e->use_scan3 = k3_fits && forced != "dfa" && forced != "scan2" && (forced == "scan3" || !e->use_scan2);
+    if (e->use_scan3) {
+        if ((rc = upload(e, e->d_s3_filter, e->s3.filter, "table upload"))) return rc;
+        std::vector<uint8_t> s3v = e->s3.short3;
+        if (s3v.empty()) s3v.assign(16, 0);
+        if ((rc = upload(e, e->d_s3_short3, s3v, "table upload"))) return rc;
+        if ((rc = upload(e, e->d_s3_srec, e->s3.srec, "table upload"))) return rc;
+        if (!e->s3.short3_big.empty() && (rc = upload(e, e->d_s3_short3_big, e->s3.short3_big, "table upload"))) return rc;
+        if ((rc = upload(e, e->d_s3_srec_big, e->s3.srec_big, "table upload"))) return rc;
+        if ((rc = upload(e, e->d_s3_bloom, e->s3.bloom, "table upload"))) return rc;
+        if ((rc = upload(e, e->d_s3_slots, e->s3.slots, "table upload"))) return rc;
+        if ((rc = upload(e, e->d_s3_more, e->s3.more, "table upload"))) return rc;
+        if ((rc = upload(e, e->d_s3_term_blob, e->s3.term_blob, "table upload"))) return rc;
+        if ((rc = upload(e, e->d_s3_term_off, e->s3.term_off, "table upload"))) return rc;
+        std::vector<uint8_t> g1(e->s3.cls, e->s3.cls + 256), g2(e->s3.cls_fold, e->s3.cls_fold + 256);
+        if ((rc = upload(e, e->d_s3_cls, g1, "table upload"))) return rc;
+        if ((rc = upload(e, e->d_s3_cls_fold, g2, "table upload"))) return rc;
+        HIP_TRY(hipStreamSynchronize(e->stream), "table upload");      // g1 / g2 / s3v are locals
+        if (getenv("GFT_SCAN_DEBUG"))
+            fprintf(stderr, "[gft build debug] scan3: G=%u%s keys=%llu anchors=%llu slots=%zu more=%zu bloom 2^%u (%s) short cells: lds records %zu, big words %zu; waves=%u cand_cap=%u\n",
+                    e->s3.G, e->s3.grouped ? " (merged classes)" : "", (unsigned long long)e->s3.n_keys, (unsigned long long)e->s3.n_anchors,
+                    e->s3.slots.size(), e->s3.more.size(), e->s3.bloom_lg, bloom_lds_bytes ? "LDS" : "global", e->s3.srec.size() / kScan3RecWords - 1,
+                    e->s3.srec_big.size(), e->scan3_waves, e->scan3_cand_cap);
+    }
     if (e->use_scan2 && getenv("GFT_SCAN_DEBUG")) {
         size_t n_ff = 0, n_used = 0, n_simple = 0, n_slots = 0;
         for (uint8_t b : e->s2.fpt) { n_ff += b == 0xFF; n_used += b != 0; }
@@ -743,7 +831,8 @@ int gft_build(gft_engine* e, const uint8_t* terms_blob, const uint64_t* term_off
     }
     e->built = false;
     build_ac_tables(std::move(terms), e->tab);
-    build_scan2_tables(e->tab, e->s2);     // suffix-window tables (the fast path)
+    build_scan2_tables(e->tab, e->s2);     // suffix-window tables (scan2, kept as a cross-check)
+    build_scan3_tables(e->tab, e->s3);     // stride-2 suffix-window tables (the fast path)
     return install_tables(e, flags);
 }
 
@@ -1101,6 +1190,25 @@ int gft_process(gft_engine* e, const uint8_t* text_blob, const uint64_t* doc_off
         HIP_TRY(hipMemcpyAsync(hit_bitmap, e->d_bitmap.p, n_docs * words * 4, hipMemcpyDeviceToHost, e->stream), "download");
     }
     HIP_TRY(hipStreamSynchronize(e->stream), "process pipeline");
+    return GFT_OK;
+}
+
+int gft_debug_emulate_scan(const uint8_t* terms_blob, const uint64_t* term_off, uint32_t n_terms, const uint8_t* text,
+                           uint32_t len, uint32_t lo, uint32_t flags, uint32_t scan_flags, uint32_t* out_term,
+                           uint32_t* out_pos, uint64_t cap, uint64_t* needed) {
+    if ((n_terms && (!terms_blob || !term_off)) || (len && !text) || lo > len || !needed) return GFT_E_INVALID;
+    std::vector<std::string> terms;
+    for (uint32_t i = 0; i < n_terms; i++) terms.emplace_back((const char*)terms_blob + term_off[i], (size_t)(term_off[i + 1] - term_off[i]));
+    AcTables tab;
+    build_ac_tables(std::move(terms), tab);
+    Scan3Tables t;
+    build_scan3_tables(tab, t);
+    if (!t.supported) return GFT_E_UNSUPPORTED;
+    std::vector<Scan3Hit> hits;
+    scan3_emulate(t, text, len, lo, (scan_flags & GFT_FOLD_ASCII) != 0, (flags & GFT_POS_END) != 0, hits);
+    *needed = hits.size();
+    if (hits.size() > cap || (hits.size() && (!out_term || !out_pos))) return GFT_E_INVALID;
+    for (size_t i = 0; i < hits.size(); i++) { out_term[i] = hits[i].term; out_pos[i] = hits[i].pos; }
     return GFT_OK;
 }
 

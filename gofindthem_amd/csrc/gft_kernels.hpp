@@ -233,6 +233,70 @@ bool scan2_plan(uint32_t filter_words, uint32_t short3_bytes, uint32_t shorts_wo
                 uint32_t* waves, uint32_t* cand_cap);
 hipError_t launch_scan2(const Scan2Params& P, uint32_t waves, unsigned n_cus, hipStream_t st);
 
+
+// ---- stride-2 suffix-window scan (gft_scan3.hip; tables built by scan3_tables.cpp) ---------------------------------
+// The text is probed at every OTHER position: a probe at p looks at the window text[p-3 .. p] and finds every term that
+// ends at p or at p-1 (terms of length <= 3, from the short3 records) and every term of length >= 4 that has one of its
+// two anchor windows end at p.  Each such term has two anchors whose distances to the term's end differ in parity, so
+// whatever the parity of an occurrence, exactly one of its anchors falls on a probe.  Byte classes are merged down to
+// at most kScan3Groups filter groups, so the LDS tables are direct-indexed for every alphabet; exactness comes from the
+// byte compares of the bucket table (and of the short records), never from a hash.
+constexpr uint32_t kScan3Groups = 27;            // filter groups: G^4 bits = 66 KB, G^3 bytes = 20 KB of LDS at 27
+constexpr uint32_t kScan3Threads = 1024;         // 16 waves per workgroup share one LDS copy of the tables
+constexpr uint32_t kScan3UnitMax = 8192;         // bytes per work unit: up to 8 coalesced rounds of 1 KiB (16 B per lane)
+constexpr uint32_t kScan3RecWords = 6;           // short record: 3 entries x {term_id | len << 28, bytes}
+constexpr uint32_t kScan3RecLds = 254;           // record ids 1..254 live in LDS; cell 255 = look the cell up in short3_big
+constexpr uint32_t kScan3BloomLdsLg = 13;        // Bloom table in LDS: 2^13 cells x 4 B = 32 KB; larger dictionaries: global
+constexpr uint32_t kScan3SurvCap = 128;          // stage-B candidates parked per wave ({entry, window key}, 8 B each)
+constexpr uint32_t kScan3MinRoom = 512;          // a unit starts with at least this much room in the wave's slab
+constexpr uint32_t kScan3CandCapMin = 256;       // per-wave candidate list (u16 probe indices); the rest of LDS goes here
+constexpr uint32_t kScan3BloomMul1 = 0x9E3779B1u, kScan3BloomMul2 = 0x85EBCA6Bu;
+// Bloom cell and the two bits of a 5-group key (window key * G + group of the byte in front of the window)
+GFT_HD inline uint32_t scan3_bloom_cell(uint32_t key5, uint32_t lg) { return (key5 * kScan3BloomMul1) >> (32 - lg); }
+GFT_HD inline uint32_t scan3_bloom_bits(uint32_t key5) {
+    const uint32_t h = key5 * kScan3BloomMul2;
+    return 1u << (h >> 27) | 1u << ((h >> 22) & 31);
+}
+
+struct Scan3Params {
+    const uint8_t* text;
+    const uint64_t* doc_off;
+    const Unit* units;
+    uint64_t n_units;
+    uint64_t text_bytes;
+    const uint8_t* cls;          // [256] byte -> filter group (the folded table when GFT_FOLD_ASCII), copied to LDS
+    const uint32_t* filter;      // G^4 bits, copied to LDS
+    uint32_t filter_words;
+    const uint8_t* short3;       // [short3_bytes] record id per 3-group END window (0 none, 255 -> short3_big), copied to LDS
+    uint32_t short3_bytes;       // 0: no term shorter than 4 bytes
+    const uint32_t* srec;        // LDS records, kScan3RecWords words each (record 0 = empty)
+    uint32_t srec_words;
+    const uint32_t* short3_big;  // [G^3] offset into srec_big for cells whose record is not in LDS (nullptr: none)
+    const uint32_t* srec_big;    // {n, n x {term_id | len << 28, bytes}} records in global memory
+    const uint32_t* bloom;       // 2^bloom_lg cells
+    uint32_t bloom_lg, bloom_lds;
+    const Scan2Slot* slots;
+    uint32_t slot_shift, slot_seed;
+    const Scan2Slot* more;
+    const uint8_t* term_blob;
+    const uint32_t* term_off;
+    uint32_t G, fold, pos_end, want_pos, grouped, prio;
+    uint32_t cand_cap;           // entries of a wave's LDS candidate list (scan3_plan)
+    uint32_t dbg;                // GFT_SCAN_DEBUG (timing studies; selects the kernel instantiation that has the knock-outs)
+    uint64_t* cursor;
+    uint64_t pool_cap;
+    uint32_t* pool_term;
+    uint32_t* pool_pos;
+    uint64_t* unit_start;
+    uint32_t* unit_count;
+    uint64_t* n_matches;
+    uint32_t slab;
+};
+// waves per workgroup and candidate-list capacity that fit lds_max; false if nothing fits
+bool scan3_plan(uint32_t filter_words, uint32_t short3_bytes, uint32_t srec_words, uint32_t bloom_lds_bytes, size_t lds_max,
+                uint32_t* waves, uint32_t* cand_cap);
+hipError_t launch_scan3(const Scan3Params& P, uint32_t waves, unsigned n_cus, hipStream_t st);
+
 // *d_bad |= 1 when a document is longer than 2^32 - 1 bytes (or its offsets descend); such documents get zero units
 hipError_t launch_unit_count(const uint64_t* d_doc_off, uint64_t n_docs, uint32_t unit_max, uint32_t* d_cnt,
                              uint32_t* d_bad, hipStream_t st);

@@ -241,6 +241,15 @@ int gft_profile_enable(gft_engine* e, int on);
 int gft_profile_read(gft_engine* e, const char* name, double* total_ms, uint64_t* launches);
 int gft_profile_reset(gft_engine* e);
 
+/* ---- test hook: the table compiler without a device ------------------------------------------------------- */
+/* Compiles `terms` into the scan kernel's tables on the host and walks them over ONE document the way the kernel does
+ * (host emulation of the per-probe logic, csrc/scan3_tables.cpp): the matches of the unit [lo, len) of the document, in no
+ * particular order, as (term id in sorted-unique order, position) pairs.  No HIP device is needed; tests use it to check
+ * the table compiler against the oracle.  *needed = number of matches (GFT_E_INVALID when cap is too small). */
+int gft_debug_emulate_scan(const uint8_t* terms_blob, const uint64_t* term_off, uint32_t n_terms, const uint8_t* text,
+                           uint32_t len, uint32_t lo, uint32_t flags, uint32_t scan_flags, uint32_t* out_term,
+                           uint32_t* out_pos, uint64_t cap, uint64_t* needed);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,11 +9,11 @@ from oracle.pyoracle import Oracle, POS_END, POS_START
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["window", "window-ordered", "dfa"], autouse=True)
+@pytest.fixture(params=["scan3", "scan2", "scan2-ordered", "dfa"], autouse=True)
 def scan_kernel(request, monkeypatch):
-    """every test runs against the suffix-window kernel (default: balanced path, CSR results sorted by the gather),
-    the same kernel's in-kernel ordered path (GFT_SCAN_ORDERED=1) and the general two-tier DFA kernel
-    (GFT_SCAN_KERNEL=dfa, read by gft_build)"""
+    """every test runs against the stride-2 suffix-window kernel (the default), the round-1 suffix-window kernel
+    (GFT_SCAN_KERNEL=scan2: balanced path, and its in-kernel ordered path with GFT_SCAN_ORDERED=1) and the general
+    two-tier DFA kernel (GFT_SCAN_KERNEL=dfa); the variable is read by gft_build"""
     monkeypatch.setenv("GFT_SCAN_KERNEL", request.param.split("-")[0])
     if request.param.endswith("-ordered"):
         monkeypatch.setenv("GFT_SCAN_ORDERED", "1")

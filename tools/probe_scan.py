@@ -21,13 +21,21 @@ ap.add_argument("--unordered", action="store_true", help="time the scan as the p
 args = ap.parse_args()
 
 wl = Workload(args.terms)
-eng = Engine(0)
-eng.build(wl.terms())
-eng.set_stream(torch.cuda.current_stream().cuda_stream)
 text, off = wl.docs_device(0, args.docs)
 nbytes = text.numel()
-eng.set_programs([[1 << 28]])
 bm = torch.zeros((args.docs, 1), dtype=torch.int32, device="cuda")
+eng = None
+
+
+def make_engine():
+    """GFT_SCAN_DEBUG is read when the engine is created"""
+    global eng
+    if eng is not None:
+        eng.close()
+    eng = Engine(0)
+    eng.build(wl.terms())
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng.set_programs([[1 << 28]])
 
 
 class _M:
@@ -43,6 +51,7 @@ def run():
 
 for mode in args.modes.split(","):
     os.environ["GFT_SCAN_DEBUG"] = mode
+    make_engine()
     run()    # warm-up
     eng.profile(True)
     eng.profile_reset()

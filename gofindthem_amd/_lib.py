@@ -34,6 +34,7 @@ SYMBOLS = {
     "gft_import_tables": (_i, [_vp, C.c_char_p, _u64]),
     "gft_n_terms": (_u32, [_vp]),
     "gft_n_states": (_u32, [_vp]),
+    "gft_last_nonascii": (_i, [_vp]),
     "gft_term": (_i, [_vp, _u32, C.POINTER(_vp), C.POINTER(_u32)]),
     "gft_term_id": (C.c_int64, [_vp, _vp, _u32]),
     "gft_scan": (_i, [_vp, _vp, _vp, _u64, _u32, C.POINTER(GftMatches)]),

@@ -1,5 +1,8 @@
 #include "finder_host.hpp"
 
+#include <hip/hip_runtime.h>
+
+#include <mutex>
 #include <algorithm>
 #include <cstring>
 #include <thread>
@@ -417,6 +420,23 @@ Error Finder::ProcessDevice(const uint8_t* d_blob, const uint64_t* d_doc_off, ui
     int rc = gft_process_device(gpu_->handle(), d_blob, d_doc_off, n_docs, caseSensitive_ ? 0 : GFT_FOLD_ASCII, nullptr,
                                 d_bitmap);
     if (rc) return fail_gft(rc);
+    if (!caseSensitive_ && n_docs && gft_last_nonascii(gpu_->handle())) {
+        // The kernels lower-case A-Z only; the reference runs strings.ToLower (finder.go:140-142), which also maps
+        // non-ASCII upper-case letters, rewrites invalid UTF-8 and may change byte lengths.  A batch that holds bytes
+        // >= 0x80 is therefore repeated through the host path: text back to the host, ToLower per document, bitmap up.
+        std::vector<uint64_t> off(n_docs + 1);
+        if (hipMemcpy(off.data(), d_doc_off, (n_docs + 1) * 8, hipMemcpyDeviceToHost) != hipSuccess) { last_code_ = GFT_E_HIP; return "device-to-host copy failed"; }
+        std::vector<uint8_t> text((size_t)(off[n_docs] - off[0]) + 1);
+        if (off[n_docs] > off[0] &&
+            hipMemcpy(text.data(), d_blob + off[0], (size_t)(off[n_docs] - off[0]), hipMemcpyDeviceToHost) != hipSuccess) { last_code_ = GFT_E_HIP; return "device-to-host copy failed"; }
+        const uint64_t base = off[0];
+        for (auto& o : off) o -= base;
+        const size_t words = (expressions_.size() + 31) / 32;
+        std::vector<uint32_t> bm((size_t)n_docs * words + 1);
+        Error err = ProcessTexts(text.data(), off.data(), n_docs, bm.data());
+        if (!err.empty()) return err;
+        if (words && hipMemcpy(d_bitmap, bm.data(), (size_t)n_docs * words * 4, hipMemcpyHostToDevice) != hipSuccess) { last_code_ = GFT_E_HIP; return "host-to-device copy failed"; }
+    }
     return "";
 }
 
@@ -448,7 +468,11 @@ struct gft_finder {
     std::unique_ptr<Finder> finder;
     bool case_sensitive = true;
     std::string err, json;
+    // one caller at a time per finder (ProcessText mutates the lazy-build flags, finder.go:152,168): Go callers share a
+    // built Finder between goroutines, so every entry point takes this
+    mutable std::recursive_mutex mu;
 };
+#define GFT_FLOCK(f) std::lock_guard<std::recursive_mutex> _gft_flock((f)->mu)
 
 // for group_host.cpp: the C++ object behind the handle
 gft::Finder* gft_finder_impl(gft_finder* f) { return f ? f->finder.get() : nullptr; }
@@ -481,6 +505,7 @@ static int finder_ret(gft_finder* f, const Error& e, int dflt) {
 // engines can only be swapped before the first expression is added (like passing them to NewFinder)
 int gft_finder_set_substring_engine(gft_finder* f, gft_engine_build_fn build, gft_engine_find_fn find, void* user) {
     if (!f) return GFT_E_INVALID;
+    GFT_FLOCK(f);
     if (f->finder->expressions().size() || f->finder->GetKeywords().size()) { f->err = "engines must be set before expressions are added"; return GFT_E_INVALID; }
     f->sub_cb.reset(new CallbackSubEngine(build, find, user));
     f->finder.reset(new Finder(f->sub_cb.get(), f->rgx.get(), f->case_sensitive, f->gpu.get()));
@@ -489,6 +514,7 @@ int gft_finder_set_substring_engine(gft_finder* f, gft_engine_build_fn build, gf
 
 int gft_finder_set_regex_engine(gft_finder* f, gft_engine_build_fn build, gft_engine_find_fn find, void* user) {
     if (!f) return GFT_E_INVALID;
+    GFT_FLOCK(f);
     if (f->finder->expressions().size() || f->finder->GetRegexes().size()) { f->err = "engines must be set before expressions are added"; return GFT_E_INVALID; }
     f->rgx.reset(new CallbackRgxEngine(build, find, user));
     SubstringEngine* sub = f->sub_cb ? f->sub_cb.get() : static_cast<SubstringEngine*>(f->gpu.get());
@@ -499,6 +525,7 @@ int gft_finder_set_regex_engine(gft_finder* f, gft_engine_build_fn build, gft_en
 int gft_finder_add_expression(gft_finder* f, const uint8_t* expr, uint64_t expr_len, const uint8_t* tag,
                               uint64_t tag_len) {
     if (!f || (!expr && expr_len)) return GFT_E_INVALID;
+    GFT_FLOCK(f);
     Error e = f->finder->AddExpressionWithTag(std::string((const char*)expr, (size_t)expr_len),
                                               std::string(tag ? (const char*)tag : "", (size_t)(tag ? tag_len : 0)));
     return finder_ret(f, e, GFT_E_PARSE);
@@ -513,6 +540,7 @@ uint32_t gft_finder_n_literals(const gft_finder* f, int which) {
 
 int gft_finder_literal(const gft_finder* f, int which, uint32_t i, const uint8_t** ptr, uint32_t* len) {
     if (!f || !ptr || !len) return GFT_E_INVALID;
+    GFT_FLOCK(f);
     const auto& v = which ? f->finder->GetRegexes() : f->finder->GetKeywords();
     if (i >= v.size()) return GFT_E_INVALID;
     *ptr = (const uint8_t*)v[i].data(); *len = (uint32_t)v[i].size();
@@ -522,6 +550,7 @@ int gft_finder_literal(const gft_finder* f, int which, uint32_t i, const uint8_t
 int gft_finder_expression(const gft_finder* f, uint32_t i, const uint8_t** str, uint32_t* str_len,
                           const uint8_t** tag, uint32_t* tag_len, const uint8_t** tree_json, uint32_t* json_len) {
     if (!f || i >= f->finder->expressions().size()) return GFT_E_INVALID;
+    GFT_FLOCK(f);
     const auto& w = f->finder->expressions()[i];
     if (str) { *str = (const uint8_t*)w.exprString.data(); *str_len = (uint32_t)w.exprString.size(); }
     if (tag) { *tag = (const uint8_t*)w.tag.data(); *tag_len = (uint32_t)w.tag.size(); }
@@ -536,12 +565,14 @@ uint64_t gft_finder_last_regex_docs(const gft_finder* f) { return f && f->finder
 
 int gft_finder_force_build(gft_finder* f) {
     if (!f) return GFT_E_INVALID;
+    GFT_FLOCK(f);
     return finder_ret(f, f->finder->ForceBuild(), GFT_E_ENGINE);
 }
 
 int gft_finder_process_text(gft_finder* f, const uint8_t* text, uint64_t text_len, uint32_t* out_idx, uint32_t cap,
                             uint32_t* n_true) {
     if (!f || !n_true || (!text && text_len)) return GFT_E_INVALID;
+    GFT_FLOCK(f);
     std::vector<ExpressionResult> res;
     Error e = f->finder->ProcessText(std::string((const char*)text, (size_t)text_len), res);
     if (!e.empty()) return finder_ret(f, e, GFT_E_ENGINE);
@@ -553,23 +584,27 @@ int gft_finder_process_text(gft_finder* f, const uint8_t* text, uint64_t text_le
 int gft_finder_process_texts(gft_finder* f, const uint8_t* text_blob, const uint64_t* doc_off, uint64_t n_docs,
                              uint32_t* hit_bitmap) {
     if (!f || (n_docs && !doc_off)) return GFT_E_INVALID;
+    GFT_FLOCK(f);
     return finder_ret(f, f->finder->ProcessTexts(text_blob, doc_off, n_docs, hit_bitmap), GFT_E_ENGINE);
 }
 
 int gft_finder_process_device(gft_finder* f, const uint8_t* d_text_blob, const uint64_t* d_doc_off, uint64_t n_docs,
                               uint32_t* d_hit_bitmap) {
     if (!f) return GFT_E_INVALID;
+    GFT_FLOCK(f);
     return finder_ret(f, f->finder->ProcessDevice(d_text_blob, d_doc_off, n_docs, d_hit_bitmap), GFT_E_ENGINE);
 }
 
 int gft_finder_debug_add_literal(gft_finder* f, int which, const uint8_t* lit, uint32_t len) {
     if (!f) return GFT_E_INVALID;
+    GFT_FLOCK(f);
     f->finder->debug_add_literal(which, std::string((const char*)lit, len));
     return GFT_OK;
 }
 
 int gft_finder_debug_set_updated(gft_finder* f, int updated_sub, int updated_rgx) {
     if (!f) return GFT_E_INVALID;
+    GFT_FLOCK(f);
     f->finder->updatedSubMachine = updated_sub != 0;
     f->finder->updatedRgxMachine = updated_rgx != 0;
     return GFT_OK;
@@ -577,6 +612,7 @@ int gft_finder_debug_set_updated(gft_finder* f, int updated_sub, int updated_rgx
 
 int gft_finder_debug_get_updated(const gft_finder* f, int* updated_sub, int* updated_rgx) {
     if (!f || !updated_sub || !updated_rgx) return GFT_E_INVALID;
+    GFT_FLOCK(f);
     *updated_sub = f->finder->updatedSubMachine; *updated_rgx = f->finder->updatedRgxMachine;
     return GFT_OK;
 }

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -73,7 +74,8 @@ struct gft_engine {
     DevBuf d_s3_filter, d_s3_short3, d_s3_srec, d_s3_short3_big, d_s3_srec_big, d_s3_bloom, d_s3_slots, d_s3_more, d_s3_cls,
         d_s3_cls_fold, d_s3_term_blob, d_s3_term_off;
     uint32_t scan3_waves = 0, scan3_cand_cap = 0;
-    // control block (64 B): [0] u32 bad-offsets flag, [8] u64 pool cursor, [16] u64 exact match count, [32] u64 n_units,
+    // control block (64 B): [0] u32 bad-offsets flag, [8] u64 pool cursor, [16] u64 exact match count, [24] u32 a folded scan
+    // saw a byte >= 0x80, [32] u64 n_units,
     // [40] u64 first text offset, [48] u64 last text offset -- one memset per batch, one read-back per synchronisation
     DevBuf d_ctl;
     DevBuf d_s2_short3, d_s2_shorts_packed, d_s2_short3_big, d_s2_fpt;
@@ -82,8 +84,19 @@ struct gft_engine {
     uint64_t scan_valid_docs = ~0ull;                   // documents of the last gft_process scan still in the pool (~0: none)
     bool csr_sorted_in_gather = false;                  // this call: balanced scan + sort in the gather
     uint32_t scan2_unit_max = kScan2UnitMax;            // bytes per work unit (adapts to the match density)
-    uint32_t opt_scan_dbg = 0;                          // GFT_SCAN_DEBUG, read once at gft_engine_create (timing studies)
+    // a scan launched without knowing the unit count / pool need (gft_process*: one read-back per batch, after the solver)
+    bool deferred = false;
+    uint64_t deferred_unit_cap = 0;
+    bool last_nonascii = false;                         // the last GFT_FOLD_ASCII scan saw a byte >= 0x80 (gft_last_nonascii)
+    // Environment switches (cross-checks and timing studies) are read when the handle is created and again
+    // by gft_build / gft_import_tables / gft_set_programs -- never on the per-batch path
+    uint32_t opt_scan_dbg = 0;                          // GFT_SCAN_DEBUG (timing studies)
     uint32_t opt_scan_prio = 1;                         // graded wave priorities in the scan kernels (GFT_SCAN_PRIO=0: off)
+    uint32_t opt_scan_ordered = 0;                      // GFT_SCAN_ORDERED=1: scan2's per-lane staging path for every unit
+    uint32_t opt_solve_dbg = 0;                         // GFT_SOLVE_DEBUG (timing studies)
+    int opt_solve_group = -1;                           // GFT_SOLVE_GROUP_DOCS: forced group width (-1: the widest that fits)
+    // one caller at a time per handle: every entry point that touches the device state takes this
+    mutable std::recursive_mutex mu;
 
     // programs
     bool have_programs = false;
@@ -112,6 +125,16 @@ struct gft_engine {
 };
 
 namespace {
+
+void refresh_options(gft_engine* e) {
+    auto num = [](const char* name, long dflt) { const char* v = getenv(name); return v ? atol(v) : dflt; };
+    e->opt_scan_dbg = (uint32_t)num("GFT_SCAN_DEBUG", 0);
+    e->opt_scan_prio = num("GFT_SCAN_PRIO", 1) ? 1u : 0u;
+    e->opt_scan_ordered = getenv("GFT_SCAN_ORDERED") ? 1u : 0u;
+    e->opt_solve_dbg = (uint32_t)num("GFT_SOLVE_DEBUG", 0);
+    e->opt_solve_group = (int)num("GFT_SOLVE_GROUP_DOCS", -1);
+}
+#define GFT_LOCK(e) std::lock_guard<std::recursive_mutex> _gft_lock((e)->mu)
 
 int fail(const gft_engine* e, int code, const std::string& msg) {
     e->err = msg;
@@ -322,10 +345,13 @@ int ensure_pool(gft_engine* e, uint64_t entries) {
 // d_term / d_pos and *n_matches is set.
 constexpr uint64_t kHostUnitDocs = 1024;   // batches up to this many documents get their unit table from the host
 
+// defer_ok: the caller reads the control block back itself after its last kernel (deferred_check) -- the unit table and
+// the match pool are then sized from the previous batch, and a batch that outgrew them is run again.
 int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_off, uint64_t n_docs, uint32_t flags,
-                  bool need_csr, uint64_t* n_matches, const uint64_t* h_doc_off = nullptr) {
+                  bool need_csr, uint64_t* n_matches, const uint64_t* h_doc_off = nullptr, bool defer_ok = false) {
     hipStream_t st = e->stream;
     *n_matches = 0;
+    e->deferred = false;
     e->scan_valid_docs = ~0ull;           // the pool is about to be overwritten
     HIP_TRY(e->d_match_off.ensure((n_docs + 1) * 8), "match_off alloc");
     if (n_docs == 0) {
@@ -340,7 +366,7 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
 
     // 1. work units
     HIP_TRY(e->d_ctl.ensure(64), "control alloc");
-    HIP_TRY(hipMemsetAsync(e->d_ctl.p, 0, 24, st), "memset");     // flag, cursor, match count
+    HIP_TRY(hipMemsetAsync(e->d_ctl.p, 0, 32, st), "memset");     // flag, cursor, match count, non-ASCII flag
     HIP_TRY(e->d_unit_cnt.ensure(n_docs * 4), "unit alloc");
     HIP_TRY(e->d_unit_base.ensure((n_docs + 1) * 8), "unit alloc");
     HIP_TRY(e->d_partial.ensure(scan_partials_needed(n_docs) * 8), "unit alloc");
@@ -375,13 +401,23 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
                                           e->d_partial.as<uint64_t>(), st), "unit scan");
             HIP_TRY(launch_pack_ctl(e->d_unit_base.as<uint64_t>(), d_doc_off, n_docs, e->d_ctl.as<uint64_t>() + 4, st), "unit scan");
         }
-        uint64_t rb[7] = {0, 0, 0, 0, 0, 0, 0};
-        HIP_TRY(hipMemcpyAsync(rb, e->d_ctl.p, sizeof rb, hipMemcpyDeviceToHost, st), "readback");
-        HIP_TRY(hipStreamSynchronize(st), "sync");
-        n_units = rb[4]; text_lo = rb[5]; text_hi = rb[6];
-        const uint32_t bad_doc = (uint32_t)rb[0];
-        if (text_hi < text_lo) return fail(e, GFT_E_INVALID, "doc_off is not ascending");
-        if (bad_doc) return fail(e, GFT_E_INVALID, "doc_off is not ascending, or a document is longer than 4 GiB - 1 bytes (positions are 32-bit)");
+        // No read-back when the caller checks afterwards: the tables keep the size the last batch gave them (a document
+        // is one unit unless it is longer than unit_max), units beyond the table are dropped and every index is clamped
+        // into it -- deferred_check sees the true count and has the batch run again
+        const uint64_t cap_units = std::min(std::min(e->d_units.cap / sizeof(Unit), e->d_unit_start.cap / 8), e->d_unit_count.cap / 4);
+        e->deferred = defer_ok && !need_csr && cap_units >= n_docs && e->pool_cap > 0;
+        if (e->deferred) {
+            n_units = cap_units; text_lo = 0; text_hi = ~0ull;       // (the text blob is readable 64 bytes past its end: gft.h)
+            e->deferred_unit_cap = cap_units;
+        } else {
+            uint64_t rb[7] = {0, 0, 0, 0, 0, 0, 0};
+            HIP_TRY(hipMemcpyAsync(rb, e->d_ctl.p, sizeof rb, hipMemcpyDeviceToHost, st), "readback");
+            HIP_TRY(hipStreamSynchronize(st), "sync");
+            n_units = rb[4]; text_lo = rb[5]; text_hi = rb[6];
+            const uint32_t bad_doc = (uint32_t)rb[0];
+            if (text_hi < text_lo) return fail(e, GFT_E_INVALID, "doc_off is not ascending");
+            if (bad_doc) return fail(e, GFT_E_INVALID, "doc_off is not ascending, or a document is longer than 4 GiB - 1 bytes (positions are 32-bit)");
+        }
     }
 
     HIP_TRY(e->d_units.ensure(n_units * sizeof(Unit)), "unit alloc");
@@ -393,13 +429,17 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         ProfScope ps(e, "aux");
         if (host_units) {
             if (n_units) HIP_TRY(hipMemcpyAsync(e->d_units.p, hun.data(), n_units * sizeof(Unit), hipMemcpyHostToDevice, st), "unit upload");
+        } else if (e->deferred) {
+            HIP_TRY(hipMemsetAsync(e->d_units.p, 0, n_units * sizeof(Unit), st), "memset");      // empty units behind the real ones
+            HIP_TRY(launch_unit_fill(d_doc_off, n_docs, e->d_unit_base.as<uint64_t>(), e->d_units.as<Unit>(), st, n_units), "unit_fill");
+            HIP_TRY(launch_clamp_u64(e->d_unit_base.as<uint64_t>(), n_docs + 1, n_units, st), "unit clamp");
         } else {
             HIP_TRY(launch_unit_fill(d_doc_off, n_docs, e->d_unit_base.as<uint64_t>(), e->d_units.as<Unit>(), st), "unit_fill");
         }
     }
 
     // 2. automaton walk into the slab pool; grow the pool and re-run if it overflowed (never truncate)
-    int rc = ensure_pool(e, std::max<uint64_t>(1u << 20, (text_hi - text_lo) / 16));
+    int rc = e->deferred ? GFT_OK : ensure_pool(e, std::max<uint64_t>(1u << 20, (text_hi - text_lo) / 16));
     if (rc) return rc;
     uint64_t total = 0;
     for (int attempt = 0; attempt < 3 && e->use_scan3; attempt++) {
@@ -423,6 +463,7 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         P.want_pos = (need_csr || e->n_inord_groups > 0) ? 1 : 0;
         P.prio = e->opt_scan_prio;
         P.dbg = e->opt_scan_dbg;
+        P.nonascii = e->d_ctl.as<uint32_t>() + 6;
         P.cand_cap = e->scan3_cand_cap;
         P.cursor = e->d_ctl.as<uint64_t>() + 1; P.pool_cap = e->pool_cap;
         P.pool_term = e->d_pool_term.as<uint32_t>(); P.pool_pos = e->d_pool_pos.as<uint32_t>();
@@ -436,11 +477,13 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
             ProfScope ps(e, "scan");
             HIP_TRY(launch_scan3(P, e->scan3_waves, e->n_cus, st), "scan kernel launch");
         }
-        uint64_t ct[2] = {0, 0};
-        HIP_TRY(hipMemcpyAsync(ct, e->d_ctl.as<uint8_t>() + 8, 16, hipMemcpyDeviceToHost, st), "readback");
+        if (e->deferred) return GFT_OK;                       // (deferred_check reads the cursor after the solver)
+        uint64_t ct[3] = {0, 0, 0};
+        HIP_TRY(hipMemcpyAsync(ct, e->d_ctl.as<uint8_t>() + 8, 24, hipMemcpyDeviceToHost, st), "readback");
         HIP_TRY(hipStreamSynchronize(st), "scan kernel");
         const uint64_t cursor = ct[0];
         total = ct[1];
+        e->last_nonascii = (uint32_t)ct[2] != 0;
         if (cursor <= e->pool_cap) break;
         if (attempt == 2) return fail(e, GFT_E_HIP, "match pool overflow persisted");
         rc = ensure_pool(e, cursor + cursor / 16);
@@ -477,14 +520,14 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         // through the kernel's per-lane staging path (normally the fallback for units whose matches overflow the LDS
         // fifo): a second implementation of the verification, kept as a cross-check
         e->csr_sorted_in_gather = need_csr;
-        P.ordered = (need_csr && getenv("GFT_SCAN_ORDERED")) ? 1 : 0;
+        P.ordered = (need_csr && e->opt_scan_ordered) ? 1 : 0;
         // presence-only mode: positions are only read by INORD groups (and by CSR callers)
         P.want_pos = (need_csr || e->n_inord_groups > 0) ? 1 : 0;
-        const char* dbg = getenv("GFT_SCAN_DEBUG");
-        P.dbg = dbg ? (uint32_t)atoi(dbg) : 0;
+        P.dbg = e->opt_scan_dbg;
+        P.nonascii = e->d_ctl.as<uint32_t>() + 6;
         // wave priorities: the latency-bound verification stages overtake the filter phase of the other waves (5 % on
         // the benchmark; GFT_SCAN_PRIO=0 switches it off)
-        { const char* pr = getenv("GFT_SCAN_PRIO"); P.prio = pr ? (atoi(pr) ? 1u : 0u) : 1u; }
+        P.prio = e->opt_scan_prio;
         P.dbg_counters = nullptr;
         if (P.dbg & 2) {
             HIP_TRY(e->d_dbg.ensure(32), "debug alloc");
@@ -496,11 +539,13 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
             // gft_scan2 serves both paths (ordered for CSR results, unordered + balanced for the solver)
             HIP_TRY(launch_scan2(P, e->scan2_k2_waves, e->n_cus, st), "scan kernel launch");
         }
-        uint64_t ct[2] = {0, 0};
-        HIP_TRY(hipMemcpyAsync(ct, e->d_ctl.as<uint8_t>() + 8, 16, hipMemcpyDeviceToHost, st), "readback");
+        if (e->deferred) return GFT_OK;                       // (deferred_check reads the cursor after the solver)
+        uint64_t ct[3] = {0, 0, 0};
+        HIP_TRY(hipMemcpyAsync(ct, e->d_ctl.as<uint8_t>() + 8, 24, hipMemcpyDeviceToHost, st), "readback");
         HIP_TRY(hipStreamSynchronize(st), "scan kernel");
         const uint64_t cursor = ct[0];
         total = ct[1];
+        e->last_nonascii = (uint32_t)ct[2] != 0;
         if (P.dbg & 2) {
             uint64_t c4[4] = {0, 0, 0, 0};
             HIP_TRY(hipMemcpy(c4, e->d_dbg.p, 32, hipMemcpyDeviceToHost), "debug readback");
@@ -533,6 +578,7 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         P.max_term_len = e->tab.max_term_len;
         P.pos_end = (e->build_flags & GFT_POS_END) ? 1 : 0;
         P.fold = (flags & GFT_FOLD_ASCII) ? 1 : 0;
+        P.nonascii = e->d_ctl.as<uint32_t>() + 6;
         P.cursor = e->d_ctl.as<uint64_t>() + 1; P.pool_cap = e->pool_cap;
         P.pool_term = e->d_pool_term.as<uint32_t>(); P.pool_pos = e->d_pool_pos.as<uint32_t>();
         P.unit_start = e->d_unit_start.as<uint64_t>(); P.unit_count = e->d_unit_count.as<uint32_t>();
@@ -540,8 +586,12 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
             ProfScope ps(e, "scan");
             HIP_TRY(launch_scan_units(P, e->n_cus, st), "scan kernel launch");
         }
-        HIP_TRY(hipMemcpyAsync(&total, e->d_ctl.as<uint8_t>() + 8, 8, hipMemcpyDeviceToHost, st), "readback");
+        if (e->deferred) return GFT_OK;
+        uint64_t ct[3] = {0, 0, 0};
+        HIP_TRY(hipMemcpyAsync(ct, e->d_ctl.as<uint8_t>() + 8, 24, hipMemcpyDeviceToHost, st), "readback");
         HIP_TRY(hipStreamSynchronize(st), "scan kernel");
+        total = ct[0];
+        e->last_nonascii = (uint32_t)ct[2] != 0;
         if (total <= e->pool_cap) break;
         if (attempt == 2) return fail(e, GFT_E_HIP, "match pool overflow persisted");
         rc = ensure_pool(e, total + total / 16);
@@ -570,6 +620,36 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
     return GFT_OK;
 }
 
+// After the last kernel of a batch whose scan was launched blind (scan_pipeline, defer_ok): ONE read-back of the control
+// block -- the batch's only host synchronisation.  *again = the unit table or the match pool was too small (they have
+// been grown): the caller runs the batch once more, this time with the sizes known.
+int deferred_check(gft_engine* e, bool* again) {
+    *again = false;
+    if (!e->deferred) return GFT_OK;
+    e->deferred = false;
+    uint64_t rb[7] = {0, 0, 0, 0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(rb, e->d_ctl.p, sizeof rb, hipMemcpyDeviceToHost, e->stream), "readback");
+    HIP_TRY(hipStreamSynchronize(e->stream), "process pipeline");
+    const uint64_t cursor = rb[1], total = rb[2], n_units = rb[4], text_lo = rb[5], text_hi = rb[6];
+    e->last_nonascii = (uint32_t)rb[3] != 0;
+    if (text_hi < text_lo) return fail(e, GFT_E_INVALID, "doc_off is not ascending");
+    if ((uint32_t)rb[0]) return fail(e, GFT_E_INVALID, "doc_off is not ascending, or a document is longer than 4 GiB - 1 bytes (positions are 32-bit)");
+    // (the DFA kernel's cursor counts matches, the suffix-window kernels' slabs: both must fit the pool)
+    if (n_units > e->deferred_unit_cap || cursor > e->pool_cap) {
+        if (cursor > e->pool_cap) { int rc = ensure_pool(e, cursor + cursor / 16); if (rc) return rc; }
+        *again = true;
+        return GFT_OK;
+    }
+    if (e->use_scan2 && !e->use_scan3 && !e->opt_scan_ordered && text_hi > text_lo) {
+        // scan2: a unit of maximal size should fill ~75 % of the fifo
+        const double per_byte = (double)total / (double)(text_hi - text_lo);
+        const double want = per_byte > 0 ? 0.75 * kScan2FifoCap / per_byte : (double)kScan2UnitMax;
+        const uint32_t um = want >= kScan2UnitMax ? kScan2UnitMax : (uint32_t)want & ~255u;
+        e->scan2_unit_max = std::max<uint32_t>(512, um);
+    }
+    return GFT_OK;
+}
+
 int solve_pipeline(gft_engine* e, uint64_t n_docs, const gft_extra_matches* d_extra, uint32_t* d_bitmap) {
     if (!n_docs || !e->n_exprs) return GFT_OK;
     SolveParams S;
@@ -591,15 +671,14 @@ int solve_pipeline(gft_engine* e, uint64_t n_docs, const gft_extra_matches* d_ex
     S.tile_words = std::min<uint32_t>(kSolveTileWords, (e->n_exprs + 31) / 32);
     S.bitmap = d_bitmap;
     S.p_scratch = nullptr;
-    { const char* dbg = getenv("GFT_SOLVE_DEBUG"); S.dbg = dbg ? (uint32_t)atoi(dbg) : 0; }
+    S.dbg = e->opt_solve_dbg;
     // Presence matrix in LDS next to the output tile: G documents per group = G / 8 bytes per slot, the widest G of
     // 64 / 32 / 16 / 8 that fits (GFT_SOLVE_GROUP_DOCS forces one, for tests); beyond that in HBM (served by L2), G = 64
     S.fprog_words = e->fprog_words;
     uint32_t group_docs = 64;
     bool p_in_lds = false;
-    const char* force_g = getenv("GFT_SOLVE_GROUP_DOCS");
     for (uint32_t G : {64u, 32u, 16u, 8u}) {
-        if (force_g && (uint32_t)atoi(force_g) != G) continue;
+        if (e->opt_solve_group >= 0 && (uint32_t)e->opt_solve_group != G) continue;
         if (solve_lds_bytes(S.n_slots, S.tile_words, G, true, 0, 0, false) + 1024 <= e->lds_max) { group_docs = G; p_in_lds = true; break; }
     }
     // ... and the fused programs too, if there is room left (the interpreter fetches them word after word)
@@ -677,8 +756,7 @@ int gft_engine_create(gft_engine** out, int device) {
     // (torch's default stream, plain hipMemcpy) produces the device buffers it hands to *_device entry points
     if (hipStreamCreateWithFlags(&e->stream, hipStreamDefault) == hipSuccess) e->own_stream = true;
     else e->stream = nullptr;
-    { const char* pr = getenv("GFT_SCAN_PRIO"); if (pr) e->opt_scan_prio = atoi(pr) ? 1u : 0u; }
-    { const char* dbg = getenv("GFT_SCAN_DEBUG"); if (dbg) e->opt_scan_dbg = (uint32_t)atoi(dbg); }
+    refresh_options(e);
     *out = e;
     return GFT_OK;
 }
@@ -714,6 +792,7 @@ const char* gft_last_error(const gft_engine* e) { return e ? e->err.c_str() : "n
 
 int gft_set_stream(gft_engine* e, void* hip_stream) {
     if (!e) return GFT_E_INVALID;
+    GFT_LOCK(e);
     if (e->device < 0) return fail(e, GFT_E_HIP, "no HIP device available");
     DeviceGuard g(e->device);
     if (e->own_stream && e->stream) { (void)hipStreamSynchronize(e->stream); (void)hipStreamDestroy(e->stream); }
@@ -732,6 +811,7 @@ static int install_tables(gft_engine* e, uint32_t flags) {
         return fail(e, GFT_E_UNSUPPORTED, "keyword longer than " + std::to_string(kTextBuf - 1024) + " bytes");
     if (e->tab.n_states >= 0x7FFFFFFFu) return fail(e, GFT_E_UNSUPPORTED, "automaton too large");
     e->build_flags = flags;
+    refresh_options(e);
 
     DeviceGuard g(e->device);
     const size_t fixed = 256 + (size_t)(kScanBlockThreads / 64) * kTextBuf + 1024;
@@ -779,7 +859,7 @@ static int install_tables(gft_engine* e, uint32_t flags) {
         if ((rc = upload(e, e->d_s3_cls, g1, "table upload"))) return rc;
         if ((rc = upload(e, e->d_s3_cls_fold, g2, "table upload"))) return rc;
         HIP_TRY(hipStreamSynchronize(e->stream), "table upload");      // g1 / g2 / s3v are locals
-        if (getenv("GFT_SCAN_DEBUG"))
+        if (e->opt_scan_dbg || getenv("GFT_SCAN_DEBUG"))
             fprintf(stderr, "[gft build debug] scan3: G=%u%s keys=%llu anchors=%llu slots=%zu more=%zu bloom 2^%u (%s) short cells: lds records %zu, big words %zu; waves=%u cand_cap=%u\n",
                     e->s3.G, e->s3.grouped ? " (merged classes)" : "", (unsigned long long)e->s3.n_keys, (unsigned long long)e->s3.n_anchors,
                     e->s3.slots.size(), e->s3.more.size(), e->s3.bloom_lg, bloom_lds_bytes ? "LDS" : "global", e->s3.srec.size() / kScan3RecWords - 1,
@@ -822,6 +902,7 @@ static int install_tables(gft_engine* e, uint32_t flags) {
 
 int gft_build(gft_engine* e, const uint8_t* terms_blob, const uint64_t* term_off, uint32_t n_terms, uint32_t flags) {
     if (!e || (n_terms && (!terms_blob || !term_off))) return e ? fail(e, GFT_E_INVALID, "null argument") : GFT_E_INVALID;
+    GFT_LOCK(e);
     if (e->device < 0) return fail(e, GFT_E_HIP, "no HIP device available");
     std::vector<std::string> terms;
     terms.reserve(n_terms);
@@ -839,6 +920,7 @@ int gft_build(gft_engine* e, const uint8_t* terms_blob, const uint64_t* term_off
 uint32_t gft_n_terms(const gft_engine* e) { return e ? (uint32_t)e->tab.terms.size() : 0; }
 uint32_t gft_n_states(const gft_engine* e) { return e ? e->tab.n_states : 0; }
 uint32_t gft_n_exprs(const gft_engine* e) { return e ? e->n_exprs : 0; }
+int gft_last_nonascii(const gft_engine* e) { return e && e->last_nonascii ? 1 : 0; }
 
 int gft_term(const gft_engine* e, uint32_t term_id, const uint8_t** ptr, uint32_t* len) {
     if (!e || !ptr || !len) return GFT_E_INVALID;
@@ -859,6 +941,7 @@ int64_t gft_term_id(const gft_engine* e, const uint8_t* term, uint32_t len) {
 
 int gft_export_tables(const gft_engine* e, uint8_t* out, uint64_t cap, uint64_t* needed) {
     if (!e) return GFT_E_INVALID;
+    GFT_LOCK(e);
     if (!e->built) return fail(e, GFT_E_NOT_BUILT, "gft_build has not been called");
     Writer w;
     w.u32(kTablesMagic); w.u32(kTablesVersion); w.u32((uint32_t)sizeof(Scan2Slot)); w.u32(kScan2FptSize); w.u32(e->build_flags);
@@ -884,6 +967,7 @@ int gft_export_tables(const gft_engine* e, uint8_t* out, uint64_t cap, uint64_t*
 
 int gft_import_tables(gft_engine* e, const uint8_t* blob, uint64_t len) {
     if (!e || !blob) return e ? fail(e, GFT_E_INVALID, "null argument") : GFT_E_INVALID;
+    GFT_LOCK(e);
     if (len < 28) return fail(e, GFT_E_INVALID, "table blob too short");
     uint64_t sum = 1469598103934665603ull, stored;
     for (uint64_t i = 0; i + 8 < len; i++) { sum ^= blob[i]; sum *= 1099511628211ull; }
@@ -930,6 +1014,7 @@ int gft_import_tables(gft_engine* e, const uint8_t* blob, uint64_t len) {
 int gft_scan_device(gft_engine* e, const uint8_t* d_text_blob, const uint64_t* d_doc_off, uint64_t n_docs,
                     uint32_t flags, gft_matches* out_dev) {
     if (!e || !out_dev || (n_docs && (!d_text_blob || !d_doc_off))) return e ? fail(e, GFT_E_INVALID, "null argument") : GFT_E_INVALID;
+    GFT_LOCK(e);
     if (e->device < 0) return fail(e, GFT_E_HIP, "no HIP device available");
     if (!e->built) return fail(e, GFT_E_NOT_BUILT, "gft_build has not been called");
     DeviceGuard g(e->device);
@@ -988,6 +1073,7 @@ static int stage_docs(gft_engine* e, const uint8_t* text_blob, const uint64_t* d
 int gft_scan(gft_engine* e, const uint8_t* text_blob, const uint64_t* doc_off, uint64_t n_docs, uint32_t flags,
              gft_matches* out) {
     if (!e || !out || (n_docs && (!doc_off))) return e ? fail(e, GFT_E_INVALID, "null argument") : GFT_E_INVALID;
+    GFT_LOCK(e);
     if (e->device < 0) return fail(e, GFT_E_HIP, "no HIP device available");
     if (!e->built) return fail(e, GFT_E_NOT_BUILT, "gft_build has not been called");
     DeviceGuard g(e->device);
@@ -1013,6 +1099,7 @@ int gft_scan(gft_engine* e, const uint8_t* text_blob, const uint64_t* doc_off, u
 int gft_set_programs(gft_engine* e, const uint32_t* prog_words, const uint64_t* prog_off, uint32_t n_exprs,
                      uint32_t n_extra) {
     if (!e || (n_exprs && (!prog_words || !prog_off))) return e ? fail(e, GFT_E_INVALID, "null argument") : GFT_E_INVALID;
+    GFT_LOCK(e);
     if (e->device < 0) return fail(e, GFT_E_HIP, "no HIP device available");
     if (!e->built) return fail(e, GFT_E_NOT_BUILT, "gft_build has not been called");
     const uint32_t n_slots = (uint32_t)e->tab.terms.size() + n_extra;
@@ -1073,7 +1160,8 @@ int gft_set_programs(gft_engine* e, const uint32_t* prog_words, const uint64_t* 
     if (blk_deep.empty()) blk_deep.push_back(0);
     if (fblk_off.empty()) fblk_off.push_back(0);
     if (fprog_t.empty()) fprog_t.push_back(0);
-    if (getenv("GFT_SOLVE_DEBUG")) {
+    refresh_options(e);
+    if (e->opt_solve_dbg) {
         uint64_t hist[16] = {0}, with_rare = 0, maxlen = 0;
         for (uint32_t i = 0; i < n_exprs; i++) {
             bool rare = false;
@@ -1107,16 +1195,27 @@ int gft_set_programs(gft_engine* e, const uint32_t* prog_words, const uint64_t* 
 int gft_process_device(gft_engine* e, const uint8_t* d_text_blob, const uint64_t* d_doc_off, uint64_t n_docs,
                        uint32_t flags, const gft_extra_matches* d_extra, uint32_t* d_hit_bitmap) {
     if (!e || (n_docs && (!d_text_blob || !d_doc_off))) return e ? fail(e, GFT_E_INVALID, "null argument") : GFT_E_INVALID;
+    GFT_LOCK(e);
     if (e->device < 0) return fail(e, GFT_E_HIP, "no HIP device available");
     if (!e->built) return fail(e, GFT_E_NOT_BUILT, "gft_build has not been called");
     if (!e->have_programs) return fail(e, GFT_E_NOT_BUILT, "gft_set_programs has not been called");
     if (n_docs && e->n_exprs && !d_hit_bitmap) return fail(e, GFT_E_INVALID, "null bitmap");
     DeviceGuard g(e->device);
-    uint64_t nm = 0;
-    int rc = scan_pipeline(e, d_text_blob, d_doc_off, n_docs, flags, false, &nm);
-    if (rc) return rc;
-    rc = solve_pipeline(e, n_docs, d_extra, d_hit_bitmap);
-    if (rc) return rc;
+    // units -> scan -> solve without a host round trip in between; one read-back at the end, and a second pass only when
+    // this batch outgrew the unit table or the match pool the previous ones left behind
+    for (int pass = 0; pass < 2; pass++) {
+        uint64_t nm = 0;
+        int rc = scan_pipeline(e, d_text_blob, d_doc_off, n_docs, flags, false, &nm, nullptr, pass == 0);
+        if (rc) return rc;
+        const bool was_deferred = e->deferred;
+        rc = solve_pipeline(e, n_docs, d_extra, d_hit_bitmap);
+        if (rc) return rc;
+        if (!was_deferred) break;
+        bool again = false;
+        rc = deferred_check(e, &again);
+        if (rc) return rc;
+        if (!again) return GFT_OK;
+    }
     HIP_TRY(hipStreamSynchronize(e->stream), "process pipeline");
     return GFT_OK;
 }
@@ -1145,6 +1244,7 @@ int upload_extra(gft_engine* e, const gft_extra_matches* extra, uint64_t n_docs,
 
 int gft_process_again(gft_engine* e, uint64_t n_docs, const gft_extra_matches* extra, uint32_t* hit_bitmap) {
     if (!e) return GFT_E_INVALID;
+    GFT_LOCK(e);
     if (e->device < 0) return fail(e, GFT_E_HIP, "no HIP device available");
     if (!e->built || !e->have_programs) return fail(e, GFT_E_NOT_BUILT, "engine not ready");
     if (e->scan_valid_docs != n_docs || !n_docs) return fail(e, GFT_E_INVALID, "gft_process_again: no scan of these documents to reuse");
@@ -1167,6 +1267,7 @@ int gft_process_again(gft_engine* e, uint64_t n_docs, const gft_extra_matches* e
 int gft_process(gft_engine* e, const uint8_t* text_blob, const uint64_t* doc_off, uint64_t n_docs, uint32_t flags,
                 const gft_extra_matches* extra, uint32_t* hit_bitmap) {
     if (!e || (n_docs && !doc_off)) return e ? fail(e, GFT_E_INVALID, "null argument") : GFT_E_INVALID;
+    GFT_LOCK(e);
     if (e->device < 0) return fail(e, GFT_E_HIP, "no HIP device available");
     if (!e->built) return fail(e, GFT_E_NOT_BUILT, "gft_build has not been called");
     if (!e->have_programs) return fail(e, GFT_E_NOT_BUILT, "gft_set_programs has not been called");
@@ -1214,12 +1315,14 @@ int gft_debug_emulate_scan(const uint8_t* terms_blob, const uint64_t* term_off, 
 
 int gft_profile_enable(gft_engine* e, int on) {
     if (!e) return GFT_E_INVALID;
+    GFT_LOCK(e);
     e->profiling = on != 0;
     return GFT_OK;
 }
 
 int gft_profile_reset(gft_engine* e) {
     if (!e) return GFT_E_INVALID;
+    GFT_LOCK(e);
     if (e->device < 0) return GFT_OK;
     DeviceGuard g(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
@@ -1232,6 +1335,7 @@ int gft_profile_reset(gft_engine* e) {
 
 int gft_profile_read(gft_engine* e, const char* name, double* total_ms, uint64_t* launches) {
     if (!e || !name || !total_ms || !launches) return GFT_E_INVALID;
+    GFT_LOCK(e);
     *total_ms = 0; *launches = 0;
     if (e->device < 0) return fail(e, GFT_E_HIP, "no HIP device available");
     DeviceGuard g(e->device);

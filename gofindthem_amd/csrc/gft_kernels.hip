@@ -52,8 +52,11 @@ __global__ void k_pack_ctl(const uint64_t* __restrict__ unit_base, const uint64_
     out[2] = doc_off[n_docs];
 }
 
+// max_units: capacity of `units` (entries beyond it are dropped: the host sized the table before it knew the count, sees
+// the true count afterwards and runs the batch again with a table that holds it)
 __global__ void __launch_bounds__(256) k_unit_fill(const uint64_t* __restrict__ doc_off, uint64_t n_docs,
-                                                   const uint64_t* __restrict__ unit_base, Unit* __restrict__ units) {
+                                                   const uint64_t* __restrict__ unit_base, Unit* __restrict__ units,
+                                                   uint64_t max_units) {
     uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= n_docs) return;
     uint64_t n = doc_off[d + 1] - doc_off[d];
@@ -63,8 +66,14 @@ __global__ void __launch_bounds__(256) k_unit_fill(const uint64_t* __restrict__ 
     for (uint32_t i = 0; i < k; i++) {
         uint64_t lo = (uint64_t)i * per, hi = lo + per < n ? lo + per : n;
         if (lo > n) lo = n;
-        units[b + i] = Unit{(uint32_t)d, (uint32_t)lo, (uint32_t)hi};
+        if (b + i < max_units) units[b + i] = Unit{(uint32_t)d, (uint32_t)lo, (uint32_t)hi};
     }
+}
+
+// unit_base[i] = min(unit_base[i], cap): after a unit table that was too small, every consumer stays inside it
+__global__ void __launch_bounds__(256) k_clamp_u64(uint64_t* __restrict__ v, uint64_t n, uint64_t cap) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && v[i] > cap) v[i] = cap;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -196,11 +205,14 @@ __global__ void __launch_bounds__(kScanBlockThreads) k_scan_units(const ScanPara
         const uint32_t seg_lo = un.lo > warm ? un.lo - warm : 0;
         const uint32_t nbytes = un.hi - seg_lo;       // <= kTextBuf by construction (host checks)
         const uint8_t* src = P.text + dstart + seg_lo;
+        uint32_t hib = 0;
         for (uint32_t i = lane; i < nbytes; i += kLane) {
             uint8_t b = src[i];
+            hib |= b;
             if (P.fold && b >= 'A' && b <= 'Z') b += 32;
             buf[i] = b;
         }
+        if (P.fold && P.nonascii && __any((hib & 0x80u) != 0) && lane == 0) atomicOr(P.nonascii, 1u);
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 
@@ -220,7 +232,7 @@ __global__ void __launch_bounds__(kScanBlockThreads) k_scan_units(const ScanPara
         if (lane == 0) {
             base = total ? atomicAdd(reinterpret_cast<unsigned long long*>(P.cursor), (unsigned long long)total) : 0;
             P.unit_start[u] = base;
-            P.unit_count[u] = total;
+            P.unit_count[u] = base + total <= P.pool_cap ? total : 0u;   // (beyond the pool: nothing is written, the host runs the batch again)
         }
         base = __shfl(base, 0, 64);
         if (active && cnt && base + total <= P.pool_cap)
@@ -422,9 +434,15 @@ hipError_t launch_pack_ctl(const uint64_t* d_unit_base, const uint64_t* d_doc_of
 }
 
 hipError_t launch_unit_fill(const uint64_t* d_doc_off, uint64_t n_docs, const uint64_t* d_unit_base, Unit* d_units,
-                            hipStream_t st) {
+                            hipStream_t st, uint64_t max_units) {
     if (!n_docs) return hipSuccess;
-    k_unit_fill<<<dim3((unsigned)((n_docs + 255) / 256)), dim3(256), 0, st>>>(d_doc_off, n_docs, d_unit_base, d_units);
+    k_unit_fill<<<dim3((unsigned)((n_docs + 255) / 256)), dim3(256), 0, st>>>(d_doc_off, n_docs, d_unit_base, d_units, max_units);
+    return hipGetLastError();
+}
+
+hipError_t launch_clamp_u64(uint64_t* d_v, uint64_t n, uint64_t cap, hipStream_t st) {
+    if (!n) return hipSuccess;
+    k_clamp_u64<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(d_v, n, cap);
     return hipGetLastError();
 }
 

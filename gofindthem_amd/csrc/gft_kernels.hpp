@@ -31,6 +31,7 @@ struct ScanParams {
     const uint32_t* term_len;
     uint32_t n_classes, n_states, n_lds_states, max_term_len;
     uint32_t pos_end, fold;
+    uint32_t* nonascii;          // fold only: *nonascii |= 1 when the text holds a byte >= 0x80 (nullptr: not wanted)
     // output
     uint64_t* cursor;            // pool allocation cursor (entries)
     uint64_t pool_cap;
@@ -226,6 +227,7 @@ struct Scan2Params {
                                  // stage B 3; 0: off
     uint32_t want_pos;           // 0: presence only -- no expression has an INORD group, pool_pos is not written
     uint32_t dbg;                // GFT_SCAN_DEBUG bits (timing studies only): 1 = skip verification, 2 = count flags
+    uint32_t* nonascii;          // fold only: *nonascii |= 1 when the text holds a byte >= 0x80 (nullptr: not wanted)
     uint64_t* dbg_counters;      // [4] when dbg & 2: flagged positions, table probes, entries compared, -
 };
 // waves per workgroup (16, 12, 8 or 4) and candidate-list capacity that fit lds_max; false if nothing fits
@@ -283,6 +285,7 @@ struct Scan3Params {
     uint32_t G, fold, pos_end, want_pos, grouped, prio;
     uint32_t cand_cap;           // entries of a wave's LDS candidate list (scan3_plan)
     uint32_t dbg;                // GFT_SCAN_DEBUG (timing studies; selects the kernel instantiation that has the knock-outs)
+    uint32_t* nonascii;          // fold only: *nonascii |= 1 when the text holds a byte >= 0x80 (nullptr: not wanted)
     uint64_t* cursor;
     uint64_t pool_cap;
     uint32_t* pool_term;
@@ -303,7 +306,8 @@ hipError_t launch_unit_count(const uint64_t* d_doc_off, uint64_t n_docs, uint32_
 // d_out[0..2] = number of units, first and last text offset (read back by the host in one copy)
 hipError_t launch_pack_ctl(const uint64_t* d_unit_base, const uint64_t* d_doc_off, uint64_t n_docs, uint64_t* d_out, hipStream_t st);
 hipError_t launch_unit_fill(const uint64_t* d_doc_off, uint64_t n_docs, const uint64_t* d_unit_base, Unit* d_units,
-                            hipStream_t st);
+                            hipStream_t st, uint64_t max_units = ~0ull);
+hipError_t launch_clamp_u64(uint64_t* d_v, uint64_t n, uint64_t cap, hipStream_t st);
 uint64_t scan_partials_needed(uint64_t n);
 // d_out has n+1 entries; d_partial has scan_partials_needed(n) entries
 hipError_t launch_exclusive_scan(const uint32_t* d_in, uint64_t n, uint64_t* d_out, uint64_t* d_partial,

@@ -102,6 +102,7 @@ struct Ctx {
     bool near24;               // ... within 23 bytes
     uint32_t lo, hi;           // the unit: a match belongs to the unit that holds its END position
     bool near_end;             // wave-uniform: the unit ends within 4 bytes of the blob end
+    uint32_t dbg;              // GFT_SCAN_DEBUG bits in the timing-study instantiations, the constant 0 in production
 };
 
 // the (up to) four bytes behind position p, text[p+1 .. p+4], for the tails of shifted terms; bytes past the blob end
@@ -171,9 +172,9 @@ __device__ __forceinline__ void cand_decide(const Ctx& c, Cand& k) {
     const uint8_t* f = FPT_LDS ? c.fpt : c.P.fpt;
     const uint32_t cx = f[scan2_fpt_xcell(k.x, flg)], cg0 = f[scan2_fpt_gcell(k.x, b1n, 0, flg)], cg1 = f[scan2_fpt_gcell(k.x, b1n, 1, flg)];
     k.go_long = scan2_fpt_pass(cx, cg0, cg1, scan2_fpt_xmix(k.x), k.tw);
-    if (c.P.dbg & 12) {         // timing studies (wrong results): 4 = no bucket-table access, 8 = no short-term records
-        if (c.P.dbg & 4) k.go_long = false;
-        if (c.P.dbg & 8) k.sid = 0;
+    if (c.dbg & 12) {           // timing studies (wrong results): 4 = no bucket-table access, 8 = no short-term records
+        if (c.dbg & 4) k.go_long = false;
+        if (c.dbg & 8) k.sid = 0;
     }
 }
 template <bool FPT_LDS>
@@ -474,7 +475,9 @@ __device__ __forceinline__ void verify_masks(const Ctx& c, uint32_t my_lo, uint3
 // ORDERED: matches of a unit leave in text order (CSR results); otherwise any order (solver input)
 // FPT_LDS: the fingerprint table is staged in LDS (dictionaries up to kScan2FptLdsItems long terms); otherwise it is read
 // in place from global memory -- the spill path of large dictionaries, which also leaves more LDS to the candidate lists
-template <bool HASHED, bool ORDERED, bool FPT_LDS>
+// DBG: the timing-study knock-outs (GFT_SCAN_DEBUG) exist only in the DBG = true instantiations; production launches
+// run DBG = false, where `dbg` is the constant 0 and every such branch is compiled out
+template <bool HASHED, bool ORDERED, bool FPT_LDS, bool DBG>
 __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
     extern __shared__ __align__(16) uint8_t smem[];
     uint8_t* cls = smem;
@@ -524,7 +527,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
         const bool more_units = u + stride < P.n_units;
         if (more_units) un_n = P.units[u + stride];
         const Ctx c{P, cls, filt, P.short3_bytes ? short3 : nullptr, fpt, lrec, P.text + doc_abs, doc_abs, kp2,
-                    doc_abs < 7, doc_abs < 23, un.lo, un.hi, doc_abs + un.hi + 4 > P.text_bytes};
+                    doc_abs < 7, doc_abs < 23, un.lo, un.hi, doc_abs + un.hi + 4 > P.text_bytes, DBG ? P.dbg : 0u};
         // A term whose window ends up to kScan2MaxOff bytes before the unit may itself end inside it: those positions
         // (units that continue a document only) join the candidates unconditionally, for such terms only
         const uint32_t nborder = un.lo < kScan2MaxOff ? un.lo : kScan2MaxOff;
@@ -556,12 +559,13 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
                                k3 = my_lo >= 3 ? lcls[(hist >> 8) & 0xFF] : P.pad_class;
                 cp = k1; pm1 = mad24s(k2, kp, k1); pm2 = mad24s(k3, kp, k2);
             }
-            uint32_t acc = 0;
+            uint32_t acc = 0, hib = 0;                           // hib: OR of the lane's text (a byte >= 0x80 anywhere?)
             const uint32_t ndw = C >> 2;                         // dwords per lane (wave-uniform, <= 32)
             const uint32_t npieces = (ndw + 3) >> 2;
             // the 16-byte piece q+1 is in flight while piece q is filtered
             for (uint32_t q = 0; q < npieces; q++) {
                 const uint32_t w[4] = {nxt.x, nxt.y, nxt.z, nxt.w};
+                if (q * 16 < nvalid) hib |= (w[0] | w[1]) | (w[2] | w[3]);   // (may take in up to 15 bytes behind the lane's range: conservative)
                 if (q + 1 < npieces && (q + 1) * 16 < nvalid) nxt = *reinterpret_cast<const U128u*>(src + (q + 1) * 16);
                 const uint32_t nd = ndw - 4 * q;                 // dwords of this piece that belong to the lane (>= 1)
 #pragma unroll
@@ -588,6 +592,8 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
                 const uint32_t k = ndw >> 3;
                 if (k == 0) m0 = v; else if (k == 1) m1 = v; else if (k == 2) m2 = v; else m3 = v;
             }
+            // ASCII folding is not strings.ToLower once the text leaves ASCII (finder.go:140-142): tell the host
+            if (P.fold && P.nonascii && __any((hib & 0x80808080u) != 0) && lane == 0) atomicOr(P.nonascii, 1u);
             // positions past the lane's range carry garbage flags
             m0 = nvalid >= 32 ? m0 : (nvalid ? m0 & ((1u << nvalid) - 1) : 0);
             m1 = nvalid >= 64 ? m1 : (nvalid > 32 ? m1 & ((1u << (nvalid - 32)) - 1) : 0);
@@ -600,7 +606,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
 
         // ---- phase 2: verify flagged positions, stage matches in LDS ----------------------------------------
         uint32_t cnt = 0;
-        if (P.dbg) {   // timing studies (GFT_SCAN_DEBUG): never set in production
+        if (DBG && P.dbg) {   // timing studies (GFT_SCAN_DEBUG)
             if (P.dbg & 2) {
                 uint32_t f = __popc(m0) + __popc(m1) + __popc(m2) + __popc(m3);
                 uint32_t mx = f;
@@ -698,7 +704,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    if (P.dbg & 2) { if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(KARG(dbg_counters) + 2), (unsigned long long)ns); }
+                    if (DBG && (P.dbg & 2)) { if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(KARG(dbg_counters) + 2), (unsigned long long)ns); }
                     if (P.prio) __builtin_amdgcn_s_setprio(3);
                     // stage B: the survivors, densely packed over the lanes, go to the L2 bucket table; the room behind
                     // them in the candidate list parks the entries of multi-term buckets
@@ -738,7 +744,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
                     slab_next += nh;
                     slab_left -= nh;
                     wave_matches += nh;
-                    if (lane == 0) { KARG(unit_start)[u] = base; KARG(unit_count)[u] = nh; }
+                    if (lane == 0) { KARG(unit_start)[u] = base; KARG(unit_count)[u] = base + nh <= KARG(pool_cap) ? nh : 0u; }   // (beyond the pool: nothing was written, the host runs the batch again)
                     if (base + nh <= KARG(pool_cap))
                         for (uint32_t i = lane; i < nh; i += 64) {
                             const uint2 r = fifo[i];
@@ -771,7 +777,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
         slab_next += total;
         slab_left -= total;
         wave_matches += total;
-        if (lane == 0) { KARG(unit_start)[u] = base; KARG(unit_count)[u] = total; }
+        if (lane == 0) { KARG(unit_start)[u] = base; KARG(unit_count)[u] = base + total <= KARG(pool_cap) ? total : 0u; }
         if (total && base + total <= KARG(pool_cap)) {
             const uint64_t mine = base + incl - cnt;
             if (cnt <= kScan2StageCap) {
@@ -804,10 +810,7 @@ static size_t scan2_fixed_lds(uint32_t filter_words, uint32_t short3_bytes, uint
 bool scan2_plan(uint32_t filter_words, uint32_t short3_bytes, uint32_t shorts_words, uint32_t fpt_lds_bytes, size_t lds_max,
                 uint32_t* waves, uint32_t* cand_cap) {
     const size_t fixed = scan2_fixed_lds(filter_words, short3_bytes, shorts_words, fpt_lds_bytes);
-    const char* cap_env = getenv("GFT_SCAN_MAX_WAVES");        // timing studies: fewer waves per workgroup
-    const uint32_t w_cap = cap_env ? (uint32_t)atoi(cap_env) : 16u;
     for (uint32_t w : {16u, 12u, 8u, 4u}) {
-        if (w > w_cap && w > 4) continue;
         if (fixed + (size_t)w * (kScan2FifoCap * 8 + kScan2CandCapMin * 2) > lds_max) continue;
         size_t per = ((lds_max - fixed) / w) & ~(size_t)15;
         size_t cap = (per - kScan2FifoCap * 8) / 2;
@@ -825,9 +828,11 @@ hipError_t launch_scan2(const Scan2Params& P, uint32_t waves, unsigned n_cus, hi
                        (size_t)waves * (kScan2FifoCap * 8 + P.cand_cap * 2);
     using Kern = void (*)(const Scan2Params);
     static const Kern table[2][2][2] = {
-        {{k_scan2<false, false, false>, k_scan2<false, false, true>}, {k_scan2<false, true, false>, k_scan2<false, true, true>}},
-        {{k_scan2<true, false, false>, k_scan2<true, false, true>}, {k_scan2<true, true, false>, k_scan2<true, true, true>}}};
-    const Kern fn = table[P.hashed ? 1 : 0][P.ordered ? 1 : 0][fl ? 1 : 0];
+        {{k_scan2<false, false, false, false>, k_scan2<false, false, true, false>}, {k_scan2<false, true, false, false>, k_scan2<false, true, true, false>}},
+        {{k_scan2<true, false, false, false>, k_scan2<true, false, true, false>}, {k_scan2<true, true, false, false>, k_scan2<true, true, true, false>}}};
+    // timing studies: the benchmark's shape only (direct filter, balanced path)
+    const Kern fn = P.dbg && !P.hashed && !P.ordered ? (fl ? k_scan2<false, false, true, true> : k_scan2<false, false, false, true>)
+                                                     : table[P.hashed ? 1 : 0][P.ordered ? 1 : 0][fl ? 1 : 0];
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     uint64_t g = (P.n_units + waves - 1) / waves;

@@ -523,9 +523,10 @@ __global__ void __launch_bounds__(kScan3Threads) k_scan3(const Scan3Params P) {
                 carry = mad24s(lcls[hp[-2]], G, lcls[hp[-1]]);
             }
             carry = __builtin_amdgcn_readfirstlane(carry);
-            uint32_t acc = 0;
+            uint32_t acc = 0, hib = 0;                              // hib: OR of the lane's text (a byte >= 0x80 anywhere?)
             for (uint32_t r = 0; r < nr; r++) {
                 const uint32_t w[4] = {nxt.x, nxt.y, nxt.z, nxt.w};
+                if (r * 1024 + lane * 16 < own) hib |= (w[0] | w[1]) | (w[2] | w[3]);   // (up to 15 bytes behind the unit: conservative)
                 if (r + 1 < nr && (r + 1) * 1024 + lane * 16 < own) nxt = *reinterpret_cast<const U128u*>(src + (r + 1) * 1024);
                 uint32_t q[8];
 #pragma unroll
@@ -548,6 +549,8 @@ __global__ void __launch_bounds__(kScan3Threads) k_scan3(const Scan3Params P) {
                 }
                 if (r == 3) { m0 = acc; acc = 0; }
             }
+            // ASCII folding is not strings.ToLower once the text leaves ASCII (finder.go:140-142): tell the host
+            if (P.fold && P.nonascii && __any((hib & 0x80808080u) != 0) && lane == 0) atomicOr(P.nonascii, 1u);
             // probe t of the unit sits in round t / 512, lane (t / 8) % 64, bit 8 * (round % 4) + t % 8 of m0 (rounds 0-3) or
             // m1 (rounds 4-7); probes of the last round that start at or beyond the unit's end carry garbage
             const uint32_t lr = nr - 1;                               // the last round
@@ -706,7 +709,8 @@ __global__ void __launch_bounds__(kScan3Threads) k_scan3(const Scan3Params P) {
             slab_next = __shfl(nb, 0, 64);
             slab_left = want;
         }
-        if (lane == 0) { KARG(unit_start)[u] = slab_next; KARG(unit_count)[u] = nh; }
+        // (a unit whose cells lie beyond the pool wrote nothing: the host sees the cursor and runs the batch again)
+        if (lane == 0) { KARG(unit_start)[u] = slab_next; KARG(unit_count)[u] = slab_next + nh <= P.pool_cap ? nh : 0u; }
         slab_next += nh;
         slab_left -= nh;
         wave_matches += nh;

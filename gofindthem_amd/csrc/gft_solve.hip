@@ -312,8 +312,9 @@ template <> struct AType<64> { using type = uint64_t; };
 // G = documents per group = bits of a presence-matrix element: 64 when 8 bytes per slot fit LDS, else 32 / 16 / 8 so that
 // large dictionaries still keep P in LDS (the evaluation then covers fewer documents per operation, but P stops being an
 // L2 ping-pong of atomics and random reads)
-template <bool P_LDS, bool PROG_LDS, int G, bool INORD>
+template <bool P_LDS, bool PROG_LDS, int G, bool INORD, bool DBG = false>
 __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const SolveParams S) {
+    const uint32_t dbg = DBG ? S.dbg : 0u;      // timing-study knock-outs (GFT_SOLVE_DEBUG): compiled out of production launches
     using PT = typename PType<G>::type;
     using AT = typename AType<G>::type;                         // document masks of the evaluation
     constexpr uint32_t kTeam = 16, kTeams = kSolveBlockThreads / kTeam;   // lanes that share one unit while P is built
@@ -371,7 +372,7 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
         const uint32_t nd = (uint32_t)(S.n_docs - d0 < (uint64_t)G ? S.n_docs - d0 : (uint64_t)G);
 
         // ---- 1. presence matrix ------------------------------------------------------------------------------
-        if (!(S.dbg & 1)) {
+        if (!(dbg & 1)) {
             const uint32_t member = threadIdx.x % kTeam;
             const uint64_t U0 = pf_U0, U1 = pf_U1;
             for (uint64_t u = U0 + threadIdx.x / kTeam; u < U1; u += kTeams) {
@@ -420,7 +421,7 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
             // 2a. evaluation in sorted order (gft_set_programs): 64 programs of similar length per wave.  Sixteen blocks
             // at a time, longest first, dealt to the waves in a snake over the four SIMDs so that the SIMDs get similar sums
             const uint32_t nblk = (ne + 63) / 64;
-            for (uint32_t b16 = 0; b16 < nblk && !(S.dbg & 2); b16 += kWaves) {
+            for (uint32_t b16 = 0; b16 < nblk && !(dbg & 2); b16 += kWaves) {
                 const uint32_t row = wave >> 2, c4 = wave & 3;
                 const uint32_t b = b16 + row * 4 + ((row & 1) ? 3 - c4 : c4);
                 const uint32_t i = b * 64 + lane;
@@ -446,8 +447,8 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
             const uint32_t rounds = (tw + 1) / 2;
             for (uint32_t r = wave; r < rounds; r += kWaves) {
                 const uint32_t el = r * 64 + lane;
-                const uint64_t acc = (el < ne && !(S.dbg & 2)) ? R[el] : 0;
-                const uint64_t mine = (S.dbg & 4) ? 0 : wave_transpose64(acc);
+                const uint64_t acc = (el < ne && !(dbg & 2)) ? R[el] : 0;
+                const uint64_t mine = (dbg & 4) ? 0 : wave_transpose64(acc);
                 O[lane * tile_words + r * 2] = (uint32_t)mine;
                 if (r * 2 + 1 < tw) O[lane * tile_words + r * 2 + 1] = (uint32_t)(mine >> 32);
             }
@@ -509,9 +510,12 @@ hipError_t launch_g(const SolveParams& S, bool p_in_lds, bool prog_in_lds, unsig
                                             : (io ? k_solve_groups<true, false, G, true> : k_solve_groups<true, false, G, false>))
                              : (prog_in_lds ? (io ? k_solve_groups<false, true, 64, true> : k_solve_groups<false, true, 64, false>)
                                             : (io ? k_solve_groups<false, false, 64, true> : k_solve_groups<false, false, 64, false>));
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    Kern run = fn;
+    // timing studies: the benchmark's shape only (presence matrix and programs in LDS, 64 documents per group)
+    if (S.dbg && G == 64 && p_in_lds && prog_in_lds) run = io ? k_solve_groups<true, true, 64, true, true> : k_solve_groups<true, true, 64, false, true>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(run), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    fn<<<dim3(grid), dim3(kSolveBlockThreads), lds, st>>>(S);
+    run<<<dim3(grid), dim3(kSolveBlockThreads), lds, st>>>(S);
     return hipGetLastError();
 }
 }  // namespace

@@ -1,5 +1,6 @@
 #include "group_host.hpp"
 
+#include <mutex>
 #include <algorithm>
 #include <atomic>
 #include <cstdio>
@@ -547,7 +548,9 @@ struct gft_group {
     std::unique_ptr<GroupFinder> g;
     std::string err;
     std::string result;      // the last gft_group_process_jsons document (gft_group_last_result)
+    mutable std::recursive_mutex mu;   // one caller at a time per handle
 };
+#define GFT_GLOCK(g) std::lock_guard<std::recursive_mutex> _gft_glock((g)->mu)
 
 // finder_host.cpp
 Finder* gft_finder_impl(gft_finder* f);
@@ -647,12 +650,14 @@ const char* gft_group_last_error(const gft_group* g) { return g ? g->err.c_str()
 
 int gft_group_add_rule(gft_group* g, const uint8_t* name, uint64_t name_len, const uint8_t* expr, uint64_t expr_len) {
     if (!g) return GFT_E_INVALID;
+    GFT_GLOCK(g);
     g->err = g->g->AddRule(std::string((const char*)name, name_len), {std::string((const char*)expr, expr_len)});
     return g->err.empty() ? GFT_OK : GFT_E_PARSE;
 }
 
 int gft_group_state(const gft_group* g, char* out, uint64_t cap, uint64_t* needed) {
     if (!g) return GFT_E_INVALID;
+    GFT_GLOCK(g);
     std::string o = "{\"rules\":{";
     bool first = true;
     for (const auto& kv : g->g->rules()) {
@@ -680,6 +685,7 @@ int gft_group_process_jsons(gft_group* g, const uint8_t* json_blob, const uint64
                             const uint8_t* include_json, uint64_t include_len, const uint8_t* exclude_json,
                             uint64_t exclude_len, int what, char* out, uint64_t cap, uint64_t* needed) {
     if (!g || (n_docs && (!json_blob || !doc_off))) return GFT_E_INVALID;
+    GFT_GLOCK(g);
     std::vector<std::string> inc, exc;
     if (!string_list(include_json, include_len, inc, g->err) || !string_list(exclude_json, exclude_len, exc, g->err))
         return GFT_E_INVALID;
@@ -707,11 +713,13 @@ int gft_group_process_jsons(gft_group* g, const uint8_t* json_blob, const uint64
 
 int gft_group_last_result(const gft_group* g, char* out, uint64_t cap, uint64_t* needed) {
     if (!g) return GFT_E_INVALID;
+    GFT_GLOCK(g);
     return put(g->result, out, cap, needed);
 }
 
 int gft_group_evaluate(gft_group* g, const uint8_t* tagmap, uint64_t len, char* out, uint64_t cap, uint64_t* needed) {
     if (!g || !tagmap) return GFT_E_INVALID;
+    GFT_GLOCK(g);
     json::Value v;
     g->err = json::Parse((const char*)tagmap, len, v);
     gdsl::TagMap m;
@@ -726,6 +734,7 @@ int gft_group_evaluate(gft_group* g, const uint8_t* tagmap, uint64_t len, char* 
 
 int gft_group_last_batch(const gft_group* g, uint64_t* leaves, uint64_t* bytes) {
     if (!g) return GFT_E_INVALID;
+    GFT_GLOCK(g);
     if (leaves) *leaves = g->g->last_leaves;
     if (bytes) *bytes = g->g->last_bytes;
     return GFT_OK;

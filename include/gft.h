@@ -15,7 +15,9 @@
  *     (finder/finder.go:11-14), uint32 per document.
  *   - match order inside one document is the reference engine's emission order: end offset ascending,
  *     then term length descending (node first, then its dictionary-suffix chain).
- *   - handles are single-caller: do not use one gft_engine from two threads at once.
+ *   - every entry point takes the handle's own mutex: a built engine / finder may be shared between threads (goroutines),
+ *     calls on one handle are serialised; result buffers the library owns (gft_scan, gft_finder_expression ...) stay valid
+ *     until the NEXT call on the same handle, so a caller that shares a handle copies them before releasing its own lock.
  *   - there is NO CPU fallback: without a HIP device every compute entry point fails with GFT_E_HIP.
  */
 #ifndef GFT_H
@@ -41,7 +43,9 @@ typedef enum gft_status {
 #define GFT_POS_START 0u /* Position = offset of the first byte of the match (default) */
 #define GFT_POS_END 1u   /* Position = offset of the last byte of the match */
 /* gft_scan / gft_process flags */
-#define GFT_FOLD_ASCII 1u /* lower-case A-Z while reading the text (finder.go:140-142 for ASCII input) */
+#define GFT_FOLD_ASCII 1u /* lower-case A-Z while reading the text (finder.go:140-142 for ASCII input).  This IS
+                           * strings.ToLower only while the text is ASCII: the kernels notice bytes >= 0x80 on their way
+                           * (gft_last_nonascii), and the finder entry points then fold such a batch on the host instead */
 
 typedef struct gft_engine gft_engine;
 
@@ -113,6 +117,11 @@ int gft_scan_device(gft_engine* e, const uint8_t* d_text_blob, const uint64_t* d
 int gft_set_programs(gft_engine* e, const uint32_t* prog_words, const uint64_t* prog_off, uint32_t n_exprs,
                      uint32_t n_extra);
 uint32_t gft_n_exprs(const gft_engine* e);
+/* 1 when the last scan / process call on this engine ran with GFT_FOLD_ASCII over text that holds a byte >= 0x80: its
+ * results equal the reference's only if that text has no non-ASCII upper-case letter, no invalid UTF-8 and no rune whose
+ * lower-case form has another length (strings.ToLower, finder/finder.go:140-142).  gft_finder_process_device checks this
+ * and repeats such a batch through the host's ToLower. */
+int gft_last_nonascii(const gft_engine* e);
 
 /* Caller-supplied matches (regex engine output, or the output of a foreign SubstringEngine), CSR per document.
  * `slot` is ABSOLUTE: n_terms + j for extra literal j, or a dictionary term id when a regex literal has the same

@@ -242,3 +242,78 @@ def test_regex_prefilter_same_results_fewer_regex_calls(prefilter, monkeypatch):
     for d in (0, 7, 199):
         one = f.ProcessText(bytes(text[int(off[d]):int(off[d + 1])]))
         assert [r.ExpresionIndex for r in one] == [i for i in range(len(exprs)) if want[d, i >> 5] >> (i & 31) & 1]
+
+
+def _device_batch(texts):
+    import torch
+    blob, off = pack_strings(texts)
+    t = torch.from_numpy(np.concatenate([blob, np.zeros(64, np.uint8)])).cuda()      # 64 bytes of readable slack
+    o = torch.from_numpy(off.astype(np.int64)).cuda()
+    return t, o
+
+
+def test_process_device_non_ascii_text_takes_the_host_tolower():
+    """gft_finder_process_device folds A-Z on the device; text that leaves ASCII must still come out like the reference's
+    strings.ToLower (finder.go:140-142): upper-case non-ASCII letters, and the Kelvin sign U+212A whose lower-case form
+    'k' is shorter.  The kernels flag bytes >= 0x80, the finder repeats such a batch through the host path."""
+    import torch
+    f = Finder(GpuEngine(), EmptyRgxEngine(), False)
+    exprs = ['"école"', '"kelvin"', 'inord("la" and "école")', '"ecole"', '"k"']
+    f.AddExpressions(exprs)
+    texts = ["Vive la École", "273 Kelvin", "plain ascii ECOLE", "", "la école"]
+    t, o = _device_batch(texts)
+    words = 1
+    bm = torch.zeros((len(texts), words), dtype=torch.int32, device="cuda")
+    f.ProcessDevice(t.data_ptr(), o.data_ptr(), len(texts), bm.data_ptr())
+    got = bm.cpu().numpy().astype(np.uint32)
+    # oracle: the reference lower-cases the text first (Python's str.lower() agrees with Go on these strings)
+    o2 = Oracle(sorted({"école", "kelvin", "la", "ecole", "k"}))
+    o2.set_expressions(exprs, False)
+    lb, lo = pack_strings([s.lower() for s in texts])
+    want = o2.process(lb, lo, fold=False)
+    assert np.array_equal(got, want)
+    assert got[:, 0].tolist() == [0b00101, 0b10010, 0b01000, 0, 0b00101]
+    assert _lib_load().gft_last_nonascii(f.engine_handle()) in (0, 1)
+    # an ASCII batch stays on the device path
+    t, o = _device_batch(["ECOLE kelvin", "K"])
+    bm = torch.zeros((2, 1), dtype=torch.int32, device="cuda")
+    f.ProcessDevice(t.data_ptr(), o.data_ptr(), 2, bm.data_ptr())
+    assert bm.cpu().numpy().astype(np.uint32)[:, 0].tolist() == [0b11010, 0b10000]
+    assert _lib_load().gft_last_nonascii(f.engine_handle()) == 0
+
+
+def _lib_load():
+    from gofindthem_amd import _lib
+    return _lib.load()
+
+
+def test_process_device_one_read_back_per_batch_and_regrowth():
+    """gft_process_device sizes the unit table and the match pool from the previous batch and reads the control block
+    back once, after the solver; a batch that outgrows them (longer documents -> more units, a denser dictionary hit
+    rate -> more matches) is run again with the right sizes.  Results must not depend on any of that."""
+    import torch
+    from gofindthem_amd.workload import Workload, make_expressions
+    w = Workload(500)
+    terms = w.terms()
+    exprs = make_expressions(terms, 64, inord_fraction=0.5, cover=True)
+    f = Finder(GpuEngine(), EmptyRgxEngine(), False)
+    f.AddExpressions(exprs)
+    o = Oracle(sorted(set(t.decode() for t in terms)))
+    o.set_expressions(exprs, False)
+
+    def run(texts):
+        t, off = _device_batch(texts)
+        bm = torch.zeros((len(texts), 2), dtype=torch.int32, device="cuda")
+        f.ProcessDevice(t.data_ptr(), off.data_ptr(), len(texts), bm.data_ptr())
+        lb, lo = pack_strings(texts)
+        assert np.array_equal(bm.cpu().numpy().astype(np.uint32), o.process(lb, lo, fold=True))
+
+    text, off = w.docs_host(0, 300)
+    docs = [bytes(text[int(off[d]):int(off[d + 1])]).decode() for d in range(300)]
+    run(docs[:50])                       # first batch: sizes unknown, synchronous path
+    run(docs[50:100])                    # same shape: deferred path
+    run(docs[100:300])                   # more documents than the unit table holds: regrown, run again
+    run([" ".join(docs[:40])] + docs[40:60])     # one 160 KB document -> many units
+    dense = " ".join(t.decode() for t in terms[:200]) * 30
+    run([dense, dense[:5000], docs[7]])  # far more matches per byte than the pool was sized for
+    run(docs[:50])

@@ -9,6 +9,7 @@ LIB_PATH = os.path.join(HERE, "libgft.so")
 GFT_OK, GFT_E_INVALID, GFT_E_NOT_BUILT, GFT_E_HIP, GFT_E_UNSUPPORTED, GFT_E_PARSE, GFT_E_ENGINE = 0, -1, -2, -3, -4, -5, -6
 GFT_POS_START, GFT_POS_END = 0, 1
 GFT_FOLD_ASCII = 1
+GFT_SCAN_UNIQUE = 2
 OP_UNIT, OP_AND, OP_OR, OP_NOT, OP_INORD = 1, 2, 3, 4, 5
 INORD_FLAG = 1 << 27
 

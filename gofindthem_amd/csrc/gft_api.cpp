@@ -116,6 +116,7 @@ struct gft_engine {
     uint64_t pool_cap = 0;
     // staging for the host-buffer entry points
     DevBuf d_text, d_doc_off, d_bitmap, d_xoff, d_xslot, d_xpos;
+    DevBuf d_uq_first, d_uq_cnt, d_uq_off, d_uq_term;   // GFT_SCAN_UNIQUE: per-workgroup first-occurrence rows, unique CSR
     std::vector<uint64_t> h_match_off;
     std::vector<uint32_t> h_term, h_pos;
 
@@ -650,6 +651,38 @@ int deferred_check(gft_engine* e, bool* again) {
     return GFT_OK;
 }
 
+// GFT_SCAN_UNIQUE: the canonical CSR in d_match_off / d_term -> every term once per document, first occurrences in order.
+// The result replaces d_match_off / d_term (positions: zeros in d_pos); *n_matches = new total.
+int unique_pipeline(gft_engine* e, uint64_t n_docs, uint64_t* n_matches) {
+    if (!n_docs) return GFT_OK;
+    hipStream_t st = e->stream;
+    const uint32_t n_terms = std::max<uint32_t>((uint32_t)e->tab.terms.size(), 1);
+    // as many workgroups as 256 MB of first-occurrence rows allow, at most 4 per CU
+    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(n_docs, (uint64_t)e->n_cus * 4), (256ull << 20) / ((uint64_t)n_terms * 4)));
+    HIP_TRY(e->d_uq_first.ensure((size_t)grid * n_terms * 4), "unique alloc");
+    HIP_TRY(e->d_uq_cnt.ensure(n_docs * 4), "unique alloc");
+    HIP_TRY(e->d_uq_off.ensure((n_docs + 1) * 8), "unique alloc");
+    HIP_TRY(e->d_partial.ensure(scan_partials_needed(n_docs) * 8), "unique alloc");
+    HIP_TRY(hipMemsetAsync(e->d_uq_first.p, 0xFF, (size_t)grid * n_terms * 4, st), "memset");
+    ProfScope ps(e, "aux");
+    HIP_TRY(launch_unique_terms(false, e->d_match_off.as<uint64_t>(), e->d_term.as<uint32_t>(), n_docs, n_terms, e->d_uq_first.as<uint32_t>(), grid,
+                                e->d_uq_cnt.as<uint32_t>(), nullptr, nullptr, st), "unique count");
+    HIP_TRY(launch_exclusive_scan(e->d_uq_cnt.as<uint32_t>(), n_docs, e->d_uq_off.as<uint64_t>(), e->d_partial.as<uint64_t>(), st), "unique scan");
+    uint64_t total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, e->d_uq_off.as<uint64_t>() + n_docs, 8, hipMemcpyDeviceToHost, st), "readback");
+    HIP_TRY(hipStreamSynchronize(st), "unique scan");
+    HIP_TRY(e->d_uq_term.ensure(std::max<uint64_t>(total, 1) * 4), "unique alloc");
+    HIP_TRY(launch_unique_terms(true, e->d_match_off.as<uint64_t>(), e->d_term.as<uint32_t>(), n_docs, n_terms, e->d_uq_first.as<uint32_t>(), grid,
+                                nullptr, e->d_uq_off.as<uint64_t>(), e->d_uq_term.as<uint32_t>(), st), "unique write");
+    // the caller-visible buffers: offsets and terms are swapped in, positions are all zero (substringEngine.go:83)
+    std::swap(e->d_match_off, e->d_uq_off);
+    std::swap(e->d_term, e->d_uq_term);
+    HIP_TRY(e->d_pos.ensure(std::max<uint64_t>(total, 1) * 4), "unique alloc");
+    HIP_TRY(hipMemsetAsync(e->d_pos.p, 0, std::max<uint64_t>(total, 1) * 4, st), "memset");
+    *n_matches = total;
+    return GFT_OK;
+}
+
 int solve_pipeline(gft_engine* e, uint64_t n_docs, const gft_extra_matches* d_extra, uint32_t* d_bitmap) {
     if (!n_docs || !e->n_exprs) return GFT_OK;
     SolveParams S;
@@ -777,7 +810,7 @@ void gft_engine_destroy(gft_engine* e) {
 &e->d_unit_cnt, &e->d_unit_base, &e->d_units, &e->d_partial,
                          &e->d_pool_term, &e->d_pool_pos, &e->d_unit_start, &e->d_unit_count, &e->d_unit_out,
                          &e->d_term, &e->d_pos, &e->d_match_off, &e->d_text, &e->d_doc_off, &e->d_bitmap, &e->d_xoff,
-                         &e->d_xslot, &e->d_xpos};
+                         &e->d_xslot, &e->d_xpos, &e->d_uq_first, &e->d_uq_cnt, &e->d_uq_off, &e->d_uq_term};
         for (DevBuf* b : all) b->release();
         for (int k = 0; k < 2; k++) {
             if (e->pin[k]) (void)hipHostFree(e->pin[k]);
@@ -1021,6 +1054,7 @@ int gft_scan_device(gft_engine* e, const uint8_t* d_text_blob, const uint64_t* d
     uint64_t nm = 0;
     int rc = scan_pipeline(e, d_text_blob, d_doc_off, n_docs, flags, true, &nm);
     if (rc) return rc;
+    if ((flags & GFT_SCAN_UNIQUE) && (rc = unique_pipeline(e, n_docs, &nm))) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream), "scan pipeline");
     out_dev->n_docs = n_docs; out_dev->n_matches = nm;
     out_dev->match_off = e->d_match_off.as<uint64_t>();
@@ -1082,6 +1116,7 @@ int gft_scan(gft_engine* e, const uint8_t* text_blob, const uint64_t* doc_off, u
     uint64_t nm = 0;
     rc = scan_pipeline(e, e->d_text.as<uint8_t>(), e->d_doc_off.as<uint64_t>(), n_docs, flags, true, &nm, doc_off);
     if (rc) return rc;
+    if ((flags & GFT_SCAN_UNIQUE) && (rc = unique_pipeline(e, n_docs, &nm))) return rc;
     e->h_match_off.assign(n_docs + 1, 0);
     e->h_term.assign(nm, 0);
     e->h_pos.assign(nm, 0);

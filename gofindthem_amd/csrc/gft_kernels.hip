@@ -410,6 +410,46 @@ __global__ void __launch_bounds__(256) k_match_off(const uint64_t* __restrict__ 
     if (d <= n_docs) match_off[d] = unit_out[unit_base[d]];
 }
 
+// ---- unique terms per document (CloudflareEngine.FindSubstrings, finder/substringEngine.go:77-86: every term once, in
+// the order of its first occurrence, Position 0).  One workgroup per document at a time; first[t] = index of the first
+// match of term t (a row of n_terms words per workgroup, all ones between documents).  Pass 1 counts, pass 2 writes.
+template <bool WRITE>
+__global__ void __launch_bounds__(256) k_unique_terms(const uint64_t* __restrict__ match_off, const uint32_t* __restrict__ term,
+                                                      uint64_t n_docs, uint32_t n_terms, uint32_t* __restrict__ first_all,
+                                                      uint32_t* __restrict__ cnt, const uint64_t* __restrict__ out_off,
+                                                      uint32_t* __restrict__ out_term) {
+    uint32_t* first = first_all + (size_t)blockIdx.x * n_terms;
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t run;
+    for (uint64_t d = blockIdx.x; d < n_docs; d += gridDim.x) {
+        const uint64_t a = match_off[d], b = match_off[d + 1];
+        for (uint64_t i = a + threadIdx.x; i < b; i += blockDim.x) atomicMin(&first[term[i]], (uint32_t)(i - a));
+        __syncthreads();
+        if (threadIdx.x == 0) run = 0;
+        __syncthreads();
+        // in order, 256 matches per round: a match stays if it is the first of its term
+        uint32_t total = 0;
+        for (uint64_t i0 = a; i0 < b; i0 += blockDim.x) {
+            const uint64_t i = i0 + threadIdx.x;
+            const bool keep = i < b && first[term[i]] == (uint32_t)(i - a);
+            const uint64_t m = __ballot(keep);
+            const uint32_t w = threadIdx.x >> 6, l = threadIdx.x & 63;
+            if (l == 0) wsum[w] = (uint32_t)__popcll(m);
+            __syncthreads();
+            uint32_t before = run;
+            for (uint32_t k = 0; k < w; k++) before += wsum[k];
+            if (WRITE && keep) out_term[out_off[d] + before + (uint32_t)__popcll(m & ((1ull << l) - 1))] = term[i];
+            total = run + wsum[0] + wsum[1] + wsum[2] + wsum[3];
+            __syncthreads();
+            if (threadIdx.x == 0) run = total;
+            __syncthreads();
+        }
+        if (!WRITE && threadIdx.x == 0) cnt[d] = total;
+        for (uint64_t i = a + threadIdx.x; i < b; i += blockDim.x) first[term[i]] = 0xFFFFFFFFu;
+        __syncthreads();
+    }
+}
+
 inline unsigned grid_for(uint64_t n, unsigned per_block, unsigned cap) {
     uint64_t g = (n + per_block - 1) / per_block;
     if (g < 1) g = 1;
@@ -491,6 +531,15 @@ hipError_t launch_gather(const uint64_t* d_unit_start, const uint32_t* d_unit_co
     else if (n_units)
         k_gather<<<dim3(grid_for(n_units, 4, n_cus * 16)), dim3(256), 0, st>>>(
             d_unit_start, d_unit_count, d_unit_out, n_units, d_pool_term, d_pool_pos, d_term, d_pos);
+    return hipGetLastError();
+}
+
+hipError_t launch_unique_terms(bool write, const uint64_t* d_match_off, const uint32_t* d_term, uint64_t n_docs, uint32_t n_terms,
+                               uint32_t* d_first, unsigned grid, uint32_t* d_cnt, const uint64_t* d_out_off, uint32_t* d_out_term,
+                               hipStream_t st) {
+    if (!n_docs) return hipSuccess;
+    if (write) k_unique_terms<true><<<dim3(grid), dim3(256), 0, st>>>(d_match_off, d_term, n_docs, n_terms, d_first, d_cnt, d_out_off, d_out_term);
+    else k_unique_terms<false><<<dim3(grid), dim3(256), 0, st>>>(d_match_off, d_term, n_docs, n_terms, d_first, d_cnt, d_out_off, d_out_term);
     return hipGetLastError();
 }
 

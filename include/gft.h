@@ -47,6 +47,10 @@ typedef enum gft_status {
                            * strings.ToLower only while the text is ASCII: the kernels notice bytes >= 0x80 on their way
                            * (gft_last_nonascii), and the finder entry points then fold such a batch on the host instead */
 
+#define GFT_SCAN_UNIQUE 2u /* gft_scan / gft_scan_device: CloudflareEngine's output instead of CloudflareForkEngine's
+                            * (finder/substringEngine.go:77-86): every term that occurs in a document once, in the order
+                            * of its first occurrence, every pos 0 -- enough for expressions without INORD */
+
 typedef struct gft_engine gft_engine;
 
 /* ---- lifetime ------------------------------------------------------------------------------------- */

@@ -8,6 +8,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+try:
+    # torch brings its own HIP runtime: it has to be in the process before libgft.so binds to one, or the GPU tests that
+    # hand torch tensors to the library would end up with two runtimes ("No HIP GPUs are available")
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 

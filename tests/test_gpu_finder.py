@@ -317,3 +317,29 @@ def test_process_device_one_read_back_per_batch_and_regrowth():
     dense = " ".join(t.decode() for t in terms[:200]) * 30
     run([dense, dense[:5000], docs[7]])  # far more matches per byte than the pool was sized for
     run(docs[:50])
+
+
+def test_keyword_and_regex_with_the_same_literal_known_deviation():
+    """The one documented difference from the reference.  A keyword "aa" and a regex r"aa" feed ONE map key
+    in the reference (finder/finder.go:181-196): its list is the keyword positions followed by the regex positions,
+    [2 3 4 5] ++ [2 4] for the text below -- not sorted, so getLowestIdxGTVal's binary search (dsl/expression.go:175-189)
+    can miss an element that is there: inord("aaay" and "aa") asks for a position > 4 and the reference answers none.
+    The device solver keeps one sorted position set per slot and finds 5.  Only INORD over such a pair can differ; truth
+    values of everything else (here: the plain regex and keyword expressions) are the reference's."""
+    exprs = ['inord("aaay" and "aa")', 'r"aa"', '"aa" and "aaay"', 'inord("aa" and "aaay")']
+    text = "xxaaaaay"
+    f = Finder(GpuEngine(), PyRegexpEngine(), True)
+    f.AddExpressions(exprs)
+    got = [r.ExpresionIndex for r in f.ProcessText(text)]
+    blob, off = pack_strings([text])
+    want_bm, _ = _oracle_with_regex(f, exprs, blob, off, 1)
+    want = [i for i in range(len(exprs)) if want_bm[0, 0] >> i & 1]
+    assert want == [1, 2, 3]            # the reference: expression 0 is false (binary search over [2 3 4 5 2 4] misses 5)
+    assert got == [0, 1, 2, 3]          # the device: 5 > 4 is found
+    # without the regex twin the two agree again
+    f2 = Finder(GpuEngine(), PyRegexpEngine(), True)
+    f2.AddExpressions(exprs[:1] + exprs[2:])
+    o = Oracle(sorted(f2.GetKeywords()))
+    o.set_expressions(exprs[:1] + exprs[2:], True)
+    assert [r.ExpresionIndex for r in f2.ProcessText(text)] == [0, 1, 2]
+    assert o.process(blob, off)[0, 0] == 0b111

@@ -1,6 +1,7 @@
 """GPU parity: the HIP path (through the C ABI of libgft.so) against the CPU oracle, bit-exact."""
 import numpy as np
 import pytest
+import torch  # noqa: F401  (before libgft.so is loaded: both must share ONE HIP runtime, the one torch brings along)
 
 from helpers import assert_csr_equal, docs, tree_to_program
 from oracle import dsl_ref
@@ -340,3 +341,31 @@ def test_descending_offsets_are_refused_on_the_device_unit_path(eng):
     with pytest.raises(GftError):
         eng.scan(blob, bad)
     assert_csr_equal(eng.scan(blob, off), Oracle([b"ab", b"abc"], POS_START).scan(blob, off))
+
+
+def test_unique_terms_mode_is_the_cloudflare_engine_output(eng):
+    """GFT_SCAN_UNIQUE = CloudflareEngine.FindSubstrings (finder/substringEngine.go:77-86): Matcher.Match reports every
+    dictionary term that occurs in the text once, Position 0.  Expected from the oracle's full match list: first
+    occurrences in emission order."""
+    from gofindthem_amd.workload import Workload
+    o = both(eng, ["he", "she", "his", "hers"])
+    blob, off = docs(["ushers", "", "hishishershe", "xx"])
+    mo, ti, po = eng.scan(blob, off, unique=True)
+    assert mo.tolist() == [0, 3, 3, 7, 7] and not po.any()
+    assert ti.tolist() == [3, 0, 1, 2, 3, 0, 1]          # she he hers | his she he hers (ids: he 0, hers 1, his 2, she 3)
+    w = Workload(3000)
+    o = both(eng, w.terms())
+    text, toff = w.docs_host(0, 700)
+    mo, ti, po = eng.scan(text, toff, fold=True, unique=True)
+    wo, wt, _ = o.scan(text, toff, fold=True)
+    assert not po.any()
+    for d in range(700):
+        full = wt[int(wo[d]):int(wo[d + 1])].tolist()
+        first = list(dict.fromkeys(full))
+        assert ti[int(mo[d]):int(mo[d + 1])].tolist() == first, d
+    # device-resident variant
+    import torch
+    t = torch.from_numpy(np.concatenate([text, np.zeros(64, np.uint8)])).cuda()
+    oo = torch.from_numpy(toff.astype(np.int64)).cuda()
+    m = eng.scan_device(t.data_ptr(), oo.data_ptr(), 700, fold=True, unique=True)
+    assert int(m.n_matches) == int(mo[-1])

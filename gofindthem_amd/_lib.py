@@ -28,6 +28,11 @@ _vp, _u32, _u64, _i = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
 SYMBOLS = {
     "gft_engine_create": (_i, [C.POINTER(_vp), _i]),
     "gft_engine_destroy": (None, [_vp]),
+    "gft_engine_create_multi": (_i, [C.POINTER(_vp), _vp, _i]),
+    "gft_n_devices": (_i, [_vp]),
+    "gft_device_engine": (_vp, [_vp, _i]),
+    "gft_split_docs": (_i, [_vp, _vp, _u64, _vp]),
+    "gft_process_device_multi": (_i, [_vp, _vp, _vp, _vp, _u32, _vp]),
     "gft_last_error": (C.c_char_p, [_vp]),
     "gft_set_stream": (_i, [_vp, _vp]),
     "gft_build": (_i, [_vp, _vp, _vp, _u32, _u32]),
@@ -36,6 +41,7 @@ SYMBOLS = {
     "gft_n_terms": (_u32, [_vp]),
     "gft_n_states": (_u32, [_vp]),
     "gft_last_nonascii": (_i, [_vp]),
+    "gft_scan_kernel": (C.c_char_p, [_vp]),
     "gft_term": (_i, [_vp, _u32, C.POINTER(_vp), C.POINTER(_u32)]),
     "gft_term_id": (C.c_int64, [_vp, _vp, _u32]),
     "gft_scan": (_i, [_vp, _vp, _vp, _u64, _u32, C.POINTER(GftMatches)]),
@@ -46,6 +52,7 @@ SYMBOLS = {
     "gft_process_again": (_i, [_vp, _u64, C.POINTER(GftExtra), _vp]),
     "gft_process_device": (_i, [_vp, _vp, _vp, _u64, _u32, C.POINTER(GftExtra), _vp]),
     "gft_finder_create": (_i, [C.POINTER(_vp), _i, _i]),
+    "gft_finder_create_multi": (_i, [C.POINTER(_vp), _i, _vp, _i]),
     "gft_finder_destroy": (None, [_vp]),
     "gft_finder_last_error": (C.c_char_p, [_vp]),
     "gft_finder_engine": (_vp, [_vp]),

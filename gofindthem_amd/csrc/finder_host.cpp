@@ -32,6 +32,13 @@ GpuEngine::GpuEngine(int device) {
         if (h_) { gft_engine_destroy(h_); h_ = nullptr; }
     }
 }
+GpuEngine::GpuEngine(const int* devices, int n_devices) {
+    int rc = gft_engine_create_multi(&h_, devices, n_devices);
+    if (rc != GFT_OK) {
+        create_err_ = h_ ? gft_last_error(h_) : "gft_engine_create_multi failed";
+        if (h_) { gft_engine_destroy(h_); h_ = nullptr; }
+    }
+}
 GpuEngine::~GpuEngine() { if (h_) gft_engine_destroy(h_); }
 
 Error GpuEngine::BuildEngine(const std::vector<std::string>& keywords, bool) {
@@ -484,6 +491,18 @@ int gft_finder_create(gft_finder** out, int case_sensitive, int device) {
     gft_finder* f = new gft_finder();
     f->case_sensitive = case_sensitive != 0;
     f->gpu.reset(new GpuEngine(device));
+    f->rgx.reset(new EmptyRgxEngine());
+    f->finder.reset(new Finder(f->gpu.get(), f->rgx.get(), f->case_sensitive, f->gpu.get()));
+    *out = f;
+    if (!f->gpu->handle()) { f->err = f->gpu->create_error(); return GFT_E_HIP; }
+    return GFT_OK;
+}
+
+int gft_finder_create_multi(gft_finder** out, int case_sensitive, const int* devices, int n_devices) {
+    if (!out || n_devices < 0 || (n_devices && !devices)) return GFT_E_INVALID;
+    gft_finder* f = new gft_finder();
+    f->case_sensitive = case_sensitive != 0;
+    f->gpu.reset(new GpuEngine(devices, n_devices));
     f->rgx.reset(new EmptyRgxEngine());
     f->finder.reset(new Finder(f->gpu.get(), f->rgx.get(), f->case_sensitive, f->gpu.get()));
     *out = f;

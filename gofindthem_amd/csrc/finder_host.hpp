@@ -61,6 +61,8 @@ public:
 class GpuEngine : public SubstringEngine {
 public:
     explicit GpuEngine(int device = -1);
+    // one engine over several devices (gft_engine_create_multi): batches are sharded across them by the library
+    GpuEngine(const int* devices, int n_devices);
     ~GpuEngine() override;
     Error BuildEngine(const std::vector<std::string>& keywords, bool caseSensitive) override;
     Error FindSubstrings(const std::string& text, std::vector<Match>& matches) override;

@@ -87,7 +87,9 @@ struct gft_engine {
     // a scan launched without knowing the unit count / pool need (gft_process*: one read-back per batch, after the solver)
     bool deferred = false;
     uint64_t deferred_unit_cap = 0;
-    bool last_nonascii = false;                         // the last GFT_FOLD_ASCII scan saw a byte >= 0x80 (gft_last_nonascii)
+    bool last_nonascii = false;                         // the last GFT_FOLD_ASCII scan ran over text that ASCII folding does not
+                                                        // lower-case the way strings.ToLower does (gft_last_nonascii)
+    uint64_t last_text_lo = 0, last_text_hi = 0;        // text range of the last scan
     // Environment switches (cross-checks and timing studies) are read when the handle is created and again
     // by gft_build / gft_import_tables / gft_set_programs -- never on the per-batch path
     uint32_t opt_scan_dbg = 0;                          // GFT_SCAN_DEBUG (timing studies)
@@ -97,6 +99,14 @@ struct gft_engine {
     int opt_solve_group = -1;                           // GFT_SOLVE_GROUP_DOCS: forced group width (-1: the widest that fits)
     // one caller at a time per handle: every entry point that touches the device state takes this
     mutable std::recursive_mutex mu;
+    // multi-device handle (gft_engine_create_multi): this engine serves devices[0], `peers` the others.  Tables and
+    // programs are replicated, a batch is cut into contiguous document ranges of near-equal text bytes, every device
+    // has its own host thread and stream for the duration of a call
+    std::vector<gft_engine*> peers;
+    std::vector<uint64_t> shard_cut;                     // document cuts of the last multi-device gft_process
+    bool in_multi = false;                               // set while a multi-device call runs this engine's own share
+    std::vector<void*> comms;                            // RCCL communicators (ncclCommInitAll), one per device; empty: none
+    void* rccl_lib = nullptr;
 
     // programs
     bool have_programs = false;
@@ -421,6 +431,7 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         }
     }
 
+    if (!e->deferred) { e->last_text_lo = text_lo; e->last_text_hi = text_hi; }
     HIP_TRY(e->d_units.ensure(n_units * sizeof(Unit)), "unit alloc");
     HIP_TRY(e->d_unit_start.ensure(n_units * 8), "unit alloc");
     HIP_TRY(e->d_unit_count.ensure(n_units * 4), "unit alloc");
@@ -633,6 +644,7 @@ int deferred_check(gft_engine* e, bool* again) {
     HIP_TRY(hipStreamSynchronize(e->stream), "process pipeline");
     const uint64_t cursor = rb[1], total = rb[2], n_units = rb[4], text_lo = rb[5], text_hi = rb[6];
     e->last_nonascii = (uint32_t)rb[3] != 0;
+    e->last_text_lo = text_lo; e->last_text_hi = text_hi;
     if (text_hi < text_lo) return fail(e, GFT_E_INVALID, "doc_off is not ascending");
     if ((uint32_t)rb[0]) return fail(e, GFT_E_INVALID, "doc_off is not ascending, or a document is longer than 4 GiB - 1 bytes (positions are 32-bit)");
     // (the DFA kernel's cursor counts matches, the suffix-window kernels' slabs: both must fit the pool)
@@ -648,6 +660,22 @@ int deferred_check(gft_engine* e, bool* again) {
         const uint32_t um = want >= kScan2UnitMax ? kScan2UnitMax : (uint32_t)want & ~255u;
         e->scan2_unit_max = std::max<uint32_t>(512, um);
     }
+    return GFT_OK;
+}
+
+// A folded scan that met bytes >= 0x80: is ASCII folding still the whole of strings.ToLower for this text (k_fold_safe)?
+// One more pass over the text and one more read-back, for such batches only.
+int refine_nonascii(gft_engine* e, const uint8_t* d_text, uint32_t flags) {
+    if (!(flags & GFT_FOLD_ASCII)) { e->last_nonascii = false; return GFT_OK; }
+    if (!e->last_nonascii) return GFT_OK;
+    uint32_t flag = 0;
+    {
+        ProfScope ps(e, "aux");
+        HIP_TRY(launch_fold_safe(d_text, e->last_text_lo, e->last_text_hi, e->d_ctl.as<uint32_t>() + 6, e->stream), "fold check");
+    }
+    HIP_TRY(hipMemcpyAsync(&flag, e->d_ctl.as<uint32_t>() + 6, 4, hipMemcpyDeviceToHost, e->stream), "readback");
+    HIP_TRY(hipStreamSynchronize(e->stream), "fold check");
+    e->last_nonascii = (flag & 2u) != 0;
     return GFT_OK;
 }
 
@@ -735,7 +763,7 @@ int solve_pipeline(gft_engine* e, uint64_t n_docs, const gft_extra_matches* d_ex
 // ---- compiled tables as one blob (BuildEngine for a large dictionary is paid once) -----------------
 namespace {
 constexpr uint32_t kTablesMagic = 0x54544647u;   // "GFTT"
-constexpr uint32_t kTablesVersion = 6;           // bump when a table layout or a hash function changes
+constexpr uint32_t kTablesVersion = 7;           // bump when a table layout or a hash function changes
 
 struct Writer {
     std::vector<uint8_t> b;
@@ -756,6 +784,84 @@ struct Reader {
         if (k) raw(v.data(), (size_t)k * sizeof(T));
     }
 };
+// Every index a kernel follows must stay inside the table it indexes: a blob that passes the checksum may still be stale
+// (another library build) or crafted.  Returns what is wrong, or nullptr.
+const char* validate_tables(const AcTables& a, const Scan2Tables& t, const Scan3Tables& u) {
+    const size_t n_terms = a.terms.size();
+    if (a.n_classes == 0 || a.n_classes > 256) return "class count";
+    for (int b = 0; b < 256; b++) if (a.byte_class[b] >= a.n_classes) return "byte class";
+    for (uint32_t d : a.delta) if ((d & ~kOutFlag) >= a.n_states) return "DFA target";
+    for (uint32_t x : a.out_term) if (x != kNoTerm && x >= n_terms) return "DFA output term";
+    for (uint32_t x : a.out_link) if (x >= a.n_states) return "DFA output link";
+    for (size_t i = 0; i < n_terms; i++) if (a.term_len[i] != a.terms[i].size()) return "term length";
+    auto slots_ok = [&](const std::vector<Scan2Slot>& slots, const std::vector<Scan2Slot>& more, uint32_t shift, const std::vector<uint8_t>& blob,
+                        const std::vector<uint32_t>& off) -> const char* {
+        if (shift < 1 || shift > 31 || slots.size() != ((size_t)1 << (32 - shift))) return "bucket table size";
+        if (off.size() != n_terms + 1) return "term offsets";
+        for (size_t i = 0; i < n_terms; i++)
+            if (off[i] < 4 || (uint64_t)off[i] + a.terms[i].size() + 8 > blob.size()) return "term offset";
+        auto entry_ok = [&](const Scan2Slot& s) {
+            const uint32_t len1 = s.len & kScan2LenMask;
+            const int off8 = (int)(int8_t)(s.len >> 24);
+            return s.info < n_terms && off8 >= -1 && off8 <= (int)kScan2MaxOff && (int64_t)len1 + off8 == (int64_t)a.terms[s.info].size() && len1 >= 4;
+        };
+        for (const Scan2Slot& s : slots) {
+            if (s.key == kScan2EmptyKey) continue;
+            if (s.info & kScan2Multi) {
+                const uint64_t at = s.info & ~kScan2Multi;
+                if (at + s.len > more.size() || s.len == 0) return "bucket list";
+            } else if (!entry_ok(s)) return "bucket entry";
+        }
+        for (const Scan2Slot& s : more) if (s.key != kScan2EmptyKey && !entry_ok(s)) return "bucket list entry";
+        return nullptr;
+    };
+    if (t.supported) {
+        if (t.kp == 0 || t.kp > 256 || t.pad_class >= t.kp) return "scan2 classes";
+        for (int b = 0; b < 256; b++) if (t.cls[b] >= t.kp || t.cls_fold[b] >= t.kp) return "scan2 byte class";
+        if (t.hashed ? (t.hash_shift < 1 || t.hash_shift > 31 || t.filter_bits != (1u << (32 - t.hash_shift)))
+                     : (uint64_t)t.kp * t.kp * t.kp * t.kp > t.filter_bits) return "scan2 filter size";
+        if (!t.short3.empty() && t.short3.size() < (uint64_t)t.kp * t.kp * t.kp) return "scan2 short3 size";
+        if (!t.short3_big.empty() && t.short3_big.size() != t.short3.size()) return "scan2 short3_big size";
+        if (t.shorts_packed.size() != t.shorts.size() * 3) return "scan2 short records";
+        for (uint8_t id : t.short3) if (id != 255 && id >= t.shorts.size()) return "scan2 short record id";
+        for (uint32_t id : t.short3_big) if (id >= t.shorts.size()) return "scan2 short record id";
+        for (uint32_t w : t.shorts_packed) if (w && ((w & 0x0FFFFFFFu) >= n_terms || (w >> 28) > 3)) return "scan2 short record";
+        if (const char* why = slots_ok(t.slots, t.more, t.slot_shift, t.term_blob, t.term_off)) return why;
+    }
+    if (u.supported) {
+        if (u.G == 0 || u.G > kScan3Groups) return "scan3 groups";
+        const uint64_t G3 = (uint64_t)u.G * u.G * u.G;
+        for (int b = 0; b < 256; b++) if (u.cls[b] >= u.G || u.cls_fold[b] >= u.G) return "scan3 byte group";
+        if (u.filter.size() != (size_t)((G3 * u.G + 31) / 32)) return "scan3 filter size";
+        if (!u.short3.empty() && (u.short3.size() < G3 || u.short3.size() % 16)) return "scan3 short3 size";
+        if (!u.short3_big.empty() && u.short3_big.size() != u.short3.size()) return "scan3 short3_big size";
+        if (u.srec.size() % kScan3RecWords || u.srec.empty() || u.srec.size() / kScan3RecWords > kScan3RecLds + 1) return "scan3 records";
+        for (uint8_t id : u.short3) if (id != 255 && id >= u.srec.size() / kScan3RecWords) return "scan3 record id";
+        for (size_t i = 0; i < u.short3.size(); i++) if (u.short3[i] == 255 && (u.short3_big.empty() || u.short3_big[i] >= u.srec_big.size())) return "scan3 big record";
+        for (size_t i = 0; i < u.srec.size(); i += 2) if (u.srec[i] && ((u.srec[i] & 0x0FFFFFFFu) >= n_terms || (u.srec[i] >> 28) > 3)) return "scan3 record entry";
+        for (size_t at = 0; at < u.srec_big.size();) {
+            const uint64_t n = u.srec_big[at];
+            if (at + 1 + 2 * n > u.srec_big.size()) return "scan3 big record length";
+            for (uint64_t j = 0; j < n; j++) { const uint32_t w = u.srec_big[at + 1 + 2 * j]; if (w && ((w & 0x0FFFFFFFu) >= n_terms || (w >> 28) > 3)) return "scan3 big record entry"; }
+            at += 1 + 2 * n;
+        }
+        if (u.bloom_lg < 1 || u.bloom_lg > 28 || u.bloom.size() != ((size_t)1 << u.bloom_lg)) return "scan3 bloom size";
+        if (const char* why = slots_ok(u.slots, u.more, u.slot_shift, u.term_blob, u.term_off)) return why;
+    }
+    return nullptr;
+}
+
+
+void destroy_multi(gft_engine* e);
+// multi-device dispatch (definitions behind the single-device entry points)
+int multi_process(gft_engine* e, const uint8_t* text_blob, const uint64_t* doc_off, uint64_t n_docs, uint32_t flags,
+                  const gft_extra_matches* extra, uint32_t* hit_bitmap);
+int multi_process_again(gft_engine* e, uint64_t n_docs, const gft_extra_matches* extra, uint32_t* hit_bitmap);
+int multi_scan(gft_engine* e, const uint8_t* text_blob, const uint64_t* doc_off, uint64_t n_docs, uint32_t flags, gft_matches* out);
+int multi_set_programs(gft_engine* e, const uint32_t* prog_words, const uint64_t* prog_off, uint32_t n_exprs, uint32_t n_extra);
+int multi_build(gft_engine* e, const uint8_t* terms_blob, const uint64_t* term_off, uint32_t n_terms, uint32_t flags);
+int multi_import_tables(gft_engine* e, const uint8_t* blob, uint64_t len);
+
 }  // namespace
 
 
@@ -796,6 +902,7 @@ int gft_engine_create(gft_engine** out, int device) {
 
 void gft_engine_destroy(gft_engine* e) {
     if (!e) return;
+    destroy_multi(e);
     if (e->device >= 0) {
         DeviceGuard g(e->device);
         if (e->stream) (void)hipStreamSynchronize(e->stream);
@@ -936,6 +1043,7 @@ static int install_tables(gft_engine* e, uint32_t flags) {
 int gft_build(gft_engine* e, const uint8_t* terms_blob, const uint64_t* term_off, uint32_t n_terms, uint32_t flags) {
     if (!e || (n_terms && (!terms_blob || !term_off))) return e ? fail(e, GFT_E_INVALID, "null argument") : GFT_E_INVALID;
     GFT_LOCK(e);
+    if (!e->peers.empty() && !e->in_multi) return multi_build(e, terms_blob, term_off, n_terms, flags);
     if (e->device < 0) return fail(e, GFT_E_HIP, "no HIP device available");
     std::vector<std::string> terms;
     terms.reserve(n_terms);
@@ -954,6 +1062,10 @@ uint32_t gft_n_terms(const gft_engine* e) { return e ? (uint32_t)e->tab.terms.si
 uint32_t gft_n_states(const gft_engine* e) { return e ? e->tab.n_states : 0; }
 uint32_t gft_n_exprs(const gft_engine* e) { return e ? e->n_exprs : 0; }
 int gft_last_nonascii(const gft_engine* e) { return e && e->last_nonascii ? 1 : 0; }
+const char* gft_scan_kernel(const gft_engine* e) {
+    if (!e || !e->built) return "";
+    return e->use_scan3 ? "scan3" : e->use_scan2 ? "scan2" : "dfa";
+}
 
 int gft_term(const gft_engine* e, uint32_t term_id, const uint8_t** ptr, uint32_t* len) {
     if (!e || !ptr || !len) return GFT_E_INVALID;
@@ -989,6 +1101,11 @@ int gft_export_tables(const gft_engine* e, uint8_t* out, uint64_t cap, uint64_t*
     w.vec(t.filter); w.vec(t.short3); w.vec(t.shorts); w.vec(t.short3_big); w.vec(t.shorts_packed); w.u32(t.fpt_lg); w.vec(t.fpt);
     w.u32(t.slot_shift); w.u32(t.slot_seed); w.vec(t.slots); w.vec(t.more);
     w.raw(t.cls, 256); w.raw(t.cls_fold, 256); w.vec(t.term_blob); w.vec(t.term_off); w.u64(t.n_keys);
+    const Scan3Tables& u = e->s3;
+    w.u32(u.supported ? 1 : 0); w.u32(u.G); w.u32(u.grouped ? 1 : 0); w.raw(u.cls, 256); w.raw(u.cls_fold, 256);
+    w.vec(u.filter); w.vec(u.short3); w.vec(u.srec); w.vec(u.short3_big); w.vec(u.srec_big); w.u32(u.bloom_lg); w.vec(u.bloom);
+    w.u32(u.slot_shift); w.u32(u.slot_seed); w.vec(u.slots); w.vec(u.more); w.vec(u.term_blob); w.vec(u.term_off);
+    w.u64(u.n_keys); w.u64(u.n_anchors);
     uint64_t sum = 1469598103934665603ull;          // FNV-1a over everything before it
     for (uint8_t c : w.b) { sum ^= c; sum *= 1099511628211ull; }
     w.u64(sum);
@@ -1001,6 +1118,7 @@ int gft_export_tables(const gft_engine* e, uint8_t* out, uint64_t cap, uint64_t*
 int gft_import_tables(gft_engine* e, const uint8_t* blob, uint64_t len) {
     if (!e || !blob) return e ? fail(e, GFT_E_INVALID, "null argument") : GFT_E_INVALID;
     GFT_LOCK(e);
+    if (!e->peers.empty() && !e->in_multi) return multi_import_tables(e, blob, len);
     if (len < 28) return fail(e, GFT_E_INVALID, "table blob too short");
     uint64_t sum = 1469598103934665603ull, stored;
     for (uint64_t i = 0; i + 8 < len; i++) { sum ^= blob[i]; sum *= 1099511628211ull; }
@@ -1029,7 +1147,13 @@ int gft_import_tables(gft_engine* e, const uint8_t* blob, uint64_t len) {
     r.vec(t.filter); r.vec(t.short3); r.vec(t.shorts); r.vec(t.short3_big); r.vec(t.shorts_packed); t.fpt_lg = r.u32(); r.vec(t.fpt);
     t.slot_shift = r.u32(); t.slot_seed = r.u32(); r.vec(t.slots); r.vec(t.more);
     r.raw(t.cls, 256); r.raw(t.cls_fold, 256); r.vec(t.term_blob); r.vec(t.term_off); t.n_keys = r.u64();
+    Scan3Tables u;
+    u.supported = r.u32() != 0; u.G = r.u32(); u.grouped = r.u32() != 0; r.raw(u.cls, 256); r.raw(u.cls_fold, 256);
+    r.vec(u.filter); r.vec(u.short3); r.vec(u.srec); r.vec(u.short3_big); r.vec(u.srec_big); u.bloom_lg = r.u32(); r.vec(u.bloom);
+    u.slot_shift = r.u32(); u.slot_seed = r.u32(); r.vec(u.slots); r.vec(u.more); r.vec(u.term_blob); r.vec(u.term_off);
+    u.n_keys = r.u64(); u.n_anchors = r.u64();
     if (!r.ok || r.i != r.n) return fail(e, GFT_E_INVALID, "table blob is truncated");
+    if (const char* why = validate_tables(a, t, u)) return fail(e, GFT_E_INVALID, std::string("table blob is inconsistent: ") + why);
     // shape checks the kernels rely on
     if (a.n_classes == 0 || a.n_classes > 256 || a.delta.size() != (size_t)a.n_states * a.n_classes || a.out_term.size() != a.n_states ||
         a.out_link.size() != a.n_states || a.term_len.size() != a.terms.size() ||
@@ -1041,6 +1165,7 @@ int gft_import_tables(gft_engine* e, const uint8_t* blob, uint64_t len) {
     e->built = false;
     e->tab = std::move(a);
     e->s2 = std::move(t);
+    e->s3 = std::move(u);
     return install_tables(e, flags);
 }
 
@@ -1055,6 +1180,7 @@ int gft_scan_device(gft_engine* e, const uint8_t* d_text_blob, const uint64_t* d
     int rc = scan_pipeline(e, d_text_blob, d_doc_off, n_docs, flags, true, &nm);
     if (rc) return rc;
     if ((flags & GFT_SCAN_UNIQUE) && (rc = unique_pipeline(e, n_docs, &nm))) return rc;
+    if ((rc = refine_nonascii(e, d_text_blob, flags))) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream), "scan pipeline");
     out_dev->n_docs = n_docs; out_dev->n_matches = nm;
     out_dev->match_off = e->d_match_off.as<uint64_t>();
@@ -1108,6 +1234,7 @@ int gft_scan(gft_engine* e, const uint8_t* text_blob, const uint64_t* doc_off, u
              gft_matches* out) {
     if (!e || !out || (n_docs && (!doc_off))) return e ? fail(e, GFT_E_INVALID, "null argument") : GFT_E_INVALID;
     GFT_LOCK(e);
+    if (!e->peers.empty() && !e->in_multi) return multi_scan(e, text_blob, doc_off, n_docs, flags, out);
     if (e->device < 0) return fail(e, GFT_E_HIP, "no HIP device available");
     if (!e->built) return fail(e, GFT_E_NOT_BUILT, "gft_build has not been called");
     DeviceGuard g(e->device);
@@ -1117,6 +1244,7 @@ int gft_scan(gft_engine* e, const uint8_t* text_blob, const uint64_t* doc_off, u
     rc = scan_pipeline(e, e->d_text.as<uint8_t>(), e->d_doc_off.as<uint64_t>(), n_docs, flags, true, &nm, doc_off);
     if (rc) return rc;
     if ((flags & GFT_SCAN_UNIQUE) && (rc = unique_pipeline(e, n_docs, &nm))) return rc;
+    if ((rc = refine_nonascii(e, e->d_text.as<uint8_t>(), flags))) return rc;
     e->h_match_off.assign(n_docs + 1, 0);
     e->h_term.assign(nm, 0);
     e->h_pos.assign(nm, 0);
@@ -1135,6 +1263,7 @@ int gft_set_programs(gft_engine* e, const uint32_t* prog_words, const uint64_t* 
                      uint32_t n_extra) {
     if (!e || (n_exprs && (!prog_words || !prog_off))) return e ? fail(e, GFT_E_INVALID, "null argument") : GFT_E_INVALID;
     GFT_LOCK(e);
+    if (!e->peers.empty() && !e->in_multi) return multi_set_programs(e, prog_words, prog_off, n_exprs, n_extra);
     if (e->device < 0) return fail(e, GFT_E_HIP, "no HIP device available");
     if (!e->built) return fail(e, GFT_E_NOT_BUILT, "gft_build has not been called");
     const uint32_t n_slots = (uint32_t)e->tab.terms.size() + n_extra;
@@ -1249,10 +1378,10 @@ int gft_process_device(gft_engine* e, const uint8_t* d_text_blob, const uint64_t
         bool again = false;
         rc = deferred_check(e, &again);
         if (rc) return rc;
-        if (!again) return GFT_OK;
+        if (!again) return refine_nonascii(e, d_text_blob, flags);
     }
     HIP_TRY(hipStreamSynchronize(e->stream), "process pipeline");
-    return GFT_OK;
+    return refine_nonascii(e, d_text_blob, flags);
 }
 
 namespace {
@@ -1280,6 +1409,7 @@ int upload_extra(gft_engine* e, const gft_extra_matches* extra, uint64_t n_docs,
 int gft_process_again(gft_engine* e, uint64_t n_docs, const gft_extra_matches* extra, uint32_t* hit_bitmap) {
     if (!e) return GFT_E_INVALID;
     GFT_LOCK(e);
+    if (!e->peers.empty() && !e->in_multi) return multi_process_again(e, n_docs, extra, hit_bitmap);
     if (e->device < 0) return fail(e, GFT_E_HIP, "no HIP device available");
     if (!e->built || !e->have_programs) return fail(e, GFT_E_NOT_BUILT, "engine not ready");
     if (e->scan_valid_docs != n_docs || !n_docs) return fail(e, GFT_E_INVALID, "gft_process_again: no scan of these documents to reuse");
@@ -1303,6 +1433,7 @@ int gft_process(gft_engine* e, const uint8_t* text_blob, const uint64_t* doc_off
                 const gft_extra_matches* extra, uint32_t* hit_bitmap) {
     if (!e || (n_docs && !doc_off)) return e ? fail(e, GFT_E_INVALID, "null argument") : GFT_E_INVALID;
     GFT_LOCK(e);
+    if (!e->peers.empty() && !e->in_multi) return multi_process(e, text_blob, doc_off, n_docs, flags, extra, hit_bitmap);
     if (e->device < 0) return fail(e, GFT_E_HIP, "no HIP device available");
     if (!e->built) return fail(e, GFT_E_NOT_BUILT, "gft_build has not been called");
     if (!e->have_programs) return fail(e, GFT_E_NOT_BUILT, "gft_set_programs has not been called");
@@ -1321,6 +1452,7 @@ int gft_process(gft_engine* e, const uint8_t* text_blob, const uint64_t* doc_off
     e->scan_valid_docs = n_docs;          // gft_process_again may reuse this scan
     rc = solve_pipeline(e, n_docs, pdx, e->d_bitmap.as<uint32_t>());
     if (rc) return rc;
+    if ((rc = refine_nonascii(e, e->d_text.as<uint8_t>(), flags))) return rc;
     if (n_docs * words) {
         if (!hit_bitmap) return fail(e, GFT_E_INVALID, "null bitmap");
         HIP_TRY(hipMemcpyAsync(hit_bitmap, e->d_bitmap.p, n_docs * words * 4, hipMemcpyDeviceToHost, e->stream), "download");
@@ -1383,6 +1515,333 @@ int gft_profile_read(gft_engine* e, const char* name, double* total_ms, uint64_t
         *total_ms += ms;
     }
     *launches = it->second.ev.size();
+    return GFT_OK;
+}
+
+}  // extern "C"
+
+// =====================================================================================================================
+// Multi-device handles: one process, one host thread + stream per device, tables replicated,
+// contiguous document ranges of near-equal text bytes, and -- for device-resident shards -- one RCCL gather of the
+// bitmaps to the first device.  The Go side keeps calling finder.NewFinder(&GpuEngine{...}): the
+// fan-out lives behind the same gft_engine handle.
+// =====================================================================================================================
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+namespace {
+
+// RCCL is bound at run time (dlopen): libgft.so itself does not depend on it, and a process that already carries a
+// copy (PyTorch does) shares that one
+struct RcclApi {
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    void* lib = nullptr;
+    bool ok() const { return CommInitAll && CommDestroy && GroupStart && GroupEnd && Send && Recv && GetErrorString; }
+};
+RcclApi& rccl_api() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char* name : {"librccl.so.1", "librccl.so"}) {
+            api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (api.lib) break;
+        }
+        if (!api.lib) return;
+        api.CommInitAll = (decltype(api.CommInitAll))dlsym(api.lib, "ncclCommInitAll");
+        api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
+        api.GroupStart = (decltype(api.GroupStart))dlsym(api.lib, "ncclGroupStart");
+        api.GroupEnd = (decltype(api.GroupEnd))dlsym(api.lib, "ncclGroupEnd");
+        api.Send = (decltype(api.Send))dlsym(api.lib, "ncclSend");
+        api.Recv = (decltype(api.Recv))dlsym(api.lib, "ncclRecv");
+        api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
+    });
+    return api;
+}
+
+std::vector<gft_engine*> all_engines(gft_engine* e) {
+    std::vector<gft_engine*> v{e};
+    v.insert(v.end(), e->peers.begin(), e->peers.end());
+    return v;
+}
+
+// contiguous document ranges of near-equal text bytes: device i owns documents [cut[i], cut[i+1])
+void split_by_bytes(const uint64_t* doc_off, uint64_t n_docs, size_t n, std::vector<uint64_t>& cut) {
+    cut.assign(n + 1, n_docs);
+    cut[0] = 0;
+    const uint64_t base = n_docs ? doc_off[0] : 0, total = n_docs ? doc_off[n_docs] - base : 0;
+    for (size_t i = 1; i < n; i++) {
+        const uint64_t target = base + (uint64_t)((unsigned __int128)total * i / n);
+        uint64_t c = (uint64_t)(std::lower_bound(doc_off, doc_off + n_docs + 1, target) - doc_off);
+        cut[i] = std::min(std::max(c, cut[i - 1]), n_docs);
+    }
+}
+
+// run f(i, engine_i) for every device, each on its own host thread (the caller's thread takes device 0); the first
+// failure's code and message become the handle's
+template <class F>
+int fan_out(gft_engine* e, F f) {
+    const std::vector<gft_engine*> eng = all_engines(e);
+    std::vector<int> rc(eng.size(), GFT_OK);
+    std::vector<std::thread> th;
+    for (size_t i = 1; i < eng.size(); i++) th.emplace_back([&, i] { rc[i] = f(i, eng[i]); });
+    e->in_multi = true;
+    rc[0] = f(0, e);
+    e->in_multi = false;
+    for (auto& t : th) t.join();
+    for (size_t i = 0; i < eng.size(); i++)
+        if (rc[i]) {
+            if (i) e->err = "device " + std::to_string(eng[i]->device) + ": " + eng[i]->err;
+            return rc[i];
+        }
+    return GFT_OK;
+}
+
+void destroy_multi(gft_engine* e) {
+    if (!e->comms.empty() && rccl_api().ok())
+        for (void* c : e->comms) (void)rccl_api().CommDestroy((ncclComm_t)c);
+    e->comms.clear();
+    for (gft_engine* p : e->peers) gft_engine_destroy(p);
+    e->peers.clear();
+}
+
+int replicate_tables(gft_engine* e, uint32_t flags) {
+    // the compiled tables are copied, not compiled again; every device uploads its own copy
+    std::vector<std::thread> th;
+    std::vector<int> rc(e->peers.size(), GFT_OK);
+    for (size_t i = 0; i < e->peers.size(); i++)
+        th.emplace_back([&, i] {
+            gft_engine* p = e->peers[i];
+            GFT_LOCK(p);
+            p->built = false;
+            p->tab = e->tab; p->s2 = e->s2; p->s3 = e->s3;
+            rc[i] = install_tables(p, flags);
+        });
+    for (auto& t : th) t.join();
+    for (size_t i = 0; i < rc.size(); i++)
+        if (rc[i]) { e->err = "device " + std::to_string(e->peers[i]->device) + ": " + e->peers[i]->err; return rc[i]; }
+    return GFT_OK;
+}
+
+int multi_build(gft_engine* e, const uint8_t* terms_blob, const uint64_t* term_off, uint32_t n_terms, uint32_t flags) {
+    e->in_multi = true;
+    const int rc = gft_build(e, terms_blob, term_off, n_terms, flags);
+    e->in_multi = false;
+    return rc ? rc : replicate_tables(e, flags);
+}
+
+int multi_import_tables(gft_engine* e, const uint8_t* blob, uint64_t len) {
+    e->in_multi = true;
+    const int rc = gft_import_tables(e, blob, len);
+    e->in_multi = false;
+    return rc ? rc : replicate_tables(e, e->build_flags);
+}
+
+int multi_set_programs(gft_engine* e, const uint32_t* prog_words, const uint64_t* prog_off, uint32_t n_exprs, uint32_t n_extra) {
+    return fan_out(e, [&](size_t, gft_engine* g) { return gft_set_programs(g, prog_words, prog_off, n_exprs, n_extra); });
+}
+
+// caller-supplied matches of the documents [a, b): the same arrays, offsets rebased
+struct ExtraSlice {
+    std::vector<uint64_t> off;
+    gft_extra_matches x{nullptr, nullptr, nullptr};
+    const gft_extra_matches* ptr = nullptr;
+    void set(const gft_extra_matches* extra, uint64_t a, uint64_t b) {
+        if (!(extra && extra->off)) return;
+        off.assign(extra->off + a, extra->off + b + 1);
+        const uint64_t base = off[0];
+        for (auto& o : off) o -= base;
+        x.off = off.data(); x.slot = extra->slot + base; x.pos = extra->pos + base;
+        ptr = &x;
+    }
+};
+
+int multi_process(gft_engine* e, const uint8_t* text_blob, const uint64_t* doc_off, uint64_t n_docs, uint32_t flags,
+                  const gft_extra_matches* extra, uint32_t* hit_bitmap) {
+    const size_t n = e->peers.size() + 1;
+    split_by_bytes(doc_off, n_docs, n, e->shard_cut);
+    const uint64_t words = (e->n_exprs + 31) / 32;
+    e->last_nonascii = false;
+    const int rc = fan_out(e, [&](size_t i, gft_engine* g) {
+        const uint64_t a = e->shard_cut[i], b = e->shard_cut[i + 1];
+        std::vector<uint64_t> off(doc_off + a, doc_off + b + 1);        // this shard's documents, offsets from its first byte
+        const uint64_t base = off[0];
+        for (auto& o : off) o -= base;
+        ExtraSlice xs;
+        xs.set(extra, a, b);
+        return gft_process(g, text_blob + base, off.data(), b - a, flags, xs.ptr, hit_bitmap ? hit_bitmap + a * words : nullptr);
+    });
+    for (gft_engine* g : e->peers) e->last_nonascii = e->last_nonascii || g->last_nonascii;
+    return rc;
+}
+
+int multi_process_again(gft_engine* e, uint64_t n_docs, const gft_extra_matches* extra, uint32_t* hit_bitmap) {
+    const size_t n = e->peers.size() + 1;
+    if (e->shard_cut.size() != n + 1 || e->shard_cut.back() != n_docs || !n_docs)
+        return fail(e, GFT_E_INVALID, "gft_process_again: no scan of these documents to reuse");
+    const uint64_t words = (e->n_exprs + 31) / 32;
+    return fan_out(e, [&](size_t i, gft_engine* g) {
+        const uint64_t a = e->shard_cut[i], b = e->shard_cut[i + 1];
+        if (a == b) return (int)GFT_OK;
+        ExtraSlice xs;
+        xs.set(extra, a, b);
+        return gft_process_again(g, b - a, xs.ptr, hit_bitmap ? hit_bitmap + a * words : nullptr);
+    });
+}
+
+int multi_scan(gft_engine* e, const uint8_t* text_blob, const uint64_t* doc_off, uint64_t n_docs, uint32_t flags, gft_matches* out) {
+    const size_t n = e->peers.size() + 1;
+    std::vector<uint64_t> cut;
+    split_by_bytes(doc_off, n_docs, n, cut);
+    std::vector<gft_matches> part(n);
+    int rc = fan_out(e, [&](size_t i, gft_engine* g) {
+        const uint64_t a = cut[i], b = cut[i + 1];
+        std::vector<uint64_t> off(doc_off + a, doc_off + b + 1);
+        const uint64_t base = off[0];
+        for (auto& o : off) o -= base;
+        return gft_scan(g, text_blob + base, off.data(), b - a, flags, &part[i]);
+    });
+    if (rc) return rc;
+    // the shards' CSRs one behind the other (device 0's own result lives in this handle's vectors: copied out first)
+    uint64_t total = 0;
+    for (const auto& p : part) total += p.n_matches;
+    std::vector<uint64_t> mo(n_docs + 1, 0);
+    std::vector<uint32_t> ti((size_t)total), po((size_t)total);
+    uint64_t at = 0;
+    for (size_t i = 0; i < n; i++) {
+        const uint64_t a = cut[i], nd = cut[i + 1] - a;
+        for (uint64_t d = 0; d <= nd; d++) mo[a + d] = at + part[i].match_off[d];
+        if (part[i].n_matches) {
+            memcpy(ti.data() + at, part[i].term_id, part[i].n_matches * 4);
+            memcpy(po.data() + at, part[i].pos, part[i].n_matches * 4);
+        }
+        at += part[i].n_matches;
+    }
+    e->h_match_off.swap(mo); e->h_term.swap(ti); e->h_pos.swap(po);
+    e->last_nonascii = false;
+    for (gft_engine* g : all_engines(e)) e->last_nonascii = e->last_nonascii || g->last_nonascii;
+    out->n_docs = n_docs; out->n_matches = total;
+    out->match_off = e->h_match_off.data(); out->term_id = e->h_term.data(); out->pos = e->h_pos.data();
+    return GFT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gft_engine_create_multi(gft_engine** out, const int* devices, int n_devices) {
+    if (!out || n_devices < 0 || (n_devices && !devices)) return GFT_E_INVALID;
+    *out = nullptr;
+    std::vector<int> devs(devices, devices + n_devices);
+    if (devs.empty()) {
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess) count = 0;
+        for (int d = 0; d < count; d++) devs.push_back(d);
+        if (devs.empty()) devs.push_back(0);       // (gft_engine_create reports the missing device)
+    }
+    gft_engine* e = nullptr;
+    int rc = gft_engine_create(&e, devs[0]);
+    *out = e;
+    if (rc) return rc;
+    for (size_t i = 1; i < devs.size(); i++) {
+        gft_engine* p = nullptr;
+        rc = gft_engine_create(&p, devs[i]);
+        if (rc) {
+            e->err = "device " + std::to_string(devs[i]) + ": " + (p ? p->err : std::string("cannot create an engine"));
+            if (p) gft_engine_destroy(p);
+            return rc;
+        }
+        e->peers.push_back(p);
+    }
+    // RCCL communicators over xGMI for the device-resident entry point -- only when the devices are distinct (a list
+    // that names one device twice is a test configuration: the gather is then plain device-to-device copies)
+    std::vector<int> uniq(devs);
+    std::sort(uniq.begin(), uniq.end());
+    const bool distinct = std::adjacent_find(uniq.begin(), uniq.end()) == uniq.end();
+    if (devs.size() > 1 && distinct) {
+        RcclApi& api = rccl_api();
+        if (api.ok()) {
+            std::vector<ncclComm_t> comms(devs.size());
+            const ncclResult_t r = api.CommInitAll(comms.data(), (int)devs.size(), devs.data());
+            if (r == ncclSuccess) for (ncclComm_t c : comms) e->comms.push_back((void*)c);
+            else e->err = std::string("ncclCommInitAll: ") + api.GetErrorString(r) + " (bitmaps will be gathered by device-to-device copies)";
+        }
+    }
+    return GFT_OK;
+}
+
+int gft_n_devices(const gft_engine* e) { return e ? (int)e->peers.size() + 1 : 0; }
+
+gft_engine* gft_device_engine(gft_engine* e, int i) {
+    if (!e || i < 0 || i > (int)e->peers.size()) return nullptr;
+    return i == 0 ? e : e->peers[(size_t)i - 1];
+}
+
+int gft_split_docs(const gft_engine* e, const uint64_t* doc_off, uint64_t n_docs, uint64_t* cut) {
+    if (!e || !cut || (n_docs && !doc_off)) return GFT_E_INVALID;
+    std::vector<uint64_t> c;
+    split_by_bytes(doc_off, n_docs, e->peers.size() + 1, c);
+    memcpy(cut, c.data(), c.size() * 8);
+    return GFT_OK;
+}
+
+int gft_process_device_multi(gft_engine* e, const uint8_t* const* d_text, const uint64_t* const* d_doc_off, const uint64_t* n_docs,
+                             uint32_t flags, uint32_t* d_bitmap_root) {
+    if (!e || !d_text || !d_doc_off || !n_docs) return e ? fail(e, GFT_E_INVALID, "null argument") : GFT_E_INVALID;
+    GFT_LOCK(e);
+    if (!e->built) return fail(e, GFT_E_NOT_BUILT, "gft_build has not been called");
+    if (!e->have_programs) return fail(e, GFT_E_NOT_BUILT, "gft_set_programs has not been called");
+    const std::vector<gft_engine*> eng = all_engines(e);
+    const size_t n = eng.size();
+    const uint64_t words = (e->n_exprs + 31) / 32;
+    std::vector<uint64_t> first(n + 1, 0);
+    for (size_t i = 0; i < n; i++) first[i + 1] = first[i] + n_docs[i];
+    if (first[n] * words && !d_bitmap_root) return fail(e, GFT_E_INVALID, "null bitmap");
+    // every device solves its shard into its own bitmap (device 0 straight into its slice of the result) ...
+    int rc = fan_out(e, [&](size_t i, gft_engine* g) {
+        uint32_t* dst = d_bitmap_root;
+        if (i) {
+            GFT_LOCK(g);
+            DeviceGuard dg(g->device);
+            if (g->d_bitmap.ensure(std::max<uint64_t>(n_docs[i] * words, 1) * 4) != hipSuccess) return fail(g, GFT_E_HIP, "bitmap alloc");
+            dst = g->d_bitmap.as<uint32_t>();
+        }
+        return gft_process_device(g, d_text[i], d_doc_off[i], n_docs[i], flags, nullptr, dst);
+    });
+    if (rc) return rc;
+    // ... then ONE exchange step: the shards' bitmaps to the first device, ncclSend / ncclRecv in one group over xGMI
+    // (plain device-to-device copies when there is no communicator)
+    if (n > 1 && words) {
+        RcclApi& api = rccl_api();
+        if (!e->comms.empty() && api.ok()) {
+            ncclResult_t r = api.GroupStart();
+            for (size_t i = 1; i < n && r == ncclSuccess; i++) {
+                if (!n_docs[i]) continue;
+                r = api.Recv(d_bitmap_root + first[i] * words, n_docs[i] * words, ncclUint32, (int)i, (ncclComm_t)e->comms[0], e->stream);
+                if (r == ncclSuccess)
+                    r = api.Send(eng[i]->d_bitmap.p, n_docs[i] * words, ncclUint32, 0, (ncclComm_t)e->comms[i], eng[i]->stream);
+            }
+            const ncclResult_t r2 = api.GroupEnd();
+            if (r != ncclSuccess || r2 != ncclSuccess)
+                return fail(e, GFT_E_HIP, std::string("RCCL gather: ") + api.GetErrorString(r != ncclSuccess ? r : r2));
+            for (gft_engine* g : eng) {
+                DeviceGuard dg(g->device);
+                HIP_TRY(hipStreamSynchronize(g->stream), "RCCL gather");
+            }
+        } else {
+            DeviceGuard dg(e->device);
+            for (size_t i = 1; i < n; i++)
+                if (n_docs[i]) HIP_TRY(hipMemcpyAsync(d_bitmap_root + first[i] * words, eng[i]->d_bitmap.p, n_docs[i] * words * 4, hipMemcpyDeviceToDevice, e->stream), "bitmap gather");
+            HIP_TRY(hipStreamSynchronize(e->stream), "bitmap gather");
+        }
+    }
+    e->last_nonascii = false;
+    for (gft_engine* g : eng) e->last_nonascii = e->last_nonascii || g->last_nonascii;
     return GFT_OK;
 }
 

@@ -450,6 +450,46 @@ __global__ void __launch_bounds__(256) k_unique_terms(const uint64_t* __restrict
     }
 }
 
+// ---- is ASCII case folding the whole of strings.ToLower for this text?  (finder/finder.go:140-142 lower-cases with
+// strings.ToLower; the scan kernels fold A-Z only.)  Run when a folded scan saw bytes >= 0x80.  Accepted without a
+// host round: ASCII, and the two-byte sequences C2 80..BF (Latin-1 signs: no case) and C3 9F..BF / C3 97 (Latin-1
+// LOWER-case letters and the multiplication sign).  Anything else -- upper-case Latin-1 (C3 80..9E), every other lead
+// byte, a continuation byte out of place (Go rewrites invalid UTF-8 to U+FFFD) -- sets *flag: the finder then lower-cases
+// that batch on the host.  The rule looks at byte pairs (previous, this) only, so every thread checks its 16 bytes
+// with one byte of context.
+__global__ void __launch_bounds__(256) k_fold_safe(const uint8_t* __restrict__ text, uint64_t lo, uint64_t hi, uint32_t* __restrict__ flag) {
+    // 16-byte blocks aligned in memory (one 16-byte load each); a block without a high bit -- nearly all of them even in
+    // text that leaves ASCII now and then -- costs the load and two ORs, so the pass runs at streaming speed
+    const uint64_t a0 = ((uint64_t)(uintptr_t)text + lo) & ~(uint64_t)15;          // address of the first block
+    const uint64_t blk = a0 + ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    const uint64_t end = (uint64_t)(uintptr_t)text + hi, beg = (uint64_t)(uintptr_t)text + lo;
+    bool bad = false;
+    if (blk < end) {
+        const uint4 v = *reinterpret_cast<const uint4*>((uintptr_t)blk);           // (reads < 16 bytes outside [lo, hi): inside the allocation's slack)
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        if ((v.x | v.y | v.z | v.w) & 0x80808080u) {
+            // the byte in front of the block decides about its first byte; a lead byte that ends the block is judged by
+            // the next block's thread
+            uint32_t p = blk > beg ? *reinterpret_cast<const uint8_t*>((uintptr_t)(blk - 1)) : 0u;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint32_t b = (w[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+                const uint64_t at = blk + k;
+                if (at >= beg && at < end) {
+                    if (p == 0xC2u) bad |= (b & 0xC0u) != 0x80u;
+                    else if (p == 0xC3u) bad |= !((b >= 0x9Fu && b <= 0xBFu) || b == 0x97u);
+                    else bad |= b >= 0x80u && b != 0xC2u && b != 0xC3u;
+                    if (at + 1 == end && (b == 0xC2u || b == 0xC3u)) bad = true;   // a lead byte at the very end
+                    p = b;
+                } else if (at < beg) {
+                    p = 0;                                                          // (bytes in front of the text do not count)
+                }
+            }
+        }
+    }
+    if (__any(bad) && (threadIdx.x & 63u) == 0) atomicOr(flag, 2u);
+}
+
 inline unsigned grid_for(uint64_t n, unsigned per_block, unsigned cap) {
     uint64_t g = (n + per_block - 1) / per_block;
     if (g < 1) g = 1;
@@ -531,6 +571,14 @@ hipError_t launch_gather(const uint64_t* d_unit_start, const uint32_t* d_unit_co
     else if (n_units)
         k_gather<<<dim3(grid_for(n_units, 4, n_cus * 16)), dim3(256), 0, st>>>(
             d_unit_start, d_unit_count, d_unit_out, n_units, d_pool_term, d_pool_pos, d_term, d_pos);
+    return hipGetLastError();
+}
+
+hipError_t launch_fold_safe(const uint8_t* d_text, uint64_t lo, uint64_t hi, uint32_t* d_flag, hipStream_t st) {
+    if (hi <= lo) return hipSuccess;
+    const uint64_t a0 = ((uint64_t)(uintptr_t)d_text + lo) & ~(uint64_t)15, a1 = (uint64_t)(uintptr_t)d_text + hi;
+    const uint64_t n = (a1 - a0 + 15) / 16;
+    k_fold_safe<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(d_text, lo, hi, d_flag);
     return hipGetLastError();
 }
 

@@ -30,10 +30,15 @@ def _p(a):
 class Engine:
     """Thin object wrapper of the C ABI (one gft_engine handle)."""
 
-    def __init__(self, device=-1):
+    def __init__(self, device=-1, devices=None):
+        """devices: a list of HIP device ordinals -> one handle over all of them (gft_engine_create_multi)"""
         self._L = _lib.load()
         h = C.c_void_p()
-        rc = self._L.gft_engine_create(C.byref(h), device)
+        if devices is not None:
+            arr = (C.c_int * len(devices))(*devices)
+            rc = self._L.gft_engine_create_multi(C.byref(h), C.cast(arr, C.c_void_p), len(devices))
+        else:
+            rc = self._L.gft_engine_create(C.byref(h), device)
         self._h = h
         if rc != 0:
             msg = self._L.gft_last_error(h).decode() if h else "engine_create failed"

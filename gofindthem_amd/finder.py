@@ -161,12 +161,16 @@ def _mk_find(obj, method):
 class Finder:
     """finder.Finder (finder/finder.go:32-240).  NewFinder(subEng, rgxEng, caseSensitive)."""
 
-    def __init__(self, subEng=None, rgxEng=None, caseSensitive=True, device=-1, allow_no_device=False):
+    def __init__(self, subEng=None, rgxEng=None, caseSensitive=True, device=-1, allow_no_device=False, devices=None):
         """allow_no_device: keep the handle when no HIP device exists, so the host-only half (expression
         registry, parser, engine-build orchestration) can be exercised; every GPU step then fails with GFT_E_HIP."""
         self._L = _lib.load()
         h = C.c_void_p()
-        rc = self._L.gft_finder_create(C.byref(h), 1 if caseSensitive else 0, device)
+        if devices is not None:        # one finder over several devices (gft_finder_create_multi)
+            arr = (C.c_int * len(devices))(*devices)
+            rc = self._L.gft_finder_create_multi(C.byref(h), 1 if caseSensitive else 0, C.cast(arr, C.c_void_p), len(devices))
+        else:
+            rc = self._L.gft_finder_create(C.byref(h), 1 if caseSensitive else 0, device)
         self._h = h
         if rc != 0 and not (allow_no_device and rc == _lib.GFT_E_HIP and h):
             msg = self._L.gft_finder_last_error(h).decode() if h else "gft_finder_create failed"

@@ -68,16 +68,64 @@ def stream(seed, i):
     return mix(seed + GOLDEN * (i + 1))
 
 
+_LEET = {ord("a"): b"4", ord("e"): b"3", ord("i"): b"1", ord("o"): b"0", ord("s"): b"5", ord("t"): b"7", ord("b"): b"8",
+         ord("g"): b"9", ord("z"): b"2", ord("l"): b"6"}
+_UTF8 = {ord("a"): "ä", ord("e"): "é", ord("o"): "ö", ord("u"): "ü", ord("n"): "ñ", ord("c"): "ç", ord("s"): "ß", ord("i"): "í"}
+_PUNCT = b"-_.'@#&+"
+
+
+def _dress_vocabulary(blob, off, seed):
+    """every word, deterministically by its index: maybe a capital / all capitals, a digit for a letter, a two-byte
+    UTF-8 letter (lower-case forms only, so that ASCII case folding equals strings.ToLower on this corpus), a
+    punctuation mark inside or behind it.  Returns (blob uint8[], off uint64[n+1])."""
+    raw = blob.tobytes()
+    out, offs = bytearray(), [0]
+    key = mix(seed ^ 0x5EED)
+    for i in range(len(off) - 1):
+        w = bytearray(raw[int(off[i]):int(off[i + 1])])
+        h = stream(key, i)
+        r = [(h >> (8 * k)) & 0xFF for k in range(8)]
+        if r[0] < 26:                                   # ~10 %: Capitalised
+            w[0] = w[0] - 32
+        elif r[0] < 34:                                 # ~3 %: SHOUTED
+            w = bytearray(bytes(w).upper())
+        if r[1] < 20:                                   # ~8 %: a digit for a letter
+            k = r[2] % len(w)
+            if w[k] in _LEET:
+                w[k:k + 1] = _LEET[w[k]]
+        if r[3] < 20:                                   # ~8 %: a two-byte letter
+            k = r[4] % len(w)
+            if w[k] in _UTF8:
+                w[k:k + 1] = _UTF8[w[k]].encode("utf-8")
+        if r[5] < 15:                                   # ~6 %: punctuation behind
+            w.append(_PUNCT[r[6] % len(_PUNCT)])
+        elif r[5] < 23 and len(w) >= 4:                 # ~3 %: punctuation inside
+            k = 1 + r[6] % (len(w) - 2)
+            if w[k] < 0x80 and w[k - 1] < 0xC0:
+                w[k:k] = bytes([_PUNCT[r[7] % 3]])
+        out += w
+        offs.append(len(out))
+    return np.frombuffer(bytes(out), dtype=np.uint8).copy(), np.asarray(offs, dtype=np.uint64)
+
+
 class Workload:
     """vocabulary + an n_terms dictionary; generates documents on the host or straight into HBM."""
 
-    def __init__(self, n_terms, base_seed=BASE_SEED, n_vocab=VOCAB_WORDS):
+    def __init__(self, n_terms, base_seed=BASE_SEED, n_vocab=VOCAB_WORDS, alphabet="lower"):
+        """alphabet = "lower": SURVEY.md 8(d), words over a-z.  "mixed": the same words dressed the way a real word list
+        looks (benchmarks/benchmark_test.go:43,72-83 reads one): capitals, digits, punctuation, two-byte UTF-8 letters --
+        more than 48 distinct bytes even after ASCII case folding, terms of 2-3 bytes included."""
         L = _lib()
         self.base_seed = base_seed
+        self.alphabet = alphabet
         blob, off = C.c_void_p(), C.c_void_p()
         self.n_vocab = L.gfw_vocab_build(base_seed, n_vocab, C.byref(blob), C.byref(off))
         self.vocab_off = np.ctypeslib.as_array(C.cast(off, C.POINTER(C.c_uint64)), shape=(self.n_vocab + 1,))
         self.vocab_blob = np.ctypeslib.as_array(C.cast(blob, C.POINTER(C.c_uint8)), shape=(int(self.vocab_off[-1]),))
+        if alphabet == "mixed":
+            self.vocab_blob, self.vocab_off = _dress_vocabulary(self.vocab_blob, self.vocab_off, base_seed)
+        elif alphabet != "lower":
+            raise ValueError("alphabet must be 'lower' or 'mixed'")
         self.n_terms = n_terms
         self.dict_idx = np.zeros(max(n_terms, 1), dtype=np.uint32)
         if n_terms:
@@ -167,7 +215,7 @@ def make_expressions(terms, n_exprs, inord_fraction=0.0, seed=BASE_SEED + 3, reg
         return stream(key, ctr[0]) % n
 
     def lit(t):
-        s = t.decode("ascii").replace("\\", "\\\\").replace('"', '\\"')
+        s = t.decode("utf-8").replace("\\", "\\\\").replace('"', '\\"')
         return '"%s"' % s
 
     if cover:

@@ -121,11 +121,16 @@ int gft_scan_device(gft_engine* e, const uint8_t* d_text_blob, const uint64_t* d
 int gft_set_programs(gft_engine* e, const uint32_t* prog_words, const uint64_t* prog_off, uint32_t n_exprs,
                      uint32_t n_extra);
 uint32_t gft_n_exprs(const gft_engine* e);
-/* 1 when the last scan / process call on this engine ran with GFT_FOLD_ASCII over text that holds a byte >= 0x80: its
- * results equal the reference's only if that text has no non-ASCII upper-case letter, no invalid UTF-8 and no rune whose
- * lower-case form has another length (strings.ToLower, finder/finder.go:140-142).  gft_finder_process_device checks this
- * and repeats such a batch through the host's ToLower. */
+/* 1 when the last scan / process call on this engine ran with GFT_FOLD_ASCII over text for which lower-casing A-Z is
+ * not provably the whole of strings.ToLower (finder/finder.go:140-142): it holds bytes >= 0x80 other than the two-byte
+ * sequences C2 80..BF and C3 9F..BF / C3 97 (Latin-1 signs and LOWER-case letters) -- i.e. possibly an upper-case
+ * non-ASCII letter, a rune whose lower-case form has another length, or invalid UTF-8.  The scan kernels notice high
+ * bytes on their way; only such a batch pays one more pass over its text for this answer.
+ * gft_finder_process_device checks it and repeats an unsafe batch through the host's ToLower. */
 int gft_last_nonascii(const gft_engine* e);
+/* which scan kernel the built dictionary runs on: "scan2" (suffix-window kernel, small alphabets), "scan3" (stride-2
+ * suffix-window kernel, any alphabet) or "dfa" (general two-tier DFA kernel: only when forced) */
+const char* gft_scan_kernel(const gft_engine* e);
 
 /* Caller-supplied matches (regex engine output, or the output of a foreign SubstringEngine), CSR per document.
  * `slot` is ABSOLUTE: n_terms + j for extra literal j, or a dictionary term id when a regex literal has the same
@@ -170,6 +175,8 @@ typedef int (*gft_engine_find_fn)(void* user, const uint8_t* text, uint64_t text
                                   char* err, uint32_t err_cap);
 
 int gft_finder_create(gft_finder** out, int case_sensitive, int device); /* NewFinder(GpuEngine, EmptyRgxEngine, cs) */
+/* the same finder over several devices (gft_engine_create_multi): finder.NewFinder(&GpuEngine{Devices: ...}, ...) */
+int gft_finder_create_multi(gft_finder** out, int case_sensitive, const int* devices, int n_devices);
 void gft_finder_destroy(gft_finder* f);
 const char* gft_finder_last_error(const gft_finder* f);
 gft_engine* gft_finder_engine(gft_finder* f); /* the GPU engine handle used for scanning/solving */
@@ -253,6 +260,25 @@ int gft_profile_enable(gft_engine* e, int on);
 /* Sums since the last reset.  names: "scan", "solve", "aux".  Synchronises the stream. */
 int gft_profile_read(gft_engine* e, const char* name, double* total_ms, uint64_t* launches);
 int gft_profile_reset(gft_engine* e);
+
+/* ---- several devices behind one handle ------------------------------------------------------ */
+/* A handle over n_devices HIP devices (devices == NULL / n_devices == 0: every visible device).  It is used exactly like
+ * a single-device handle -- gft_build, gft_set_programs, gft_scan, gft_process, gft_process_again and the gft_finder_*
+ * functions on top of it --: tables and programs are replicated, a batch is cut into contiguous document ranges of
+ * near-equal text bytes, every device has its own host thread and stream for the duration of a call, results land in the
+ * caller's buffers in document order.  The *_device entry points of such a handle run on its first device; shards that
+ * are already resident on their devices go through gft_process_device_multi.  A device may be named twice (tests). */
+int gft_engine_create_multi(gft_engine** out, const int* devices, int n_devices);
+int gft_n_devices(const gft_engine* e);
+gft_engine* gft_device_engine(gft_engine* e, int i);     /* the per-device engine (its stream, its profile counters) */
+/* the document cuts gft_process would use: device i gets documents [cut[i], cut[i+1]); cut has n_devices + 1 entries */
+int gft_split_docs(const gft_engine* e, const uint64_t* doc_off, uint64_t n_docs, uint64_t* cut);
+/* Device-resident shards: d_text[i] / d_doc_off[i] / n_docs[i] live on device i (64 bytes of readable slack behind every
+ * blob).  Every device scans and solves its shard; then the path's ONE exchange step gathers the bitmaps into
+ * d_bitmap_root on the first device, shard after shard (sum(n_docs) x ceil(n_exprs / 32) words): ncclSend / ncclRecv in
+ * one group over xGMI on communicators from ncclCommInitAll (device-to-device copies if RCCL is not available). */
+int gft_process_device_multi(gft_engine* e, const uint8_t* const* d_text, const uint64_t* const* d_doc_off, const uint64_t* n_docs,
+                             uint32_t flags, uint32_t* d_bitmap_root);
 
 /* ---- test hook: the table compiler without a device ------------------------------------------------------- */
 /* Compiles `terms` into the scan kernel's tables on the host and walks them over ONE document the way the kernel does

@@ -1,0 +1,123 @@
+"""Several devices behind ONE handle of the C ABI (gft_engine_create_multi): a Go caller keeps
+finder.NewFinder(&GpuEngine{...}) and the library fans a batch out -- tables replicated, contiguous document ranges of
+near-equal text bytes, one host thread + stream per device, results back in document order.
+
+With >= 2 visible devices the test uses devices [0, 1] (and the RCCL gather of the device-resident entry point);
+on a one-GPU box it names device 0 twice: two engines, two host threads and streams on the same card, the gather done by
+device-to-device copies -- everything but the RCCL call itself."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from gofindthem_amd import _lib
+from gofindthem_amd.engine import Engine
+from gofindthem_amd.finder import EmptyRgxEngine, Finder, GpuEngine, PyRegexpEngine
+from gofindthem_amd.workload import Workload, make_expressions
+from helpers import assert_csr_equal
+from oracle.pyoracle import Oracle, pack_strings
+
+pytestmark = pytest.mark.gpu
+
+
+def _devices():
+    n = torch.cuda.device_count()
+    return [0, 1] if n >= 2 else [0, 0]
+
+
+def test_split_is_contiguous_and_byte_balanced():
+    e = Engine(devices=[0, 0, 0])
+    try:
+        L = _lib.load()
+        assert L.gft_n_devices(e._h) == 3
+        off = np.asarray([0, 10, 10, 500, 510, 520, 1000, 1500], np.uint64)
+        cut = np.zeros(4, np.uint64)
+        assert L.gft_split_docs(e._h, off.ctypes.data, 7, cut.ctypes.data) == 0
+        assert cut.tolist() == [0, 3, 6, 7]          # 500 | 500 | 500 bytes
+        assert L.gft_split_docs(e._h, off.ctypes.data, 0, cut.ctypes.data) == 0 and cut.tolist() == [0, 0, 0, 0]
+    finally:
+        e.close()
+
+
+def test_engine_over_two_devices_equals_one():
+    w = Workload(2000)
+    terms = w.terms()
+    o = Oracle(terms)
+    text, off = w.docs_host(0, 501)
+    one, two = Engine(0), Engine(devices=_devices())
+    try:
+        for e in (one, two):
+            e.build(terms)
+        assert two.terms() == one.terms()
+        # FindSubstrings: the shards' CSRs come back as one
+        assert_csr_equal(two.scan(text, off, fold=True), o.scan(text, off, fold=True))
+        assert_csr_equal(two.scan(text[:0], off[:1]), one.scan(text[:0], off[:1]))
+        assert_csr_equal(two.scan(text, off[:2]), one.scan(text, off[:2]))            # one document: the second shard is empty
+        exprs = make_expressions(terms, 200, inord_fraction=0.4)
+        o.set_expressions(exprs, False)
+        from test_gpu_parity import _programs
+        progs, _ = _programs(o, one, exprs, False)
+        for e in (one, two):
+            e.set_programs(progs)
+        want = o.process(text, off, fold=True)
+        assert np.array_equal(two.process(text, off, fold=True), want)
+        assert np.array_equal(two.process(text, off, fold=True), want)
+    finally:
+        one.close()
+        two.close()
+
+
+def test_finder_over_two_devices_with_regex_terms():
+    """the whole Finder on a multi-device handle, regex prefilter (gft_process_again on every shard) included"""
+    w = Workload(300)
+    terms = w.terms()
+    rx = ["en.*nr", "po[a-z]+ud", "q+"]
+    exprs = make_expressions(terms, 120, inord_fraction=0.4, regexes=rx)
+    text, off = w.docs_host(0, 160)
+    got = []
+    for kw in (dict(device=0), dict(devices=_devices())):
+        f = Finder(GpuEngine(), PyRegexpEngine(), False, **kw)
+        f.AddExpressions(exprs)
+        got.append(f.ProcessTexts(blob=text, doc_off=off))
+        one = f.ProcessText(bytes(text[int(off[5]):int(off[6])]))
+        assert [r.ExpresionIndex for r in one] == [i for i in range(len(exprs)) if got[-1][5, i >> 5] >> (i & 31) & 1]
+        f.close()
+    assert np.array_equal(got[0], got[1]) and got[0].any()
+
+
+def test_device_resident_shards_and_the_gather():
+    """gft_process_device_multi: every device's shard is already in its HBM; the bitmaps are gathered to the first device
+    (RCCL when the devices are distinct)"""
+    devs = _devices()
+    w = Workload(1000)
+    terms = w.terms()
+    exprs = make_expressions(terms, 96, inord_fraction=0.3, cover=True)
+    f = Finder(GpuEngine(), EmptyRgxEngine(), False, devices=devs)
+    f.AddExpressions(exprs)
+    f.ForceBuild()
+    L = _lib.load()
+    eh = f.engine_handle()
+    text, off = w.docs_host(0, 300)
+    cut = np.zeros(len(devs) + 1, np.uint64)
+    assert L.gft_split_docs(eh, off.ctypes.data, 300, cut.ctypes.data) == 0
+    keep, tp, op, nd = [], [], [], []
+    for i, d in enumerate(devs):
+        a, b = int(cut[i]), int(cut[i + 1])
+        t = np.concatenate([text[int(off[a]):int(off[b])], np.zeros(64, np.uint8)])
+        o = (off[a:b + 1] - off[a]).astype(np.int64)
+        tt, oo = torch.from_numpy(t).to("cuda:%d" % d), torch.from_numpy(o).to("cuda:%d" % d)
+        keep += [tt, oo]
+        tp.append(tt.data_ptr()); op.append(oo.data_ptr()); nd.append(b - a)
+    words = 3
+    bm = torch.zeros((300, words), dtype=torch.int32, device="cuda:%d" % devs[0])
+    torch.cuda.synchronize()
+    # (the finder uploaded its programs when it was built: the engine-level entry point can be used directly)
+    f.ProcessTexts(blob=text[:int(off[1])], doc_off=off[:2])
+    rc = L.gft_process_device_multi(eh, (C.c_void_p * len(devs))(*tp), (C.c_void_p * len(devs))(*op),
+                                    (C.c_uint64 * len(devs))(*nd), _lib.GFT_FOLD_ASCII, bm.data_ptr())
+    assert rc == 0, L.gft_last_error(eh)
+    o = Oracle(sorted(k.encode() for k in f.GetKeywords()))
+    o.set_expressions(exprs, False)
+    assert np.array_equal(bm.cpu().numpy().astype(np.uint32), o.process(text, off, fold=True))
+    f.close()

@@ -237,7 +237,31 @@ def test_table_export_import_roundtrip(eng, scan_kernel):
         for bad in (blob[:-1], blob[:1000], b"GFTT" + blob[4:200], blob[:500] + bytes([blob[500] ^ 1]) + blob[501:], b""):
             with pytest.raises(GftError):
                 e2.import_tables(bad)
+        # a blob that is internally consistent as far as the checksum goes, but whose tables point outside themselves
+        # (stale or crafted): every index-bearing table is validated before anything is uploaded
+        import struct
+
+        def resealed(b):
+            h = 1469598103934665603
+            for c in b[:-8]:
+                h = ((h ^ c) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+            return b[:-8] + struct.pack("<Q", h)
+        n_bad = 0
+        for frac in (0.2, 0.35, 0.5, 0.65, 0.8, 0.9, 0.97):
+            at = int(len(blob) * frac) & ~3
+            forged = resealed(blob[:at] + b"\xff\xff\xff\x7f" + blob[at + 4:])
+            try:
+                e2.import_tables(forged)
+            except GftError:
+                n_bad += 1
+                continue
+            # accepted: then the word was not an index (text bytes, filter bits ...) and the scan must still be in bounds
+            e2.scan(text, off, fold=True)
+        assert n_bad >= 2
+        e2.import_tables(blob)
         # a refused blob leaves the engine as it was
+        with pytest.raises(GftError):
+            e2.import_tables(blob[:-1])
         assert_csr_equal(e2.scan(text, off, fold=True), o.scan(text, off, fold=True))
     finally:
         e2.close()
@@ -369,3 +393,30 @@ def test_unique_terms_mode_is_the_cloudflare_engine_output(eng):
     oo = torch.from_numpy(toff.astype(np.int64)).cuda()
     m = eng.scan_device(t.data_ptr(), oo.data_ptr(), 700, fold=True, unique=True)
     assert int(m.n_matches) == int(mo[-1])
+
+
+def test_mixed_alphabet_workload(eng, scan_kernel):
+    """a real word list's shape (benchmarks/benchmark_test.go:72-83): capitals, digits, punctuation, two-byte UTF-8
+    letters -- more than 48 byte classes after folding, 2- and 3-byte terms included.  The round-1 kernel refuses such a
+    dictionary; the stride-2 kernel merges byte classes into filter groups and must stay bit-exact."""
+    from gofindthem_amd import _lib
+    from gofindthem_amd.workload import Workload, make_expressions
+    w = Workload(3000, alphabet="mixed")
+    kws = sorted({t.decode("utf-8").lower().encode("utf-8") for t in w.terms()})      # the finder's keyword set
+    assert len({b for t in kws for b in t}) >= 48 and min(len(t) for t in kws) <= 3
+    o = both(eng, kws)
+    L = _lib.load()
+    assert L.gft_scan_kernel(eng._h).decode() == {"scan3": "scan3", "scan2": "dfa", "scan2-ordered": "dfa", "dfa": "dfa"}[scan_kernel]
+    text, off = w.docs_host(0, 400)
+    assert_csr_equal(eng.scan(text, off, fold=True), o.scan(text, off, fold=True))
+    assert_csr_equal(eng.scan(text, off, fold=False), o.scan(text, off, fold=False))
+    exprs = make_expressions(kws, 150, inord_fraction=0.4)
+    o.set_expressions(exprs, case_sensitive=False)
+    progs, _ = _programs(o, eng, exprs, False)
+    eng.set_programs(progs)
+    assert np.array_equal(eng.process(text, off, fold=True), o.process(text, off, fold=True))
+    # this corpus leaves ASCII, but only with lower-case Latin-1 letters: ASCII folding is still strings.ToLower
+    assert L.gft_last_nonascii(eng._h) == 0
+    bad = np.frombuffer("Ünsafe: an upper-case letter beyond ASCII".encode("utf-8"), dtype=np.uint8)
+    eng.process(bad, np.asarray([0, bad.size], np.uint64), fold=True)
+    assert L.gft_last_nonascii(eng._h) == 1

@@ -16,11 +16,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--docs", type=int, default=500000)
 ap.add_argument("--terms", type=int, default=10000)
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--alphabet", default="lower")
 ap.add_argument("--modes", default="0,1,2")
 ap.add_argument("--unordered", action="store_true", help="time the scan as the process path runs it (any order)")
 args = ap.parse_args()
 
-wl = Workload(args.terms)
+wl = Workload(args.terms, alphabet=args.alphabet)
 text, off = wl.docs_device(0, args.docs)
 nbytes = text.numel()
 bm = torch.zeros((args.docs, 1), dtype=torch.int32, device="cuda")
@@ -33,7 +34,7 @@ def make_engine():
     if eng is not None:
         eng.close()
     eng = Engine(0)
-    eng.build(wl.terms())
+    eng.build(sorted({t.decode('utf-8').lower().encode('utf-8') for t in wl.terms()}))
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     eng.set_programs([[1 << 28]])
 

@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libgft.so")
+LIB_PATH = os.environ.get("GFT_LIBRARY") or os.path.join(HERE, "libgft.so")   # GFT_LIBRARY: another build (tools/asan_host.sh)
 
 GFT_OK, GFT_E_INVALID, GFT_E_NOT_BUILT, GFT_E_HIP, GFT_E_UNSUPPORTED, GFT_E_PARSE, GFT_E_ENGINE = 0, -1, -2, -3, -4, -5, -6
 GFT_POS_START, GFT_POS_END = 0, 1

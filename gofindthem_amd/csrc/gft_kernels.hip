@@ -198,6 +198,7 @@ __global__ void __launch_bounds__(kScanBlockThreads) k_scan_units(const ScanPara
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     uint8_t* buf = text_lds + (size_t)wave * kTextBuf;
     const uint32_t warm = P.max_term_len > 0 ? P.max_term_len - 1 : 0;
+    bool told_nonascii = false;
 
     for (uint64_t u = (uint64_t)blockIdx.x * wpb + wave; u < P.n_units; u += (uint64_t)gridDim.x * wpb) {
         const Unit un = P.units[u];
@@ -212,7 +213,7 @@ __global__ void __launch_bounds__(kScanBlockThreads) k_scan_units(const ScanPara
             if (P.fold && b >= 'A' && b <= 'Z') b += 32;
             buf[i] = b;
         }
-        if (P.fold && P.nonascii && __any((hib & 0x80u) != 0) && lane == 0) atomicOr(P.nonascii, 1u);
+        if (P.fold && P.nonascii && !told_nonascii && __any((hib & 0x80u) != 0)) { told_nonascii = true; if (lane == 0) atomicOr(P.nonascii, 1u); }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 
@@ -466,24 +467,32 @@ __global__ void __launch_bounds__(256) k_fold_safe(const uint8_t* __restrict__ t
     bool bad = false;
     if (blk < end) {
         const uint4 v = *reinterpret_cast<const uint4*>((uintptr_t)blk);           // (reads < 16 bytes outside [lo, hi): inside the allocation's slack)
-        uint32_t w[4] = {v.x, v.y, v.z, v.w};
-        if ((v.x | v.y | v.z | v.w) & 0x80808080u) {
-            // the byte in front of the block decides about its first byte; a lead byte that ends the block is judged by
-            // the next block's thread
-            uint32_t p = blk > beg ? *reinterpret_cast<const uint8_t*>((uintptr_t)(blk - 1)) : 0u;
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        // the byte in front of the block decides about the block's first byte (a lead byte that ends a block is judged
+        // by the next block's thread): after a lead byte, even an ASCII byte is a violation
+        const uint32_t prev = blk > beg ? *reinterpret_cast<const uint8_t*>((uintptr_t)(blk - 1)) : 0u;
+        auto byte_at = [&](uint32_t k) { return (w[k >> 2] >> (8 * (k & 3))) & 0xFFu; };
+        const uint32_t k_lo = blk < beg ? (uint32_t)(beg - blk) : 0u, k_hi = end - blk < 16 ? (uint32_t)(end - blk) : 16u;   // in-range bytes
+        if ((prev == 0xC2u || prev == 0xC3u) && k_lo == 0 && byte_at(0) < 0x80u) bad = true;
+        // one bit per byte that has its high bit set; the rule is evaluated for those bytes only
+        uint32_t m = 0;
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const uint32_t b = (w[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-                const uint64_t at = blk + k;
-                if (at >= beg && at < end) {
-                    if (p == 0xC2u) bad |= (b & 0xC0u) != 0x80u;
-                    else if (p == 0xC3u) bad |= !((b >= 0x9Fu && b <= 0xBFu) || b == 0x97u);
-                    else bad |= b >= 0x80u && b != 0xC2u && b != 0xC3u;
-                    if (at + 1 == end && (b == 0xC2u || b == 0xC3u)) bad = true;   // a lead byte at the very end
-                    p = b;
-                } else if (at < beg) {
-                    p = 0;                                                          // (bytes in front of the text do not count)
-                }
+        for (int d = 0; d < 4; d++) m |= ((((w[d] & 0x80808080u) >> 7) * 0x00204081u) >> 21 & 0xFu) << (4 * d);
+        m &= (0xFFFFu << k_lo) & (0xFFFFu >> (16 - k_hi));
+        while (m) {
+            const uint32_t k = (uint32_t)__builtin_ctz(m);
+            m &= m - 1;
+            const uint32_t b = byte_at(k), p = k > k_lo ? byte_at(k - 1) : (k == 0 ? prev : 0u);
+            const bool p_lead = p == 0xC2u || p == 0xC3u;
+            if (b == 0xC2u || b == 0xC3u) {
+                // a lead byte: not behind another lead, and the byte behind it (if this block holds it) continues it
+                bad |= p_lead;
+                if (k + 1 < k_hi) bad |= (byte_at(k + 1) & 0xC0u) != 0x80u;
+                else if (blk + k + 1 == end) bad = true;                            // a lead byte at the very end
+            } else if ((b & 0xC0u) == 0x80u) {
+                bad |= !p_lead || (p == 0xC3u && !(b >= 0x9Fu || b == 0x97u));     // C3 80..9E: upper-case Latin-1
+            } else {
+                bad = true;                                                         // any other lead byte, or 0xC0 / 0xC1 / 0xF8+
             }
         }
     }

@@ -510,6 +510,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
     if ((uint32_t)(uintptr_t)(lds_u8*)smem != 0) __builtin_trap();   // see lds_u8
 
     uint64_t slab_next = 0, wave_matches = 0;   // wave-uniform
+    bool told_nonascii = false;                  // (one atomic per wave, not one per unit: they all hit the same word)
     uint32_t slab_left = 0;
 
     // the next unit's record and document offset are fetched while the current unit is processed
@@ -593,7 +594,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
                 if (k == 0) m0 = v; else if (k == 1) m1 = v; else if (k == 2) m2 = v; else m3 = v;
             }
             // ASCII folding is not strings.ToLower once the text leaves ASCII (finder.go:140-142): tell the host
-            if (P.fold && P.nonascii && __any((hib & 0x80808080u) != 0) && lane == 0) atomicOr(P.nonascii, 1u);
+            if (P.fold && P.nonascii && !told_nonascii && __any((hib & 0x80808080u) != 0)) { told_nonascii = true; if (lane == 0) atomicOr(P.nonascii, 1u); }
             // positions past the lane's range carry garbage flags
             m0 = nvalid >= 32 ? m0 : (nvalid ? m0 & ((1u << nvalid) - 1) : 0);
             m1 = nvalid >= 64 ? m1 : (nvalid > 32 ? m1 & ((1u << (nvalid - 32)) - 1) : 0);

@@ -490,6 +490,7 @@ __global__ void __launch_bounds__(kScan3Threads) k_scan3(const Scan3Params P) {
     const bool have_short = P.short3_bytes != 0;
 
     uint64_t slab_next = 0, wave_matches = 0;   // wave-uniform
+    bool told_nonascii = false;                  // (one atomic per wave, not one per unit: they all hit the same word)
     uint32_t slab_left = 0;
 
     // the next unit's record and document offset are fetched while the current unit is processed
@@ -550,7 +551,7 @@ __global__ void __launch_bounds__(kScan3Threads) k_scan3(const Scan3Params P) {
                 if (r == 3) { m0 = acc; acc = 0; }
             }
             // ASCII folding is not strings.ToLower once the text leaves ASCII (finder.go:140-142): tell the host
-            if (P.fold && P.nonascii && __any((hib & 0x80808080u) != 0) && lane == 0) atomicOr(P.nonascii, 1u);
+            if (P.fold && P.nonascii && !told_nonascii && __any((hib & 0x80808080u) != 0)) { told_nonascii = true; if (lane == 0) atomicOr(P.nonascii, 1u); }
             // probe t of the unit sits in round t / 512, lane (t / 8) % 64, bit 8 * (round % 4) + t % 8 of m0 (rounds 0-3) or
             // m1 (rounds 4-7); probes of the last round that start at or beyond the unit's end carry garbage
             const uint32_t lr = nr - 1;                               // the last round

@@ -376,31 +376,39 @@ struct Leaf { uint32_t doc; std::string path; const std::string* text; };
 
 // getRulesInfo (internal.go:9-97) over a decoded JSON value: strings are leaves, objects extend the path with
 // ".key", arrays with ".index(i)"; numbers, booleans and null are not taggable
-void walk(const json::Value& v, const std::string& path, uint32_t doc, const std::vector<std::string>& inc,
+void walk(const json::Value& root, const std::string& root_path, uint32_t doc, const std::vector<std::string>& inc,
           const std::vector<std::string>& exc, std::vector<Leaf>& out) {
-    switch (v.kind) {
-    case json::Value::String:
-        if (IsValidFieldPath(path, inc, exc)) out.push_back(Leaf{doc, path, &v.str});
-        break;
-    case json::Value::Object:
-        for (size_t i = 0; i < v.obj.size(); i++) {
-            if (!v.last_wins(i)) continue;               // a Go map keeps the last duplicate
-            walk(v.obj[i].second, path.empty() ? v.obj[i].first : path + "." + v.obj[i].first, doc, inc, exc, out);
+    // depth first, children in document order, with an explicit stack (documents nest up to 10 000 levels)
+    struct Item { const json::Value* v; std::string path; };
+    std::vector<Item> todo;
+    todo.push_back(Item{&root, root_path});
+    while (!todo.empty()) {
+        Item it = std::move(todo.back());
+        todo.pop_back();
+        const json::Value& v = *it.v;
+        const std::string& path = it.path;
+        switch (v.kind) {
+        case json::Value::String:
+            if (IsValidFieldPath(path, inc, exc)) out.push_back(Leaf{doc, path, &v.str});
+            break;
+        case json::Value::Object:
+            for (size_t i = v.obj.size(); i-- > 0;) {          // pushed in reverse: popped in document order
+                if (!v.last_wins(i)) continue;                   // a Go map keeps the last duplicate
+                todo.push_back(Item{&v.obj[i].second, path.empty() ? v.obj[i].first : path + "." + v.obj[i].first});
+            }
+            break;
+        case json::Value::Array:
+            for (size_t i = v.arr.size(); i-- > 0;) {
+                const std::string fn = "index(" + std::to_string(i) + ")";
+                todo.push_back(Item{&v.arr[i], path.empty() ? fn : path + "." + fn});
+            }
+            break;
+        default:
+            break;
         }
-        break;
-    case json::Value::Array:
-        for (size_t i = 0; i < v.arr.size(); i++) {
-            const std::string fn = "index(" + std::to_string(i) + ")";
-            walk(v.arr[i], path.empty() ? fn : path + "." + fn, doc, inc, exc, out);
-        }
-        break;
-    default:
-        break;
     }
 }
-}  // namespace
 
-namespace {
 unsigned host_threads() {
     if (const char* e = getenv("GFT_HOST_THREADS")) { const int v = atoi(e); if (v > 0) return (unsigned)v; }
     const unsigned hc = std::thread::hardware_concurrency();

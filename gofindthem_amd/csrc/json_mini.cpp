@@ -138,60 +138,72 @@ struct Reader {
         return true;
     }
 
-    // iterative over containers would be kinder to the stack; depth is capped like encoding/json caps it
-    bool value(Value& v, int depth) {
-        ws();
-        if (i >= n) return eof();
+    // Containers are walked with an explicit stack (no recursion per nesting level: documents come from outside and a
+    // caller's thread may have a small stack); depth is capped like encoding/json caps it
+    bool scalar(Value& v) {
         const char c = p[i];
-        if (c == '{') {
-            if (depth >= kMaxDepth) return fail("exceeded max depth");
-            v.kind = Value::Object;
-            i++;
-            ws();
-            if (i >= n) return eof();
-            if (p[i] == '}') { i++; return true; }
-            for (;;) {
-                ws();
-                if (i >= n) return eof();
-                if (p[i] != '"') return fail_char("looking for beginning of object key string");
-                std::string key;
-                if (!string(key)) return false;
-                ws();
-                if (i >= n) return eof();
-                if (p[i] != ':') return fail_char("after object key");
-                i++;
-                v.obj.emplace_back(std::move(key), Value());
-                if (!value(v.obj.back().second, depth + 1)) return false;
-                ws();
-                if (i >= n) return eof();
-                if (p[i] == ',') { i++; continue; }
-                if (p[i] == '}') { i++; return true; }
-                return fail_char("after object key:value pair");
-            }
-        }
-        if (c == '[') {
-            if (depth >= kMaxDepth) return fail("exceeded max depth");
-            v.kind = Value::Array;
-            i++;
-            ws();
-            if (i >= n) return eof();
-            if (p[i] == ']') { i++; return true; }
-            for (;;) {
-                v.arr.emplace_back();
-                if (!value(v.arr.back(), depth + 1)) return false;
-                ws();
-                if (i >= n) return eof();
-                if (p[i] == ',') { i++; continue; }
-                if (p[i] == ']') { i++; return true; }
-                return fail_char("after array element");
-            }
-        }
         if (c == '"') { v.kind = Value::String; return string(v.str); }
         if (c == 't') { v.kind = Value::Bool; v.b = true; return literal("true", "in literal true (expecting 'r')"); }
         if (c == 'f') { v.kind = Value::Bool; v.b = false; return literal("false", "in literal false (expecting 'a')"); }
         if (c == 'n') { v.kind = Value::Null; return literal("null", "in literal null (expecting 'u')"); }
         if (c == '-' || (c >= '0' && c <= '9')) { v.kind = Value::Number; return number(v.str); }
         return fail_char("looking for beginning of value");
+    }
+
+    bool value(Value& root) {
+        std::vector<Value*> open;                      // the containers being filled, outermost first
+        Value* v = &root;                              // where the next value goes
+        for (;;) {
+            ws();
+            if (i >= n) return eof();
+            const char c = p[i];
+            bool opened = false;
+            if (c == '{' || c == '[') {
+                if ((int)open.size() >= kMaxDepth) return fail("exceeded max depth");
+                v->kind = c == '{' ? Value::Object : Value::Array;
+                i++;
+                ws();
+                if (i >= n) return eof();
+                if (p[i] == (c == '{' ? '}' : ']')) i++;               // empty container: a finished value
+                else { open.push_back(v); opened = true; }
+            } else if (!scalar(*v)) {
+                return false;
+            }
+            // after a finished value: close containers / step to the next member; after an opening: its first member
+            for (;;) {
+                if (open.empty()) return true;
+                Value* top = open.back();
+                if (!opened) {
+                    ws();
+                    if (i >= n) return eof();
+                    if (top->kind == Value::Object) {
+                        if (p[i] == '}') { i++; open.pop_back(); continue; }
+                        if (p[i] != ',') return fail_char("after object key:value pair");
+                    } else {
+                        if (p[i] == ']') { i++; open.pop_back(); continue; }
+                        if (p[i] != ',') return fail_char("after array element");
+                    }
+                    i++;
+                }
+                if (top->kind == Value::Object) {
+                    ws();
+                    if (i >= n) return eof();
+                    if (p[i] != '"') return fail_char("looking for beginning of object key string");
+                    std::string key;
+                    if (!string(key)) return false;
+                    ws();
+                    if (i >= n) return eof();
+                    if (p[i] != ':') return fail_char("after object key");
+                    i++;
+                    top->obj.emplace_back(std::move(key), Value());
+                    v = &top->obj.back().second;
+                } else {
+                    top->arr.emplace_back();
+                    v = &top->arr.back();
+                }
+                break;
+            }
+        }
     }
 };
 
@@ -200,10 +212,28 @@ struct Reader {
 std::string Parse(const char* p, size_t n, Value& out) {
     Reader r{p, n};
     out = Value();
-    if (!r.value(out, 0)) return r.err;
+    if (!r.value(out)) return r.err;
     r.ws();
     if (r.i < n) { r.fail_char("after top-level value"); return r.err; }
     return "";
+}
+
+// teardown without recursion: the children of every container are moved onto one work list before their parent dies
+Value::~Value() {
+    if (arr.empty() && obj.empty()) return;
+    std::vector<Value> work;
+    auto take = [&](Value& v) {
+        for (auto& c : v.arr) if (!c.arr.empty() || !c.obj.empty()) work.push_back(std::move(c));
+        for (auto& kv : v.obj) if (!kv.second.arr.empty() || !kv.second.obj.empty()) work.push_back(std::move(kv.second));
+        v.arr.clear();
+        v.obj.clear();
+    };
+    take(*this);
+    while (!work.empty()) {
+        Value v = std::move(work.back());
+        work.pop_back();
+        take(v);
+    }      // (v and the emptied children die here: nothing below them is left)
 }
 
 void Quote(const std::string& s, std::string& out) { dsl::json_str(s, out); }

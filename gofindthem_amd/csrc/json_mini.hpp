@@ -18,6 +18,14 @@ struct Value {
     std::vector<Value> arr;
     std::vector<std::pair<std::string, Value>> obj;    // in document order; duplicate keys are kept (last one wins
                                                        // for a Go map: see last_wins())
+    Value() = default;
+    Value(Value&&) = default;
+    Value& operator=(Value&&) = default;
+    Value(const Value&) = default;
+    Value& operator=(const Value&) = default;
+    // documents nest up to 10 000 levels (encoding/json's limit): the teardown, like the parser and the walk over a
+    // value, must not recurse once per level -- a caller's thread may have a small stack
+    ~Value();
     // index of the member that a Go map would hold for key obj[i].first (the last duplicate)
     bool last_wins(size_t i) const {
         for (size_t j = i + 1; j < obj.size(); j++)

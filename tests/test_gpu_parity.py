@@ -420,3 +420,53 @@ def test_mixed_alphabet_workload(eng, scan_kernel):
     bad = np.frombuffer("Ünsafe: an upper-case letter beyond ASCII".encode("utf-8"), dtype=np.uint8)
     eng.process(bad, np.asarray([0, bad.size], np.uint64), fold=True)
     assert L.gft_last_nonascii(eng._h) == 1
+
+
+def test_config5_100k_terms_with_regex_leaves(scan_kernel):
+    """BASELINE configs[4]: 100 000 terms (the large automaton: second-level filter and tables spill from LDS to L2, ~1 200
+    matches per document, the solver's presence matrix at 8 documents per group) + r"..." regex terms through the host
+    RegexpEngine (finder/regexEngine.go:36-47), CSR and bitmap against the oracle."""
+    from gofindthem_amd.engine import Engine
+    from gofindthem_amd.finder import Finder, GpuEngine, PyRegexpEngine
+    from gofindthem_amd.workload import Workload, make_expressions
+    w = Workload(100_000)
+    terms = w.terms()
+    assert len(terms) == 100_000
+    text, off = w.docs_host(0, 260)
+    o = Oracle(terms)
+    e = Engine()
+    try:
+        e.build(terms)
+        assert e.n_states == o.n_states
+        got, want = e.scan(text, off, fold=True), o.scan(text, off, fold=True)
+        assert_csr_equal(got, want)
+        assert want[1].size > 1000 * 260                  # > 1 000 matches per document
+        mo, ti, _ = e.scan(text, off, fold=True, unique=True)
+        assert ti[:int(mo[1])].tolist() == list(dict.fromkeys(want[1][:int(want[0][1])].tolist()))
+    finally:
+        e.close()
+    # the finder: 100 k keywords in 3 000 expressions (INORD included), 16 regexes of the benchmark's r"wA.*wB" shape
+    rx = ["%s.*%s" % (terms[7 * i + 1].decode(), terms[11 * i + 5].decode()) for i in range(16)]
+    exprs = make_expressions(terms, 3000, inord_fraction=0.4, regexes=rx, cover=True)
+    f = Finder(GpuEngine(), PyRegexpEngine(), False)
+    try:
+        f.AddExpressions(exprs)
+        assert len(f.GetKeywords()) == 100_000 and len(f.GetRegexes()) == 16
+        bm = f.ProcessTexts(blob=text, doc_off=off)
+        kws = sorted(f.GetKeywords())
+        o2 = Oracle(kws)
+        o2.set_expressions(exprs, False)
+        reng = PyRegexpEngine()
+        reng.BuildEngine(sorted(f.GetRegexes()), False)
+        offs, lits, poss = [0], [], []
+        for d in range(260):
+            t = bytes(text[int(off[d]):int(off[d + 1])])
+            for m in reng.FindRegexes(t):
+                lits.append(o2.literals.index(m.Term))
+                poss.append(m.Position)
+            offs.append(len(lits))
+        extra = (np.asarray(offs, np.uint64), np.asarray(lits or [0], np.int32), np.asarray(poss or [0], np.int64))
+        want = o2.process(text, off, fold=True, extra=extra)
+        assert np.array_equal(bm, want) and bm.any()
+    finally:
+        f.close()

@@ -173,3 +173,41 @@ def test_json_string_decoding_matches_python():
         assert n == len(want)
         # lone surrogates become U+FFFD (3 bytes) in Go; Python keeps them as surrogates
         assert nbytes == sum(len(s.encode("utf-8", "replace").replace(b"?", b"\xef\xbf\xbd")) for s in want), raw
+
+
+def test_deeply_nested_json_on_a_small_stack():
+    """untrusted JSON, 9 999 levels deep (encoding/json allows 10 000), evaluated on a thread with a 256 KiB stack: the
+    parser, the teardown of the decoded value and the walk over it must not recurse per level"""
+    import ctypes as C
+    import threading
+    from gofindthem_amd import _lib
+    L = _lib.load()
+    deep = ("[" * 9999 + "]" * 9999).encode()
+    too_deep = ("[" * 10001 + "]" * 10001).encode()
+    out = {}
+
+    def run():
+        buf = C.create_string_buffer(1 << 16)
+        need = C.c_uint64(0)
+        out["ok"] = L.gft_group_dsl_parse(b'"a"', 3, buf, len(buf), C.byref(need))
+        # gft_to_lower etc. do not parse JSON; the group finder's evaluate entry point does
+        fh = C.c_void_p()
+        rc = L.gft_finder_create(C.byref(fh), 1, -1)
+        gh = C.c_void_p()
+        out["create"] = L.gft_group_create(C.byref(gh), fh)
+        out["deep"] = L.gft_group_evaluate(gh, deep, len(deep), buf, len(buf), C.byref(need))
+        out["deep_err"] = L.gft_group_last_error(gh)
+        out["too_deep"] = L.gft_group_evaluate(gh, too_deep, len(too_deep), buf, len(buf), C.byref(need))
+        out["too_deep_err"] = L.gft_group_last_error(gh)
+        L.gft_group_destroy(gh)
+        L.gft_finder_destroy(fh)
+        out["rc"] = rc
+    old = threading.stack_size(256 * 1024)
+    try:
+        t = threading.Thread(target=run)
+        t.start()
+        t.join()
+    finally:
+        threading.stack_size(old)
+    assert out["deep"] == _lib.GFT_E_INVALID and b"expected" in out["deep_err"]           # parsed, then refused as a tag map
+    assert out["too_deep"] == _lib.GFT_E_INVALID and b"exceeded max depth" in out["too_deep_err"]

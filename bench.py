@@ -9,7 +9,8 @@ over 1 M synthetic ~4 KB documents per GPU (BASELINE.json configs[2]; SURVEY.md 
 One "step" = one pass of the hot path over the rank's batch, inputs already resident in HBM:
 Finder.ProcessDevice = work-unit setup + Aho-Corasick scan kernel + CSR gather + solver kernel -> hit bitmap,
 plus (N > 1) one RCCL gather of every rank's bitmap to rank 0.  Documents are independent, so ranks own
-disjoint document ranges of the same size ("weak" scaling) and nothing else is exchanged.
+disjoint document ranges and nothing else is exchanged: --scaling strong (default, the configuration the metric is quoted
+on: 1 M documents in total, sharded across the N GPUs) or weak (1 M documents per GPU).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (scan kernel, live HIP-event
 timing) and `cpu_baseline` (the CPU oracle timed on this host, rank 0 / N=1 only).
@@ -29,7 +30,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--docs", type=int, default=1_000_000, help="documents per GPU")
+    ap.add_argument("--docs", type=int, default=1_000_000, help="documents: in total (--scaling strong) or per GPU (weak)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="strong (default): the configuration the metric is quoted on -- --docs documents in total, sharded "
+                         "across the GPUs (BASELINE.json configs[3]: 1 M documents across 8); weak: --docs documents per GPU")
     ap.add_argument("--terms", type=int, default=10_000)
     ap.add_argument("--exprs", type=int, default=1_000)
     ap.add_argument("--inord", type=float, default=0.0, help="fraction of INORD(...) expressions (config 4: 0.5)")
@@ -85,13 +89,21 @@ def main():
     eh = finder.engine_handle()
     stream = torch.cuda.current_stream().cuda_stream
     assert L.gft_set_stream(eh, stream) == 0
-    from gofindthem_amd.sharding import BitmapGather, all_ranks_ok, max_over_ranks, shard_range
-    first, _ = shard_range(rank, world, args.docs)
+    from gofindthem_amd.sharding import BitmapGather, all_ranks_ok, max_over_ranks, shard_range, split_docs
+    total_docs = args.docs if args.scaling == "strong" else args.docs * world
+    if args.scaling == "strong":
+        shards = split_docs(total_docs, world)       # contiguous document ranges (the synthetic documents are alike: equal
+        first, my_docs = shards[rank]                # counts are equal bytes; a real corpus is cut by bytes, gft_split_docs)
+        rows = max(n for _, n in shards)             # (gather buffers are equal-sized: the last shard may be one row short)
+    else:
+        first, my_docs = shard_range(rank, world, args.docs)
+        rows = my_docs
+    args.docs = my_docs                              # from here on: this rank's documents
     text, doc_off = wl.docs_device(first, args.docs, device=dev)
     words = (args.exprs + 31) // 32
     # two result buffers: the gather of batch i (the path's only exchange step, RCCL over xGMI) is in flight on the
     # process group's stream while batch i + 1 is scanned and solved; everything is complete before the closing fence
-    bitmaps = [torch.zeros((args.docs, words), dtype=torch.int32, device=dev) for _ in range(2 if world > 1 else 1)]
+    bitmaps = [torch.zeros((rows, words), dtype=torch.int32, device=dev) for _ in range(2 if world > 1 else 1)]
     bitmap = bitmaps[0]
     gather = BitmapGather(bitmaps)         # rank 0 receives every rank's bitmap
     text_bytes = int(text.numel())
@@ -196,7 +208,7 @@ def main():
     if rank == 0:
         scan_kernel = (L.gft_scan_kernel(eh) or b"").decode()
         kernel_names = {"scan2": "k_scan2 (suffix-window scan)", "scan3": "k_scan3 (stride-2 suffix-window scan)", "dfa": "k_scan_units (two-tier DFA)"}
-        docs_total = args.docs * world * args.steps
+        docs_total = total_docs * args.steps
         ms_per_step = elapsed / args.steps * 1e3
         # algorithmic bytes of the dominant (scan) kernel per launch: text once + one offset entry per document +
         # 8 bytes per match written
@@ -218,20 +230,21 @@ def main():
             pass
         out = {
             "metric": "ProcessText throughput: documents/s (and input GB/s), %d-term dictionary + %d expressions, "
-                      "%d docs of ~4 KB per GPU" % (args.terms, args.exprs, args.docs),
+                      "%d docs of ~4 KB %s" % (args.terms, args.exprs, total_docs if args.scaling == "strong" else args.docs,
+                                               "sharded over %d GPU(s)" % world if args.scaling == "strong" else "per GPU"),
             "value": docs_total / elapsed,
             "unit": "docs/s",
-            "input_GBps": text_bytes * world * args.steps / elapsed / 1e9,
+            "input_GBps": text_bytes * (total_docs / max(args.docs, 1)) * args.steps / elapsed / 1e9,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[2]: %d terms + %d %s expressions, %d docs x ~4 KB per GPU "
+            "config": {"workload": "BASELINE.json configs[2]: %d terms + %d %s expressions, %d docs x ~4 KB on this GPU "
                                    "(SURVEY.md 8(d) generator%s), case-insensitive finder, inputs resident in HBM"
                                    % (args.terms, args.exprs, "AND/OR/NOT" if args.inord == 0 else
                                       "AND/OR/NOT + %.0f%% INORD" % (args.inord * 100), args.docs,
                                       "" if args.alphabet == "lower" else ", MIXED alphabet: capitals, digits, punctuation, UTF-8 letters"),
                        "alphabet": args.alphabet, "keywords": n_keywords,
-                       "docs_per_gpu": args.docs, "text_bytes_per_gpu": text_bytes, "matches_per_gpu": n_matches,
+                       "docs_total": total_docs, "docs_per_gpu": args.docs, "text_bytes_per_gpu": text_bytes, "matches_per_gpu": n_matches,
                        "matches_per_doc": n_matches / args.docs, "matches_per_doc_max": hits_max,
                        "parallelism": "docs sharded x%d" % world},
             "roofline": {"bound": "hbm", "kernel": kernel_names.get(scan_kernel, scan_kernel), "achieved": achieved, "peak": 8000.0, "unit": "GB/s",

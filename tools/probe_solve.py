@@ -22,15 +22,15 @@ ap.add_argument("--modes", default="0,1,2,4,3,7")
 args = ap.parse_args()
 wl = Workload(args.terms)
 exprs = make_expressions(wl.terms(), args.exprs, inord_fraction=args.inord, cover=True)
-f = Finder(GpuEngine.__new__(GpuEngine), EmptyRgxEngine(), False)
-f.AddExpressions(exprs)
 L = _lib.load()
-eh = f.engine_handle()
-L.gft_set_stream(eh, torch.cuda.current_stream().cuda_stream)
 text, off = wl.docs_device(0, args.docs)
 bm = torch.zeros((args.docs, (args.exprs + 31) // 32), dtype=torch.int32, device="cuda")
 for mode in args.modes.split(","):
-    os.environ["GFT_SOLVE_DEBUG"] = mode
+    os.environ["GFT_SOLVE_DEBUG"] = mode          # (read when the engine is created / programs are set)
+    f = Finder(GpuEngine.__new__(GpuEngine), EmptyRgxEngine(), False)
+    f.AddExpressions(exprs)
+    eh = f.engine_handle()
+    L.gft_set_stream(eh, torch.cuda.current_stream().cuda_stream)
     f.ProcessDevice(text.data_ptr(), off.data_ptr(), args.docs, bm.data_ptr())
     L.gft_profile_enable(eh, 1)
     L.gft_profile_reset(eh)
@@ -43,3 +43,4 @@ for mode in args.modes.split(","):
         out.append("%s %.3f ms x%d" % (name.decode(), ms.value / max(n.value, 1), n.value))
     L.gft_profile_enable(eh, 0)
     print("GFT_SOLVE_DEBUG=%s  %s" % (mode, "  ".join(out)), flush=True)
+    f.close()

@@ -749,8 +749,10 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
                     if (base + nh <= KARG(pool_cap))
                         for (uint32_t i = lane; i < nh; i += 64) {
                             const uint2 r = fifo[i];
-                            KARG(pool_term)[base + i] = r.x;
-                            if (P.want_pos) KARG(pool_pos)[base + i] = r.y;
+                            // (streaming stores: the pool is read by the NEXT kernel, its lines should not push the units'
+                            // text out of L2 before the verification stages have re-read it)
+                            __builtin_nontemporal_store(r.x, &KARG(pool_term)[base + i]);
+                            if (P.want_pos) __builtin_nontemporal_store(r.y, &KARG(pool_pos)[base + i]);
                         }
                     done = true;
                 }

@@ -763,7 +763,7 @@ int solve_pipeline(gft_engine* e, uint64_t n_docs, const gft_extra_matches* d_ex
 // ---- compiled tables as one blob (BuildEngine for a large dictionary is paid once) -----------------
 namespace {
 constexpr uint32_t kTablesMagic = 0x54544647u;   // "GFTT"
-constexpr uint32_t kTablesVersion = 7;           // bump when a table layout or a hash function changes
+constexpr uint32_t kTablesVersion = 8;           // bump when a table layout or a hash function changes
 
 struct Writer {
     std::vector<uint8_t> b;

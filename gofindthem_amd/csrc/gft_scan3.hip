@@ -194,60 +194,54 @@ __device__ __forceinline__ uint32_t match_pos(const Scan3Params& P, uint32_t p, 
 }
 
 // does the anchor described by e have its window end at p (and the term its end inside the unit)?  t = the (folded) bytes
-// in front of the window, w = the (folded) window, tl = the raw bytes behind it.  kmax: dwords of `front` to look at
+// in front of the window, w = the (folded) window, tl = the raw bytes behind it.  kmax: dwords of `front` to look at.
+// Slot layout (scan3_tables.cpp make_slot): a = {key, info, len, front[0]}, b = {front[1], front[2], front[3] or tail, window}
 __device__ __forceinline__ bool entry_ok(const Ctx& c, uint32_t p, const Front& t, uint32_t w, uint32_t tl, const Slot& e, uint32_t kmax) {
     const Scan3Params& P = c.P;
     const uint32_t L = e.a.z & kScan2LenMask;          // the term up to the end of its window
     const int32_t off = slot_off(e.a.z);
     const int32_t nfront = (int32_t)L - 4;
-    uint32_t diff = 0;
+    // the window's own bytes (the key names their filter groups only); a window with off = -1 holds three term bytes
+    uint32_t diff = (w ^ e.b.w) & (off < 0 ? 0x00FFFFFFu : 0xFFFFFFFFu);
 #pragma unroll
-    for (int k = 0; k < 5; k++) {
+    for (int k = 0; k < 4; k++) {
         if ((uint32_t)k < kmax) {
             int32_t nb = min(max(nfront - 4 * k, 0), 4);                           // bytes of this dword the term owns
-            if (k == 4 && off > 0) nb = 0;                                         // front[4] holds the tail instead
+            if (k == 3 && off > 0) nb = 0;                                         // front[3] holds the tail instead
             const uint32_t mask = (uint32_t)(0xFFFFFFFF00000000ull >> (8 * nb));   // ... the ones next to the window
-            const uint32_t fk = k == 0 ? e.a.w : k == 1 ? e.b.x : k == 2 ? e.b.y : k == 3 ? e.b.z : e.b.w;
+            const uint32_t fk = k == 0 ? e.a.w : k == 1 ? e.b.x : k == 2 ? e.b.y : e.b.z;
             diff |= (t.f[k] ^ fk) & mask;
         }
     }
     if (off > 0) {
         const uint32_t tv = P.fold ? fold4(tl) : tl;
-        diff |= (tv ^ e.b.w) & (0xFFFFFFFFu >> (8 * (4 - off)));
+        diff |= (tv ^ e.b.z) & (0xFFFFFFFFu >> (8 * (4 - off)));
     }
     const uint32_t pe = p + (uint32_t)off;                                         // where the term ends
     bool ok = L <= p + 1 && diff == 0 && pe >= c.lo && pe < c.hi;
-    const uint32_t inl = off > 0 ? kScan2InlineLen - 4 : kScan2InlineLen;
-    if (ok && (L > inl || P.grouped)) {
+    const uint32_t inl = off > 0 ? 16u : 20u;                                      // bytes the slot holds (window included)
+    if (ok && L > inl) {
+        // the first L-inl bytes of the term against text[p+1-L .. p-inl], four bytes at a time from the end; term_blob
+        // carries 4 bytes of slack in front of every term, the text side needs 3 bytes of slack before the match
         const uint8_t* tb = KARG(term_blob) + KARG(term_off)[e.a.y];
-        if (P.grouped) {
-            // merged groups: the key does not prove the window's bytes (a window with off = -1 holds three term bytes)
-            const uint32_t nwin = off < 0 ? 3u : 4u;
-            const uint32_t wt = load_u32_unaligned(tb + L - 4);
-            ok = ((w ^ wt) & (0xFFFFFFFFu >> (8 * (4 - nwin)))) == 0;
-        }
-        if (ok && L > inl) {
-            // the first L-inl bytes of the term against text[p+1-L .. p-inl], four bytes at a time from the end; term_blob
-            // carries 4 bytes of slack in front of every term, the text side needs 3 bytes of slack before the match
-            const uint8_t* tp = c.dbase + (int64_t)p + 1 - L;
-            const uint32_t n = L - inl;
-            if (c.doc_abs + p + 1 - L >= 3) {
-                uint32_t d2 = 0;
-                for (uint32_t j = 0; j * 4 < n; j++) {
-                    const int32_t at = (int32_t)n - 4 - (int32_t)(j * 4);       // may be -1..-3 for the last chunk
-                    uint32_t tv = load_u32_unaligned(tp + at);
-                    const uint32_t wv = load_u32_unaligned(tb + at);
-                    if (P.fold) tv = fold4(tv);
-                    const uint32_t mask = at >= 0 ? 0xFFFFFFFFu : 0xFFFFFFFFu << (8 * (uint32_t)(-at));
-                    d2 |= (tv ^ wv) & mask;
-                }
-                ok = d2 == 0;
-            } else {
-                for (uint32_t i = 0; i < n && ok; i++) {
-                    uint32_t b = tp[i];
-                    if (P.fold) b = fold1(b);
-                    ok = b == tb[i];
-                }
+        const uint8_t* tp = c.dbase + (int64_t)p + 1 - L;
+        const uint32_t n = L - inl;
+        if (c.doc_abs + p + 1 - L >= 3) {
+            uint32_t d2 = 0;
+            for (uint32_t j = 0; j * 4 < n; j++) {
+                const int32_t at = (int32_t)n - 4 - (int32_t)(j * 4);       // may be -1..-3 for the last chunk
+                uint32_t tv = load_u32_unaligned(tp + at);
+                const uint32_t wv = load_u32_unaligned(tb + at);
+                if (P.fold) tv = fold4(tv);
+                const uint32_t mask = at >= 0 ? 0xFFFFFFFFu : 0xFFFFFFFFu << (8 * (uint32_t)(-at));
+                d2 |= (tv ^ wv) & mask;
+            }
+            ok = d2 == 0;
+        } else {
+            for (uint32_t i = 0; i < n && ok; i++) {
+                uint32_t b = tp[i];
+                if (P.fold) b = fold1(b);
+                ok = b == tb[i];
             }
         }
     }
@@ -256,11 +250,11 @@ __device__ __forceinline__ bool entry_ok(const Ctx& c, uint32_t p, const Front& 
 
 // dwords of front bytes a term of length L owns (0 for lanes that are not active)
 __device__ __forceinline__ uint32_t wave_kmax(uint32_t L) {
-    return __any(L > 20) ? 5 : __any(L > 16) ? 4 : __any(L > 12) ? 3 : __any(L > 8) ? 2 : 1;
+    return __any(L > 16) ? 4 : __any(L > 12) ? 3 : __any(L > 8) ? 2 : 1;
 }
 __device__ __forceinline__ void front_fold_upto(Front& t, uint32_t& done, uint32_t kmax) {
 #pragma unroll
-    for (int k = 0; k < 5; k++)
+    for (int k = 0; k < 4; k++)
         if ((uint32_t)k >= done && (uint32_t)k < kmax) t.f[k] = fold4(t.f[k]);
     done = kmax > done ? kmax : done;
 }

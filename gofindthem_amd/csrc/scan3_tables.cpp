@@ -15,17 +15,23 @@ constexpr int kMaxOff3 = (int)kScan2MaxOff;
 
 struct Ent { uint32_t term_id, len1; int off; };   // len1 = length up to the end of the window = L - off
 
-// a bucket-table slot for the anchor (len1, off) of term s, scan2's layout: front[k] = text[p-7-4k .. p-4-4k] under the
-// term, front[4] = the bytes behind the window when off > 0
+// a bucket-table slot for the anchor (len1, off) of term s.  The 20 bytes behind the header: front[k] = the term's bytes
+// under text[p-7-4k .. p-4-4k] for k = 0..2 (3: as well, unless off > 0: then front[3] = the bytes behind the window,
+// text[p+1 ..]), and front[4] = the window's own bytes text[p-3 .. p] -- under merged filter groups the key does not prove
+// them.  A term up to 20 bytes (16 when shifted) is compared without leaving the slot.
 Scan2Slot make_slot(uint32_t key, const Ent& e, const std::string& s) {
     const int L = (int)e.len1;
     Scan2Slot r{key, e.term_id, e.len1 | (uint32_t)(uint8_t)(int8_t)e.off << 24, {0, 0, 0, 0, 0}};
-    for (int k = 0; k < (e.off > 0 ? 4 : 5); k++)
+    for (int k = 0; k < (e.off > 0 ? 3 : 4); k++)
         for (int b = 0; b < 4; b++) {
             const int idx = L - 8 - 4 * k + b;             // term byte under text[p-7-4k+b]
             if (idx >= 0) r.front[k] |= (uint32_t)(uint8_t)s[(size_t)idx] << (8 * b);
         }
-    for (int b = 0; b < e.off; b++) r.front[4] |= (uint32_t)(uint8_t)s[(size_t)(L + b)] << (8 * b);   // text[p+1+b]
+    for (int b = 0; b < e.off; b++) r.front[3] |= (uint32_t)(uint8_t)s[(size_t)(L + b)] << (8 * b);   // text[p+1+b]
+    for (int b = 0; b < 4; b++) {
+        const int idx = L - 4 + b;                         // term byte under text[p-3+b]; past the term's end (off = -1): free
+        if (idx >= 0 && idx < (int)s.size()) r.front[4] |= (uint32_t)(uint8_t)s[(size_t)idx] << (8 * b);
+    }
     return r;
 }
 
@@ -290,15 +296,15 @@ bool entry_ok_host(const Scan3Tables& t, const Scan2Slot& e, const uint8_t* text
     const uint32_t start = p + 1 - L1;
     if ((uint64_t)start + L > n) return false;
     for (uint32_t i = 0; i < L; i++) if (foldb(text[start + i], fold) != tb[i]) return false;
-    // the inline copy must agree with the blob (checks make_slot): front bytes and tail
+    // the inline copy must agree with the blob (checks make_slot): front bytes, tail and window
     const int nfront = (int)L1 - 4;
-    for (int k = 0; k < (off > 0 ? 4 : 5); k++)
+    for (int k = 0; k < (off > 0 ? 3 : 4); k++)
         for (int b = 0; b < 4; b++) {
             const int idx = (int)L1 - 8 - 4 * k + b;
-            const uint8_t want = idx >= 0 && idx < (int)L1 - 4 ? tb[idx] : 0;
-            if (idx >= 0 && idx < nfront && (uint8_t)(e.front[k] >> (8 * b)) != want) return false;
+            if (idx >= 0 && idx < nfront && (uint8_t)(e.front[k] >> (8 * b)) != tb[idx]) return false;
         }
-    for (int b = 0; b < off; b++) if ((uint8_t)(e.front[4] >> (8 * b)) != tb[L1 + (uint32_t)b]) return false;
+    for (int b = 0; b < off; b++) if ((uint8_t)(e.front[3] >> (8 * b)) != tb[L1 + (uint32_t)b]) return false;
+    for (int b = 0; b < (off < 0 ? 3 : 4); b++) if ((uint8_t)(e.front[4] >> (8 * b)) != tb[L1 - 4 + (uint32_t)b]) return false;
     return true;
 }
 }  // namespace

@@ -59,12 +59,16 @@ __global__ void __launch_bounds__(256) k_doc_fill(uint64_t base_seed, uint64_t f
 // achievable-read ceiling: every lane sums 16-byte loads of a grid-strided slice of the buffer ("a
 // trivial coalesced sum-reduction kernel over the same blob")
 __global__ void __launch_bounds__(256) k_read_sum(const uint4* __restrict__ p, uint64_t n16, uint64_t* __restrict__ out) {
+    // eight 16-byte loads in flight per lane, each wave instruction one contiguous KiB
     uint64_t acc = 0;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-        const uint4 a = p[i], b = p[i + stride], c = p[i + 2 * stride], d = p[i + 3 * stride];
-        acc += (uint64_t)a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w + c.x + c.y + c.z + c.w + d.x + d.y + d.z + d.w;
+    for (; i + 7 * stride < n16; i += 8 * stride) {
+        uint4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = p[i + k * stride];
+#pragma unroll
+        for (int k = 0; k < 8; k++) acc += (uint64_t)v[k].x + v[k].y + v[k].z + v[k].w;
     }
     for (; i < n16; i += stride) { const uint4 a = p[i]; acc += (uint64_t)a.x + a.y + a.z + a.w; }
     for (int s = 32; s; s >>= 1) acc += __shfl_xor(acc, s, 64);

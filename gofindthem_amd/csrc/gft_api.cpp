@@ -172,6 +172,14 @@ struct DeviceGuard {
     ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
+// Entry points that hand host memory (the caller's buffers, or temporaries of their own) to asynchronous copies: whatever
+// path they leave by -- an error in the middle included -- the stream has drained before that memory can go away.
+struct SyncOnExit {
+    gft_engine* e;
+    explicit SyncOnExit(gft_engine* e_) : e(e_) {}
+    ~SyncOnExit() { if (e->device >= 0 && e->stream) (void)hipStreamSynchronize(e->stream); }
+};
+
 struct ProfScope {
     gft_engine* e;
     hipEvent_t a = nullptr, b = nullptr;
@@ -387,6 +395,7 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
     const bool host_units = h_doc_off != nullptr && n_docs <= kHostUnitDocs;
     std::vector<uint64_t> hub;
     std::vector<Unit> hun;
+    struct DrainIf { gft_engine* e; bool on; ~DrainIf() { if (on && e->stream) (void)hipStreamSynchronize(e->stream); } } drain_units{e, host_units};
     if (host_units) {
         hub.assign(n_docs + 1, 0);
         for (uint64_t d = 0; d < n_docs; d++) {
@@ -960,7 +969,8 @@ static int install_tables(gft_engine* e, uint32_t flags) {
     size_t rows = (e->lds_max - fixed) / ((size_t)e->tab.n_classes * 4);
     e->n_lds_states = (uint32_t)std::min<size_t>(rows, e->tab.n_states);
 
-    std::vector<uint8_t> bc(e->tab.byte_class, e->tab.byte_class + 256);
+    std::vector<uint8_t> bc(e->tab.byte_class, e->tab.byte_class + 256), c1, c2, g1, g2, s3v;
+    SyncOnExit drained(e);                              // (declared behind the temporaries the uploads read from: it goes first)
     int rc;
     if ((rc = upload(e, e->d_byte_class, bc, "table upload"))) return rc;
     if ((rc = upload(e, e->d_delta, e->tab.delta, "table upload"))) return rc;
@@ -984,7 +994,7 @@ static int install_tables(gft_engine* e, uint32_t flags) {
     e->use_scan3 = k3_fits && forced != "dfa" && forced != "scan2" && (forced == "scan3" || !e->use_scan2);
     if (e->use_scan3) {
         if ((rc = upload(e, e->d_s3_filter, e->s3.filter, "table upload"))) return rc;
-        std::vector<uint8_t> s3v = e->s3.short3;
+        s3v = e->s3.short3;
         if (s3v.empty()) s3v.assign(16, 0);
         if ((rc = upload(e, e->d_s3_short3, s3v, "table upload"))) return rc;
         if ((rc = upload(e, e->d_s3_srec, e->s3.srec, "table upload"))) return rc;
@@ -995,7 +1005,7 @@ static int install_tables(gft_engine* e, uint32_t flags) {
         if ((rc = upload(e, e->d_s3_more, e->s3.more, "table upload"))) return rc;
         if ((rc = upload(e, e->d_s3_term_blob, e->s3.term_blob, "table upload"))) return rc;
         if ((rc = upload(e, e->d_s3_term_off, e->s3.term_off, "table upload"))) return rc;
-        std::vector<uint8_t> g1(e->s3.cls, e->s3.cls + 256), g2(e->s3.cls_fold, e->s3.cls_fold + 256);
+        g1.assign(e->s3.cls, e->s3.cls + 256); g2.assign(e->s3.cls_fold, e->s3.cls_fold + 256);
         if ((rc = upload(e, e->d_s3_cls, g1, "table upload"))) return rc;
         if ((rc = upload(e, e->d_s3_cls_fold, g2, "table upload"))) return rc;
         HIP_TRY(hipStreamSynchronize(e->stream), "table upload");      // g1 / g2 / s3v are locals
@@ -1021,7 +1031,7 @@ static int install_tables(gft_engine* e, uint32_t flags) {
         if ((rc = upload(e, e->d_s2_shorts_packed, e->s2.shorts_packed, "table upload"))) return rc;
         if (!e->s2.short3_big.empty() && (rc = upload(e, e->d_s2_short3_big, e->s2.short3_big, "table upload"))) return rc;
         if ((rc = upload(e, e->d_s2_fpt, e->s2.fpt, "table upload"))) return rc;
-        std::vector<uint8_t> c1(e->s2.cls, e->s2.cls + 256), c2(e->s2.cls_fold, e->s2.cls_fold + 256);
+        c1.assign(e->s2.cls, e->s2.cls + 256); c2.assign(e->s2.cls_fold, e->s2.cls_fold + 256);
         if ((rc = upload(e, e->d_s2_cls, c1, "table upload"))) return rc;
         if ((rc = upload(e, e->d_s2_cls_fold, c2, "table upload"))) return rc;
         if ((rc = upload(e, e->d_s2_filter, e->s2.filter, "table upload"))) return rc;
@@ -1238,6 +1248,7 @@ int gft_scan(gft_engine* e, const uint8_t* text_blob, const uint64_t* doc_off, u
     if (e->device < 0) return fail(e, GFT_E_HIP, "no HIP device available");
     if (!e->built) return fail(e, GFT_E_NOT_BUILT, "gft_build has not been called");
     DeviceGuard g(e->device);
+    SyncOnExit drained(e);      // host buffers are read by asynchronous copies: drained on every way out
     int rc = stage_docs(e, text_blob, doc_off, n_docs);
     if (rc) return rc;
     uint64_t nm = 0;
@@ -1274,6 +1285,7 @@ int gft_set_programs(gft_engine* e, const uint32_t* prog_words, const uint64_t* 
         if (rc) return rc;
     }
     DeviceGuard g(e->device);
+    SyncOnExit drained(e);      // host buffers are read by asynchronous copies: drained on every way out
     std::vector<uint32_t> w(prog_words, prog_words + (n_exprs ? prog_off[n_exprs] : 0));
     std::vector<uint64_t> o(prog_off, prog_off + (n_exprs ? n_exprs + 1 : 0));
     if (o.empty()) o.push_back(0);
@@ -1414,6 +1426,7 @@ int gft_process_again(gft_engine* e, uint64_t n_docs, const gft_extra_matches* e
     if (!e->built || !e->have_programs) return fail(e, GFT_E_NOT_BUILT, "engine not ready");
     if (e->scan_valid_docs != n_docs || !n_docs) return fail(e, GFT_E_INVALID, "gft_process_again: no scan of these documents to reuse");
     DeviceGuard g(e->device);
+    SyncOnExit drained(e);      // host buffers are read by asynchronous copies: drained on every way out
     gft_extra_matches dx;
     const gft_extra_matches* pdx = nullptr;
     int rc = upload_extra(e, extra, n_docs, dx, pdx);
@@ -1438,6 +1451,7 @@ int gft_process(gft_engine* e, const uint8_t* text_blob, const uint64_t* doc_off
     if (!e->built) return fail(e, GFT_E_NOT_BUILT, "gft_build has not been called");
     if (!e->have_programs) return fail(e, GFT_E_NOT_BUILT, "gft_set_programs has not been called");
     DeviceGuard g(e->device);
+    SyncOnExit drained(e);      // host buffers are read by asynchronous copies: drained on every way out
     int rc = stage_docs(e, text_blob, doc_off, n_docs);
     if (rc) return rc;
     gft_extra_matches dx;

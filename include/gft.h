@@ -118,6 +118,9 @@ int gft_scan_device(gft_engine* e, const uint8_t* d_text_blob, const uint64_t* d
 #define GFT_INORD_FLAG (1u << 27)
 #define GFT_SLOT_MASK ((1u << 27) - 1u)
 
+/* Limits of the device solver that the reference does not have (GFT_E_UNSUPPORTED, the message names the expression):
+ * an INORD group with more than 64 leaves-with-thresholds alive at once or nested deeper than 32, an operand stack deeper
+ * than 128 (left-deep chains of any length are fine: they need no stack), keywords longer than 7 424 bytes (gft_build). */
 int gft_set_programs(gft_engine* e, const uint32_t* prog_words, const uint64_t* prog_off, uint32_t n_exprs,
                      uint32_t n_extra);
 uint32_t gft_n_exprs(const gft_engine* e);

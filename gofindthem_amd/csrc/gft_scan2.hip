@@ -152,6 +152,7 @@ __device__ __forceinline__ Text8 cand_load(const Ctx& c, uint32_t p) {
     return Text8{v.lo, v.hi};
 }
 // window key, bucket hash and the short-term record id
+template <bool WANT_SID = true>
 __device__ __forceinline__ void cand_keys(const Ctx& c, uint32_t p, const Text8 t, Cand& k) {
     const uint32_t kp = c.P.kp, w = t.w;
     k.p = p;
@@ -161,7 +162,7 @@ __device__ __forceinline__ void cand_keys(const Ctx& c, uint32_t p, const Text8 
     const uint32_t x3 = mad24s(c1, c.kp2, lo);
     k.x = mad24s(mad24s(c0, kp, c1), c.kp2, lo);
     k.x3 = x3;
-    k.sid = c.short3 ? c.short3[x3] : 0;
+    k.sid = WANT_SID && c.short3 ? c.short3[x3] : 0;      // (stage B has no use for the short-term record: one LDS probe less)
 }
 // LDS-only decision: can a term of length >= 4 end here at all (fingerprint of the bytes in front of the window)?
 // Most flagged positions stop here without touching L2.
@@ -721,7 +722,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
                         const Front fr = front_load(c, p, t8.tw);
                         const uint32_t tl = tail_load(c, p);
                         Cand k;
-                        cand_keys(c, p, t8, k);
+                        cand_keys<false>(c, p, t8, k);
                         const Slot s0 = slot_load(&P.slots[scan2_slot_hash(k.x, 0, P.slot_shift, P.slot_seed)]);
                         const Slot s1 = slot_load(&P.slots[scan2_slot_hash(k.x, 1, P.slot_shift, P.slot_seed)]);
                         finish_long(c, on, rel, k, s0, s1, fr, tl, fifo, nf, dfr);

@@ -113,11 +113,13 @@ struct gft_engine {
     uint32_t n_exprs = 0, n_extra = 0;
     DevBuf d_prog, d_prog_off;            // public postfix words (INORD group subtrees are read from these)
     DevBuf d_fprog, d_fprog_off, d_groups; // fused internal form + INORD group table
-    DevBuf d_order, d_blk_deep;            // evaluation order of the programs (gft_set_programs)
+    DevBuf d_solve_dbg;                    // GFT_SOLVE_DEBUG & 8: phase clocks
+    DevBuf d_order, d_blk_class, d_wave_blk;            // evaluation order of the programs (gft_set_programs)
     uint32_t last_solve_group_docs = 64;   // documents per solver group of the last launch (0 = presence matrix in HBM)
     DevBuf d_fprog_t, d_fblk_off;          // fused programs per sorted block of 64, transposed (read when they do not fit LDS)
     uint32_t fprog_words = 0;
     uint32_t n_inord_groups = 0;           // fused INORD ops: 0 = the solver never reads positions
+    uint32_t n_rare_words = 0;             // fused NOT + INORD ops: 0 = the solver variant without their slow path
     DevBuf d_pscratch;                    // HBM presence matrices when n_slots * 8 B does not fit LDS
 
     // workspace
@@ -286,15 +288,30 @@ uint32_t fuse_program(const uint32_t* w, uint64_t len, uint64_t gbase, std::vect
         }
     }
     if (st.empty()) return 0;
+    const size_t out0 = out.size();
     // Code generation with an explicit job stack (left-deep chains of 10 000 leaves must not recurse).
     //  * NOT is pushed down to the leaves (De Morgan; every node is evaluated anyway, the reference does not
     //    short-circuit), so it only survives on top of an INORD group;
     //  * AND / OR commute: the operand that is a leaf goes second and folds into the operator word;
-    //  * the accumulator is pushed only between two operands that are both subtrees.
+    //  * the accumulator is pushed only between two operands that are both subtrees -- and of those the one that needs
+    //    the deeper stack goes FIRST (Sethi-Ullman), so a chain of parentheses nested to the right stays one entry deep
+    //    and only a balanced tree of 2^k subtrees gets k deep: real rule sets fit the interpreter's register stack.
     auto strip = [&](int64_t n, bool& neg) {        // skip NOT chains
         while (nodes[n].op == GFT_OP_NOT) { neg = !neg; n = nodes[n].l; }
         return n;
     };
+    std::vector<uint32_t> need(nodes.size(), 0);    // stack entries the subtree's code needs (children come before parents)
+    for (size_t n = 0; n < nodes.size(); n++) {
+        const Node& nd = nodes[n];
+        bool dummy = false;
+        if (nd.op == GFT_OP_NOT || nd.op == GFT_OP_INORD) need[n] = need[nd.l];
+        else if (nd.op == GFT_OP_AND || nd.op == GFT_OP_OR) {
+            const int64_t l = strip(nd.l, dummy), r = strip(nd.r, dummy);
+            if (nodes[r].op == GFT_OP_UNIT) need[n] = need[nd.l];
+            else if (nodes[l].op == GFT_OP_UNIT) need[n] = need[nd.r];
+            else need[n] = need[nd.l] == need[nd.r] ? need[nd.l] + 1 : std::max(need[nd.l], need[nd.r]);
+        }
+    }
     struct Job { int64_t n; int phase; bool neg; };
     std::vector<Job> jobs{{st.back(), 0, false}};
     uint32_t depth = 0, max_depth = 0;
@@ -329,8 +346,9 @@ uint32_t fuse_program(const uint32_t* w, uint64_t len, uint64_t gbase, std::vect
                 if (nodes[r].op == GFT_OP_UNIT) { jobs.push_back({n, 1, neg}); jobs.push_back({nd.l, 0, neg}); }
                 else if (nodes[l].op == GFT_OP_UNIT) { jobs.push_back({n, 2, neg}); jobs.push_back({nd.r, 0, neg}); }
                 else {
-                    jobs.push_back({n, 4, neg}); jobs.push_back({nd.r, 0, neg});
-                    jobs.push_back({n, 3, neg}); jobs.push_back({nd.l, 0, neg});
+                    const bool left_first = need[nd.l] >= need[nd.r];
+                    jobs.push_back({n, 4, neg}); jobs.push_back({left_first ? nd.r : nd.l, 0, neg});
+                    jobs.push_back({n, 3, neg}); jobs.push_back({left_first ? nd.l : nd.r, 0, neg});
                 }
             } else if (j.phase == 1 || j.phase == 2) {
                 bool ln = neg;
@@ -349,6 +367,16 @@ uint32_t fuse_program(const uint32_t* w, uint64_t len, uint64_t gbase, std::vect
             break;
         }
     }
+    // a push is always followed by the first leaf of the next subtree: one word does both
+    size_t k = out0;
+    for (size_t i = out0; i < out.size(); i++) {
+        const uint32_t op = out[i] >> 28, nx = i + 1 < out.size() ? out[i + 1] >> 28 : 0u;
+        if (op == kFopPush && (nx == kFopSet || nx == kFopSetN)) {
+            out[k++] = (nx == kFopSet ? kFopPushSet : kFopPushSetN) << 28 | (out[i + 1] & 0x0FFFFFFFu);
+            i++;
+        } else out[k++] = out[i];
+    }
+    out.resize(k);
     return max_depth;
 }
 
@@ -726,7 +754,7 @@ int solve_pipeline(gft_engine* e, uint64_t n_docs, const gft_extra_matches* d_ex
     S.doc_unit_base = e->d_unit_base.as<uint64_t>();
     S.unit_start = e->d_unit_start.as<uint64_t>(); S.unit_count = e->d_unit_count.as<uint32_t>();
     S.units = e->d_units.as<Unit>();
-    S.has_inord = e->n_inord_groups > 0 ? 1u : 0u;
+    S.has_rare = e->n_rare_words > 0 ? 1u : 0u;
     S.term = e->d_pool_term.as<uint32_t>(); S.pos = e->d_pool_pos.as<uint32_t>();
     S.x_off = d_extra ? d_extra->off : nullptr;
     S.x_slot = d_extra ? d_extra->slot : nullptr;
@@ -734,7 +762,7 @@ int solve_pipeline(gft_engine* e, uint64_t n_docs, const gft_extra_matches* d_ex
     S.n_docs = n_docs;
     S.fprog = e->d_fprog.as<uint32_t>(); S.fprog_off = e->d_fprog_off.as<uint64_t>();
     S.gprog = e->d_prog.as<uint32_t>(); S.groups = e->d_groups.as<uint32_t>();
-    S.order = e->d_order.as<uint32_t>(); S.blk_deep = e->d_blk_deep.as<uint32_t>();
+    S.order = e->d_order.as<uint32_t>(); S.blk_class = e->d_blk_class.as<uint32_t>(); S.wave_blk = e->d_wave_blk.as<uint32_t>();
     S.fprog_t = e->d_fprog_t.as<uint32_t>(); S.fblk_off = e->d_fblk_off.as<uint32_t>();
     S.n_exprs = e->n_exprs;
     S.n_slots = (uint32_t)e->tab.terms.size() + e->n_extra + 1;
@@ -742,6 +770,12 @@ int solve_pipeline(gft_engine* e, uint64_t n_docs, const gft_extra_matches* d_ex
     S.bitmap = d_bitmap;
     S.p_scratch = nullptr;
     S.dbg = e->opt_solve_dbg;
+    S.dbg_out = nullptr;
+    if (S.dbg & 8) {
+        HIP_TRY(e->d_solve_dbg.ensure(128 * 8), "debug alloc");
+        HIP_TRY(hipMemsetAsync(e->d_solve_dbg.p, 0, 128 * 8, e->stream), "memset");
+        S.dbg_out = e->d_solve_dbg.as<unsigned long long>();
+    }
     // Presence matrix in LDS next to the output tile: G documents per group = G / 8 bytes per slot, the widest G of
     // 64 / 32 / 16 / 8 that fits (GFT_SOLVE_GROUP_DOCS forces one, for tests); beyond that in HBM (served by L2), G = 64
     S.fprog_words = e->fprog_words;
@@ -764,6 +798,19 @@ int solve_pipeline(gft_engine* e, uint64_t n_docs, const gft_extra_matches* d_ex
     e->last_solve_group_docs = p_in_lds ? group_docs : 0;
     ProfScope ps(e, "solve");
     HIP_TRY(launch_solve(S, group_docs, p_in_lds, prog_in_lds, grid, e->stream), "solve kernel launch");
+    if (S.dbg & 8) {
+        // phase clocks: cycles per group and wave (0 build, 1 barrier, 2 evaluation, 3 barrier, 4 transpose + wipe, 5 barrier,
+        // 6 bitmap rows, 7 loop head), averaged over the workgroups
+        unsigned long long t[128];
+        HIP_TRY(hipMemcpyAsync(t, e->d_solve_dbg.p, sizeof t, hipMemcpyDeviceToHost, e->stream), "debug read-back");
+        HIP_TRY(hipStreamSynchronize(e->stream), "debug read-back");
+        fprintf(stderr, "[gft solve debug] cycles per group: wave | build bar eval bar transpose bar rows head\n");
+        for (int w = 0; w < 16; w++) {
+            fprintf(stderr, "[gft solve debug] %2d |", w);
+            for (int ph = 0; ph < 8; ph++) fprintf(stderr, " %7.0f", (double)t[w * 8 + ph] / (double)n_groups);
+            fprintf(stderr, "\n");
+        }
+    }
     return GFT_OK;
 }
 
@@ -918,7 +965,7 @@ void gft_engine_destroy(gft_engine* e) {
         for (auto& kv : e->prof)
             for (auto& p : kv.second.ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
         DevBuf* all[] = {&e->d_byte_class, &e->d_delta, &e->d_out_term, &e->d_out_link, &e->d_term_len, &e->d_prog,
-                         &e->d_prog_off, &e->d_fprog, &e->d_fprog_off, &e->d_groups, &e->d_order, &e->d_blk_deep, &e->d_fprog_t, &e->d_fblk_off, &e->d_pscratch, &e->d_s2_filter,
+                         &e->d_prog_off, &e->d_fprog, &e->d_fprog_off, &e->d_groups, &e->d_order, &e->d_blk_class, &e->d_wave_blk, &e->d_fprog_t, &e->d_fblk_off, &e->d_pscratch, &e->d_solve_dbg, &e->d_s2_filter,
                          &e->d_s2_slots, &e->d_s2_more, &e->d_s2_cls, &e->d_s2_cls_fold, &e->d_s2_term_blob,
                          &e->d_s2_term_off, &e->d_ctl, &e->d_dbg, &e->d_s2_short3, &e->d_s2_shorts_packed, &e->d_s2_short3_big, &e->d_s2_fpt,
                          &e->d_s3_filter, &e->d_s3_short3, &e->d_s3_srec, &e->d_s3_short3_big, &e->d_s3_srec_big, &e->d_s3_bloom, &e->d_s3_slots,
@@ -1278,7 +1325,7 @@ int gft_set_programs(gft_engine* e, const uint32_t* prog_words, const uint64_t* 
     if (e->device < 0) return fail(e, GFT_E_HIP, "no HIP device available");
     if (!e->built) return fail(e, GFT_E_NOT_BUILT, "gft_build has not been called");
     const uint32_t n_slots = (uint32_t)e->tab.terms.size() + n_extra;
-    if (n_slots > GFT_SLOT_MASK) return fail(e, GFT_E_UNSUPPORTED, "too many slots");
+    if (n_slots > GFT_SLOT_MASK || n_slots > (1u << kDwFieldBits)) return fail(e, GFT_E_UNSUPPORTED, "too many slots");
     for (uint32_t i = 0; i < n_exprs; i++) {
         if (prog_off[i + 1] < prog_off[i]) return fail(e, GFT_E_INVALID, "prog_off is not ascending");
         int rc = check_program(e, prog_words + prog_off[i], prog_off[i + 1] - prog_off[i], n_slots, i);
@@ -1299,41 +1346,74 @@ int gft_set_programs(gft_engine* e, const uint32_t* prog_words, const uint64_t* 
         while (fw.size() % 4) fw.push_back((uint32_t)kFopNop << 28);       // the interpreter reads 4-word chunks
         fo.push_back(fw.size());
     }
-    // Evaluation order: inside every output tile (kSolveTileWords * 32 expressions) the programs are sorted by
-    // length, longest first, and handed to the waves 64 at a time, so the lanes of a wave run loops of similar
-    // length; programs that nest deeper than the interpreter's register stack come first (their blocks take the
-    // general interpreter).  order[i] = expression evaluated at sorted position i; blk_deep[b] = block b needs it.
-    std::vector<uint32_t> order(n_exprs), blk_deep, fprog_t, fblk_off;
+    // Evaluation order: inside every output tile (kSolveTileWords * 32 expressions) the programs are sorted by the
+    // interpreter they need -- 2: nest deeper than its register stack, 1: use the stack, 0: flat (no push / pop at all,
+    // half the work per word) -- and by length, and handed to the waves 64 at a time, so that the lanes of a wave run
+    // loops of similar length on the cheapest interpreter that serves them all (longest first inside classes 2 and 1,
+    // shortest first inside class 0: the block on the border mixes short programs of both).
+    // order[i] = expression evaluated at sorted position i; blk_class[b] = the interpreter of block b.
+    std::vector<uint32_t> order(n_exprs), blk_class, fprog_t, fblk_off, wave_blk;
     for (uint32_t i = 0; i < n_exprs; i++) order[i] = i;
+    auto klass = [&](uint32_t x) { return fdepth[x] > kSolveRegStack ? 2u : fdepth[x] > 0 ? 1u : 0u; };
+    auto plen = [&](uint32_t x) { return fo[x + 1] - fo[x]; };
     const uint32_t tile_exprs = kSolveTileWords * 32;
+    constexpr uint32_t kWaves = kSolveBlockThreads / 64;
     for (uint32_t t0 = 0; t0 < n_exprs; t0 += tile_exprs) {
         const uint32_t t1 = std::min(n_exprs, t0 + tile_exprs);
         std::stable_sort(order.begin() + t0, order.begin() + t1, [&](uint32_t a, uint32_t b) {
-            const bool da = fdepth[a] > kSolveRegStack, db = fdepth[b] > kSolveRegStack;
-            if (da != db) return da;
-            return fo[a + 1] - fo[a] > fo[b + 1] - fo[b];
+            if (klass(a) != klass(b)) return klass(a) > klass(b);
+            return klass(a) ? plen(a) > plen(b) : plen(a) < plen(b);
         });
+        std::vector<uint64_t> cost;              // VALU work of a block, for the deal below
         for (uint32_t b0 = t0; b0 < t1; b0 += 64) {
-            uint32_t deep = 0;
+            uint32_t cls = 0;
             uint64_t maxlen = 0;
             for (uint32_t i = b0; i < std::min(t1, b0 + 64); i++) {
-                deep |= fdepth[order[i]] > kSolveRegStack;
-                maxlen = std::max(maxlen, fo[order[i] + 1] - fo[order[i]]);
+                cls = std::max(cls, klass(order[i]));
+                maxlen = std::max(maxlen, plen(order[i]));
             }
-            blk_deep.push_back(deep);
+            blk_class.push_back(cls);
+            cost.push_back(maxlen * (cls == 2 ? 40 : cls == 1 ? 26 : 14) + 160);
             // the block's chunks transposed: words 4c..4c+3 of lane l at off + (c * 64 + l) * 4
             if (fprog_t.size() + maxlen * 64 > 0xFFFFFFFFull) return fail(e, GFT_E_UNSUPPORTED, "program set too large");
             fblk_off.push_back((uint32_t)fprog_t.size());
-            fprog_t.resize(fprog_t.size() + maxlen * 64, (uint32_t)kFopNop << 28);
+            fprog_t.resize(fprog_t.size() + maxlen * 64, kDwNop);
             for (uint32_t i = b0; i < std::min(t1, b0 + 64); i++) {
                 const uint64_t p0 = fo[order[i]], len = fo[order[i] + 1] - p0;
                 for (uint64_t pc = 0; pc < len; pc++)
-                    fprog_t[fblk_off.back() + ((pc / 4) * 64 + (i - b0)) * 4 + pc % 4] = fw[p0 + pc];
+                    fprog_t[fblk_off.back() + ((pc / 4) * 64 + (i - b0)) * 4 + pc % 4] = fused_to_device(fw[p0 + pc]);
             }
+        }
+        // The deal: the tile's blocks go to the workgroup's waves sixteen at a time.  Wave w runs on SIMD w % 4 and the
+        // four waves of a SIMD share its issue slots, so every round's blocks are dealt by cost, the most expensive
+        // first, to the SIMD with the least work so far that still has a wave free (its lowest wave: the oldest wave of
+        // a SIMD is served first, which suits the block everybody else ends up waiting for).
+        // wave_blk[tile's first block + round * 16 + wave] = block (relative to the tile) or ~0.
+        // (a full tile is 32 blocks = two rounds, so a tile's entries start at its first block's index)
+        const uint32_t nblk = (uint32_t)cost.size();
+        std::vector<uint32_t> by_cost(nblk);
+        for (uint32_t b = 0; b < nblk; b++) by_cost[b] = b;
+        for (uint32_t r0 = 0; r0 < nblk; r0 += kWaves) {
+            const uint32_t r1 = std::min(nblk, r0 + kWaves);
+            std::stable_sort(by_cost.begin() + r0, by_cost.begin() + r1, [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+            uint64_t load[4] = {0, 0, 0, 0};
+            uint32_t used[4] = {0, 0, 0, 0};
+            uint32_t deal[kWaves];
+            for (uint32_t w = 0; w < kWaves; w++) deal[w] = 0xFFFFFFFFu;
+            for (uint32_t k = r0; k < r1; k++) {
+                int best = -1;
+                for (int q = 0; q < 4; q++)
+                    if (used[q] < kWaves / 4 && (best < 0 || load[q] < load[best])) best = q;
+                deal[used[best] * 4 + best] = by_cost[k];
+                used[best]++;
+                load[best] += cost[by_cost[k]];
+            }
+            for (uint32_t w = 0; w < kWaves; w++) wave_blk.push_back(deal[w]);
         }
     }
     if (order.empty()) order.push_back(0);
-    if (blk_deep.empty()) blk_deep.push_back(0);
+    if (blk_class.empty()) blk_class.push_back(0);
+    if (wave_blk.empty()) wave_blk.push_back(0xFFFFFFFFu);
     if (fblk_off.empty()) fblk_off.push_back(0);
     if (fprog_t.empty()) fprog_t.push_back(0);
     refresh_options(e);
@@ -1347,24 +1427,32 @@ int gft_set_programs(gft_engine* e, const uint32_t* prog_words, const uint64_t* 
         }
         fprintf(stderr, "[gft solve debug] %u programs, %zu fused words (max %llu); programs with stack/not/inord ops: %llu; ops:",
                 n_exprs, fw.size(), (unsigned long long)maxlen, (unsigned long long)with_rare);
-        for (int k = 1; k <= 12; k++) fprintf(stderr, " %d:%llu", k, (unsigned long long)hist[k]);
+        for (int k = 1; k <= 15; k++) fprintf(stderr, " %d:%llu", k, (unsigned long long)hist[k]);
         fprintf(stderr, "\n");
     }
-    if (fw.empty()) fw.push_back(0);
+    if (groups.size() / 2 > (1u << kDwFieldBits)) return fail(e, GFT_E_UNSUPPORTED, "too many INORD groups");
+    // the kernel reads control bits, not opcodes (gft_kernels.hpp fused_to_device)
+    std::vector<uint32_t> dw(fw.size());
+    for (size_t i = 0; i < fw.size(); i++) dw[i] = fused_to_device(fw[i]);
+    if (dw.empty()) dw.push_back(kDwNop);
     if (groups.empty()) groups.assign(2, 0);
-    if ((rc = upload(e, e->d_fprog, fw, "program upload"))) return rc;
+    if ((rc = upload(e, e->d_fprog, dw, "program upload"))) return rc;
     if ((rc = upload(e, e->d_fprog_off, fo, "program upload"))) return rc;
     if ((rc = upload(e, e->d_groups, groups, "program upload"))) return rc;
     if ((rc = upload(e, e->d_order, order, "program upload"))) return rc;
-    if ((rc = upload(e, e->d_blk_deep, blk_deep, "program upload"))) return rc;
+    if ((rc = upload(e, e->d_blk_class, blk_class, "program upload"))) return rc;
+    if ((rc = upload(e, e->d_wave_blk, wave_blk, "program upload"))) return rc;
     if ((rc = upload(e, e->d_fprog_t, fprog_t, "program upload"))) return rc;
     if ((rc = upload(e, e->d_fblk_off, fblk_off, "program upload"))) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream), "program upload");
     e->n_exprs = n_exprs; e->n_extra = n_extra; e->have_programs = true;
     e->scan_valid_docs = ~0ull;          // positions may not have been written for the old program set
     e->fprog_words = (uint32_t)fw.size();
-    e->n_inord_groups = 0;
-    for (uint32_t w : fw) e->n_inord_groups += (w >> 28) == kFopInord;
+    e->n_inord_groups = e->n_rare_words = 0;
+    for (uint32_t w : fw) {
+        e->n_inord_groups += (w >> 28) == kFopInord;
+        e->n_rare_words += (w >> 28) == kFopInord || (w >> 28) == kFopNot;
+    }
     return GFT_OK;
 }
 

@@ -58,9 +58,42 @@ enum FusedOp : uint32_t {     // ops < 8 read one presence row: bit 2 = negate i
     kFopNot = 10,     // acc = ~acc (only on top of an INORD group: NOT is pushed down to the leaves otherwise)
     kFopInord = 11,   // acc = documents of acc whose INORD group `operand` has a non-empty position list
     kFopPush = 12,    // push acc
-    kFopNop = 13      // padding: every program is a whole number of 4-word chunks
+    kFopNop = 13,     // padding: every program is a whole number of 4-word chunks
+    kFopPushSet = 14, // push acc; acc = P[slot]   (what follows a push is always the first leaf of the next subtree)
+    kFopPushSetN = 15 // push acc; acc = ~P[slot]
 };
 constexpr uint32_t kSolveRegStack = 2;           // accumulator-stack entries the fast interpreter keeps in registers
+constexpr uint32_t kSolveRegStackDeep = 4;       // ... and the interpreter of the blocks that nest deeper (beyond: scratch)
+
+// What the kernel reads: the fused words re-coded as CONTROL BITS (fused_to_device, at upload), so that one step of the
+// interpreter is straight-line mask arithmetic -- v_bfe_i32 turns a bit into a lane mask, v_bfi / v_and_or do the rest:
+//   v = P[field] ^ NEG;  x = POP ? s0 : v;  A = SEL ? x : ONES;  B = OR ? x : 0;  acc = (acc & A) | B
+//   set: B = v, A = 0   and: A = v   or: A = ~0, B = v   and-pop / or-pop: the same on s0   push, nop: A = ~0, B = 0
+// RARE words (NOT, INORD group `field`) are no-ops of that data flow and take the wave-uniform slow path.
+constexpr uint32_t kDwNeg = 1u << 0, kDwSel = 1u << 1, kDwOnes = 1u << 2, kDwOr = 1u << 28, kDwPop = 1u << 29,
+                   kDwPush = 1u << 30, kDwRare = 1u << 31;
+constexpr uint32_t kDwFieldShift = 3, kDwFieldBits = 25;        // bits 3..27: slot (x 8 = its byte offset in a 64-document P)
+constexpr uint32_t kDwFieldMask = ((1u << kDwFieldBits) - 1u) << kDwFieldShift;
+constexpr uint32_t kDwNop = kDwOnes;
+inline uint32_t fused_to_device(uint32_t fw) {
+    const uint32_t field = (fw << kDwFieldShift) & kDwFieldMask;
+    switch (fw >> 28) {
+    case kFopSet: return field | kDwOr;
+    case kFopSetN: return field | kDwOr | kDwNeg;
+    case kFopAndS: return field | kDwSel;
+    case kFopAndNS: return field | kDwSel | kDwNeg;
+    case kFopOrS: return field | kDwOnes | kDwOr;
+    case kFopOrNS: return field | kDwOnes | kDwOr | kDwNeg;
+    case kFopAndPop: return kDwPop | kDwSel;
+    case kFopOrPop: return kDwPop | kDwOnes | kDwOr;
+    case kFopPush: return kDwPush | kDwOnes;
+    case kFopPushSet: return field | kDwPush | kDwOr;
+    case kFopPushSetN: return field | kDwPush | kDwOr | kDwNeg;
+    case kFopNot: return kDwRare | kDwOnes | kDwNeg;
+    case kFopInord: return kDwRare | kDwOnes | field;
+    default: return kDwNop;
+    }
+}
 constexpr uint32_t kSolveTileWords = 64;         // bitmap words (x32 expressions) evaluated per LDS output tile
 
 struct SolveParams {
@@ -75,19 +108,22 @@ struct SolveParams {
     const uint32_t* x_slot;
     const uint32_t* x_pos;
     uint64_t n_docs;
-    const uint32_t* fprog;       // fused programs
+    const uint32_t* fprog;       // fused programs, device form (fused_to_device)
     const uint64_t* fprog_off;
     const uint32_t* gprog;       // public postfix words (INORD group subtrees are interpreted from these)
     const uint32_t* groups;      // [n_groups][2] = offset, length into gprog
     const uint32_t* order;       // [n_exprs] evaluation order inside every output tile (gft_set_programs)
     const Unit* units;           // the scan's work units (document of every unit)
-    uint32_t has_inord;          // some program has an INORD group (0: the kernel variant without the position algebra)
-    const uint32_t* blk_deep;    // per 64 sorted programs: 1 = some program nests deeper than kSolveRegStack
+    uint32_t has_rare;           // some program holds a NOT or INORD word (0: the kernel variant without the position algebra)
+    const uint32_t* blk_class;   // per 64 sorted programs: the interpreter they need (0 flat, 1 register stack, 2 deep)
+    const uint32_t* wave_blk;    // per tile and round of 16 blocks: the block (inside the tile) of every wave, or ~0
     const uint32_t* fprog_t;     // the same programs per sorted block, transposed by chunk: words 4c..4c+3 of lane l at fblk_off[b] + (c * 64 + l) * 4
     const uint32_t* fblk_off;    // (read when the programs do not fit LDS: coalesced instead of one stream per lane)
     uint32_t n_exprs, n_slots, tile_words;
     uint32_t fprog_words;        // total words of fprog (staged in LDS when they fit)
-    uint32_t dbg;                // GFT_SOLVE_DEBUG bits (timing studies): 1 skip presence build, 2 skip evaluation, 4 skip transpose/output
+    uint32_t dbg;                // GFT_SOLVE_DEBUG bits (timing studies): 1 skip presence build, 2 skip evaluation, 4 skip transpose/output,
+                                 // 8 phase clocks: cycles per phase and wave summed into dbg_out[wave * 8 + phase]
+    unsigned long long* dbg_out;
     uint64_t* p_scratch;         // presence matrix in HBM when it does not fit LDS: [grid][n_slots]
     uint32_t* bitmap;
 };

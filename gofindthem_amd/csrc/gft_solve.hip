@@ -23,6 +23,14 @@ namespace {
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
+// A wave-uniform word of a read-only table through the scalar unit (constant address space: s_load, counted by lgkmcnt).
+// As a plain global load it would be a VECTOR load plus v_readfirstlane -- and its s_waitcnt vmcnt(0) would wait for every
+// prefetch in flight as well.
+__device__ __forceinline__ uint32_t uniform_word(const uint32_t* table, size_t i) {
+    using ConstWord = const __attribute__((address_space(4))) uint32_t;
+    return reinterpret_cast<ConstWord*>(reinterpret_cast<uintptr_t>(table))[i];
+}
+
 // ---- per-document view of the matches (slabs of the scan kernel + caller-supplied matches) -------------------
 struct DocHits {
     const uint64_t* unit_start;
@@ -145,21 +153,47 @@ __device__ bool inord_group_wave(const uint32_t* __restrict__ prog, uint32_t len
 }
 
 // 64 x 64 bit-matrix transpose across a wave: lane i holds row i; afterwards lane j holds column j (bit i = old row
-// i's bit j).  Six exchange steps with the partner lane i ^ s, swapping the off-diagonal s x s blocks.
+// i's bit j).  Six exchange steps with the partner lane i ^ s, swapping the off-diagonal s x s blocks -- all in the
+// vector ALU (no LDS permutes, the LDS pipe is busy enough here):
+//   s = 32: the low word of the upper lanes against the high word of the lower lanes IS v_permlane32_swap;
+//   s < 32, per 32-bit half h with the partner's t:  new = keep ? h : rot(t), bit by bit, where the lower lane of a pair
+//           keeps the bits of m = the low s of every 2s and takes t << s, the upper lane keeps ~m and takes t >> s; both
+//           shifts as rotations (v_alignbit), what wraps around lands on kept bits.
+//   partner fetch: v_permlane16_swap (s = 16), DPP row_ror:8 (s = 8), row_shl:4 / row_shr:4 by bank (s = 4), quad_perm (2, 1).
 template <int SH>
-__device__ __forceinline__ uint64_t transpose_step(uint64_t x, uint32_t lane, uint64_t m) {
-    const uint64_t t = __shfl_xor(x, SH, 64);
-    return (lane & SH) ? ((t >> SH) & m) | (x & ~m) : (x & m) | ((t & m) << SH);
+__device__ __forceinline__ uint32_t partner(uint32_t h, uint32_t lane) {
+    if constexpr (SH == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(h, h, false, false);   // [0]: odd rows <- even rows, [1]: even rows <- odd rows
+        return (lane & 16) ? r[0] : r[1];
+    } else if constexpr (SH == 8) {
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h, 0x128, 0xF, 0xF, false);               // row_ror:8
+    } else if constexpr (SH == 4) {
+        const int t = __builtin_amdgcn_update_dpp(0, (int)h, 0x104, 0xF, 0x5, false);                  // row_shl:4 -> lanes 0-3, 8-11
+        return (uint32_t)__builtin_amdgcn_update_dpp(t, (int)h, 0x114, 0xF, 0xA, false);               // row_shr:4 -> lanes 4-7, 12-15
+    } else if constexpr (SH == 2) {
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h, 0x4E, 0xF, 0xF, false);                // quad_perm:[2,3,0,1]
+    } else {
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h, 0xB1, 0xF, 0xF, false);                // quad_perm:[1,0,3,2]
+    }
+}
+template <int SH>
+__device__ __forceinline__ void transpose_step(uint32_t& lo, uint32_t& hi, uint32_t lane, uint32_t m) {
+    const bool upper = (lane & SH) != 0;
+    const uint32_t keep = upper ? ~m : m, rot = upper ? (uint32_t)SH : 32u - (uint32_t)SH;             // rotate right by `rot`
+    const uint32_t tl = partner<SH>(lo, lane), th = partner<SH>(hi, lane);
+    lo = (keep & lo) | (~keep & __builtin_amdgcn_alignbit(tl, tl, rot));
+    hi = (keep & hi) | (~keep & __builtin_amdgcn_alignbit(th, th, rot));
 }
 __device__ __forceinline__ uint64_t wave_transpose64(uint64_t x) {
     const uint32_t lane = lane_id();
-    x = transpose_step<32>(x, lane, 0x00000000FFFFFFFFull);
-    x = transpose_step<16>(x, lane, 0x0000FFFF0000FFFFull);
-    x = transpose_step<8>(x, lane, 0x00FF00FF00FF00FFull);
-    x = transpose_step<4>(x, lane, 0x0F0F0F0F0F0F0F0Full);
-    x = transpose_step<2>(x, lane, 0x3333333333333333ull);
-    x = transpose_step<1>(x, lane, 0x5555555555555555ull);
-    return x;
+    const auto r = __builtin_amdgcn_permlane32_swap((uint32_t)x, (uint32_t)(x >> 32), false, false);
+    uint32_t lo = r[0], hi = r[1];
+    transpose_step<16>(lo, hi, lane, 0x0000FFFFu);
+    transpose_step<8>(lo, hi, lane, 0x00FF00FFu);
+    transpose_step<4>(lo, hi, lane, 0x0F0F0F0Fu);
+    transpose_step<2>(lo, hi, lane, 0x33333333u);
+    transpose_step<1>(lo, hi, lane, 0x55555555u);
+    return ((uint64_t)hi << 32) | lo;
 }
 
 // INORD words of a wave's current program step.  All 64 lanes call this together; `is_inord` marks the lanes whose word
@@ -197,10 +231,6 @@ __device__ __forceinline__ uint64_t inord_wave(const SolveParams& S, bool is_ino
     return res;
 }
 
-// One fused program over 64 documents (bit j of every mask = document d0 + j).  Lanes of a wave run different
-// programs, so the interpreter is predicated rather than branched: every word costs one presence read and a handful of
-// selects.  DEEP = false keeps the accumulator stack in two registers (programs that nest deeper are sorted into
-// blocks of their own and take DEEP = true: four registers backed by scratch).
 // maximum over the 64 lanes with DPP moves: running maximum along the four rows of 16 lanes, row results broadcast into
 // the rows behind them, lane 63 ends up with the maximum of all (no LDS permutes, no index arithmetic)
 template <int CTRL, int ROWS, bool ZERO_FILL>
@@ -218,87 +248,139 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     return __builtin_amdgcn_readlane(v, 63);
 }
 
+// 64 document bits as two 32-bit halves: the interpreter's bitwise steps are then plain 32-bit operations, which the
+// compiler folds into v_bfi_b32 / v_and_or_b32 (it does not for 64-bit values)
+struct Mask64 {
+    uint32_t lo, hi;
+    Mask64() = default;                                        // (no zero fill: the scratch stack of the deep interpreter)
+    __device__ __forceinline__ Mask64(uint32_t l, uint32_t h) : lo(l), hi(h) {}
+    __device__ __forceinline__ explicit Mask64(uint64_t v) : lo((uint32_t)v), hi((uint32_t)(v >> 32)) {}
+    __device__ __forceinline__ explicit operator uint64_t() const { return ((uint64_t)hi << 32) | lo; }
+    __device__ __forceinline__ explicit operator bool() const { return (lo | hi) != 0; }
+};
+__device__ __forceinline__ Mask64 operator&(Mask64 a, Mask64 b) { return Mask64(a.lo & b.lo, a.hi & b.hi); }
+__device__ __forceinline__ Mask64 operator|(Mask64 a, Mask64 b) { return Mask64(a.lo | b.lo, a.hi | b.hi); }
+__device__ __forceinline__ Mask64 operator^(Mask64 a, Mask64 b) { return Mask64(a.lo ^ b.lo, a.hi ^ b.hi); }
+__device__ __forceinline__ Mask64 operator~(Mask64 a) { return Mask64(~a.lo, ~a.hi); }
+
+// a control bit of a device word (gft_kernels.hpp kDw*) as a mask over the group's documents: v_bfe_i32 gives 0 or ~0
+// (both halves of a Mask64 are that one register)
+template <class AT, uint32_t BIT>
+__device__ __forceinline__ AT bit_mask(uint32_t w) {
+    const uint32_t m = (uint32_t)((int32_t)(w << (31u - BIT)) >> 31);
+    if constexpr (sizeof(AT) == 8) return AT(m, m);
+    else return (AT)m;
+}
+template <class AT>
+__device__ __forceinline__ AT pick(AT m, AT a, AT b) { return (m & a) | (~m & b); }       // v_bfi_b32: m ? a : b, bit by bit
+constexpr uint32_t bit_index(uint32_t m) { return m <= 1 ? 0 : 1 + bit_index(m >> 1); }
+
+// One fused program over the group's documents (bit j of every mask = document d0 + j).  Lanes of a wave run different
+// programs, so the interpreter has no branches on the word: the control bits of a device word become lane masks and one
+// step is a handful of v_bfi / v_and_or on them plus one presence read (gft_kernels.hpp, "What the kernel reads").
+// The accumulator stack lives in R registers -- none for the blocks of flat programs (no push / pop: half the work per
+// word), 2 for the ordinary blocks, 4 for the blocks whose programs nest deeper, which also keep a depth counter and spill
+// to scratch beyond (a wave-uniform slow path, like the NOT / INORD words).
 // ALL 64 lanes of a wave call this together (lanes without a program pass chunks = 0): the trip count is the wave's
-// maximum, finished lanes run kFopNop words, so the INORD steps can use the whole wave.
-template <bool P_LDS, bool DEEP, bool INORD, class PT, class AT>
+// maximum, finished lanes run no-op words, so the INORD steps can use the whole wave.
+template <bool P_LDS, uint32_t R, bool RARE, class PT, class AT>
 __device__ __forceinline__ AT run_program(const SolveParams& S, const PT* P, const uint4* prog, uint32_t stride, uint32_t chunks,
                                           AT valid, uint64_t d0) {
+    static_assert(R == 0 || R == kSolveRegStack || R == kSolveRegStackDeep, "three interpreters");
+    constexpr bool DEEP = R > kSolveRegStack;
     // HBM-resident P was written with L2 atomics by other waves: read it past this CU's L1
-    auto ld = [&](uint32_t slot) -> AT {
-        return P_LDS ? (AT)P[slot] : (AT)__hip_atomic_load(&P[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (LDS: the field of a word is the slot's byte offset in a P of 8-byte elements, one v_and away)
+    auto ld = [&](uint32_t w) -> AT {
+        constexpr uint32_t kDown = sizeof(PT) == 8 ? 0 : sizeof(PT) == 4 ? 1 : sizeof(PT) == 2 ? 2 : 3;
+        const uint32_t byte = (w & kDwFieldMask) >> kDown;
+        if (P_LDS) return (AT)*reinterpret_cast<const PT*>(reinterpret_cast<const uint8_t*>(P) + byte);
+        return (AT)__hip_atomic_load(&P[byte / sizeof(PT)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
-    AT acc = 0, s0 = 0, s1 = 0, s2 = 0, s3 = 0, deep[DEEP ? kMaxBoolDepth : 1];
-    uint32_t sp = 0;
-    constexpr uint32_t kNop = (uint32_t)kFopNop << 28;
-    uint4 nx = chunks ? prog[0] : make_uint4(kNop, kNop, kNop, kNop);
-    uint4 nx2 = chunks > 1 ? prog[stride] : make_uint4(kNop, kNop, kNop, kNop);     // two chunks ahead (programs in L2)
+    AT acc = AT(0), s0 = AT(0), s1 = AT(0), s2 = AT(0), s3 = AT(0), deep[DEEP ? kMaxBoolDepth : 1];
+    uint32_t sp = 0;                                            // DEEP: entries on the stack (registers + scratch)
+    uint4 nx = chunks ? prog[0] : make_uint4(kDwNop, kDwNop, kDwNop, kDwNop);
+    uint4 nx2 = chunks > 1 ? prog[stride] : make_uint4(kDwNop, kDwNop, kDwNop, kDwNop);   // two chunks ahead (programs in L2)
     const uint32_t wchunks = wave_max_u32(chunks);
     // four words per trip: the next two chunks and this chunk's four presence reads are in flight together, so a trip
-    // exposes one memory round trip instead of four (programs are padded to whole chunks with kFopNop)
+    // exposes one memory round trip instead of four (programs are padded to whole chunks with no-op words)
     for (uint32_t c = 0; c < wchunks; c++) {
         const uint32_t w[4] = {nx.x, nx.y, nx.z, nx.w};
         nx = nx2;
-        nx2 = make_uint4(kNop, kNop, kNop, kNop);
+        nx2 = make_uint4(kDwNop, kDwNop, kDwNop, kDwNop);
         if (c + 2 < chunks) nx2 = prog[(size_t)(c + 2) * stride];
         AT pv[4];
-        bool rare = false;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const uint32_t op = w[q] >> 28;
-            pv[q] = ld(op < kFopAndPop ? (w[q] & 0x0FFFFFFFu) : 0);
-            rare |= op == kFopNot || op == kFopInord;
+            pv[q] = ld(RARE && (int32_t)w[q] < 0 ? 0u : w[q]);            // (a rare word's field is a group, not a slot)
         }
-        const bool any_rare = INORD && __any(rare);             // wave-uniform: only around INORD groups (INORD = false:
-                                                                // the program set has none, the path is compiled out)
-        auto step = [&](const uint32_t wq, const AT pvq, const bool with_rare) __attribute__((always_inline)) {
-            const uint32_t op = wq >> 28, a = wq & 0x0FFFFFFFu;
-            const bool is_s = op < kFopAndPop;
-            const AT v = pvq ^ (AT)(0 - (AT)((op >> 2) & 1));   // SetN / AndNS / OrNS (bits past the group are never stored)
-            const uint32_t k = op & 3;
-            const AT t = k == 3 ? (acc | v) : (acc & v);
-            const AT sacc = k == 1 ? v : t;
-            const bool is_pop = (op & 14) == kFopAndPop, is_push = op == kFopPush;
-            const AT pacc = (op & 1) ? (acc | s0) : (acc & s0);
+        // wave-uniform: a NOT / INORD word in this chunk, or a lane whose stack leaves the registers in it
+        bool careful = RARE && __any((int32_t)(w[0] | w[1] | w[2] | w[3]) < 0);
+        if (DEEP) {
+            uint32_t high = sp;                                  // an upper bound of the depth inside this chunk
+#pragma unroll
+            for (int q = 0; q < 4; q++) high += (w[q] >> bit_index(kDwPush)) & 1u;
+            careful |= __any(high > R);
+        }
+        auto step = [&](const uint32_t wq, const AT pvq, const bool care) __attribute__((always_inline)) {
+            const AT neg = bit_mask<AT, bit_index(kDwNeg)>(wq), sel = bit_mask<AT, bit_index(kDwSel)>(wq);
+            const AT ones = bit_mask<AT, bit_index(kDwOnes)>(wq), orr = bit_mask<AT, bit_index(kDwOr)>(wq);
+            const AT pop = bit_mask<AT, bit_index(kDwPop)>(wq), push = bit_mask<AT, bit_index(kDwPush)>(wq);
+            const AT v = pvq ^ neg;                             // (bits past the group are never stored)
+            const AT x = R ? pick(pop, s0, v) : v;
             const AT before = acc;
-            acc = is_s ? sacc : is_pop ? pacc : acc;
-            if (!DEEP) {
-                const AT n0 = is_push ? before : is_pop ? s1 : s0;
-                s1 = is_push ? s0 : s1;
+            acc = (acc & pick(sel, x, ones)) | (x & orr);
+            if (R == 0) {
+                // flat programs: no push, no pop
+            } else if (!DEEP) {
+                const AT n0 = pick(push, before, pick(pop, s1, s0));
+                s1 = pick(push, s0, s1);
                 s0 = n0;
             } else {
-                if (is_push) {
-                    if (sp >= 4) deep[sp - 4] = s3;
-                    s3 = s2; s2 = s1; s1 = s0; s0 = before;
-                    sp++;
-                }
-                if (is_pop) {
-                    s0 = s1; s1 = s2; s2 = s3;
-                    sp--;
-                    if (sp >= 4) s3 = deep[sp - 4];
+                if (care && push && sp >= R) deep[sp - R] = s3;
+                const AT n0 = pick(push, before, pick(pop, s1, s0)), n1 = pick(push, s0, pick(pop, s2, s1));
+                const AT n2 = pick(push, s1, pick(pop, s3, s2)), n3 = pick(push, s2, s3);
+                s0 = n0; s1 = n1; s2 = n2; s3 = n3;
+                sp = sp - bit_mask<uint32_t, bit_index(kDwPush)>(wq) + bit_mask<uint32_t, bit_index(kDwPop)>(wq);   // 0 or ~0 == -1
+                if (care && pop && sp >= R) {
+                    s3 = deep[sp - R];
+                    // (waited for here: a scratch load left pending would have the compiler wait for ALL vector loads, the
+                    // prefetch of the next group included, wherever the fast path touches the same register)
+                    __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0)
                 }
             }
-            if (with_rare) {
-                if (op == kFopNot) acc = ~acc;
+            if (RARE && care) {
+                const bool rare = (int32_t)wq < 0, is_not = rare && (wq & kDwNeg), is_inord = rare && !(wq & kDwNeg);
+                if (is_not) acc = ~acc;
                 // candidates: documents where the group's boolean value is true (rval, expression.go:137)
-                const AT in = (AT)inord_wave(S, op == kFopInord, a, (uint64_t)(acc & valid), d0);
-                if (op == kFopInord) acc = in;
+                const AT in = AT(inord_wave(S, is_inord, (wq & kDwFieldMask) >> kDwFieldShift, (uint64_t)(acc & valid), d0));
+                if (is_inord) acc = in;
             }
         };
-        if (!any_rare) {
+        if (!careful) {
 #pragma unroll
             for (int q = 0; q < 4; q++) step(w[q], pv[q], false);
         } else {
-            // one copy of the INORD code: the chunk's words one after the other in a rolled loop
+            // one copy of the slow code: the chunk's words one after the other in a rolled loop.  The words rotate through
+            // fixed registers -- indexing w[] / pv[] with the loop counter would move both arrays to scratch memory, for
+            // the fast path above as well
+            uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+            AT p0 = pv[0], p1 = pv[1], p2 = pv[2], p3 = pv[3];
 #pragma nounroll
             for (int q = 0; q < 4; q++) {
-                const uint32_t wq = q == 0 ? w[0] : q == 1 ? w[1] : q == 2 ? w[2] : w[3];
-                const AT pvq = q == 0 ? pv[0] : q == 1 ? pv[1] : q == 2 ? pv[2] : pv[3];
-                step(wq, pvq, true);
+                step(w0, p0, true);
+                w0 = w1; w1 = w2; w2 = w3;
+                p0 = p1; p1 = p2; p2 = p3;
             }
         }
     }
     return acc;
 }
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a barrier plus a fence over ALL memory: the compiler
+// puts s_waitcnt vmcnt(0) in front of it, i.e. every barrier would wait for the prefetch loads in flight and a group would
+// pay their whole latency (measured: 4 400 of 24 000 cycles per group).  The loads' registers are tracked by the
+// compiler as usual and waited for where they are read.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // PROG_LDS: the fused programs (and their offsets) are staged in LDS once per workgroup, so the interpreter's
 // dependent word-after-word fetches cost an LDS round trip instead of an L2 one
@@ -307,12 +389,12 @@ template <> struct PType<32> { using type = uint32_t; };
 template <> struct PType<16> { using type = uint16_t; };
 template <> struct PType<8> { using type = uint8_t; };
 template <int G> struct AType { using type = uint32_t; };
-template <> struct AType<64> { using type = uint64_t; };
+template <> struct AType<64> { using type = Mask64; };
 
 // G = documents per group = bits of a presence-matrix element: 64 when 8 bytes per slot fit LDS, else 32 / 16 / 8 so that
 // large dictionaries still keep P in LDS (the evaluation then covers fewer documents per operation, but P stops being an
 // L2 ping-pong of atomics and random reads)
-template <bool P_LDS, bool PROG_LDS, int G, bool INORD, bool DBG = false>
+template <bool P_LDS, bool PROG_LDS, int G, bool RARE, bool DBG = false>
 __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const SolveParams S) {
     const uint32_t dbg = DBG ? S.dbg : 0u;      // timing-study knock-outs (GFT_SOLVE_DEBUG): compiled out of production launches
     using PT = typename PType<G>::type;
@@ -324,9 +406,10 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
     const uint32_t tile_words = S.tile_words;                   // bitmap words covered by one pass (<= kSolveTileWords)
     const uint32_t bm_words = (S.n_exprs + 31) / 32;
     PT* P = P_LDS ? reinterpret_cast<PT*>(smem) : reinterpret_cast<PT*>(S.p_scratch + (size_t)blockIdx.x * S.n_slots);
-    uint32_t* O = reinterpret_cast<uint32_t*>(smem + (P_LDS ? (((size_t)S.n_slots * sizeof(PT) + 15) & ~(size_t)15) : 0));   // [64][tile_words]
+    uint32_t* O = reinterpret_cast<uint32_t*>(smem + (P_LDS ? (((size_t)S.n_slots * sizeof(PT) + 15) & ~(size_t)15) : 0));   // [64][tile_words | 1]
     uint32_t* Pw = reinterpret_cast<uint32_t*>(P);
-    uint64_t* R = reinterpret_cast<uint64_t*>(O + 64 * tile_words);   // [tile_words * 32] results by expression
+    const uint32_t ostride = tile_words | 1u;                   // odd row stride: the transposed columns land in different banks
+    uint64_t* R = reinterpret_cast<uint64_t*>(O + 64 * ostride);      // [tile_words * 32] results by expression
     uint32_t* lprog = reinterpret_cast<uint32_t*>(R + tile_words * 32);  // [fprog_words] when PROG_LDS
     uint32_t* loff = lprog + S.fprog_words;                     // [n_exprs + 1]
     uint32_t* lorder = loff + S.n_exprs + 1;                    // [n_exprs]
@@ -345,51 +428,77 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
     const uint64_t n_groups = (S.n_docs + G - 1) / G;
     // The units of a group's documents are consecutive (doc_unit_base), so the presence matrix is built unit by unit:
     // a team of kTeam lanes per unit, kTeams units at once -- a document of many units (a 1 MB document is > 100) is
-    // spread over the whole workgroup instead of queueing behind one team.  This thread's first unit of the NEXT group
-    // (range of units, slab, count, document) is fetched while the current group is evaluated (pf_*).
-    uint64_t pf_U0 = 0, pf_U1 = 0, pf_s = 0;
-    uint32_t pf_n = 0, pf_doc = 0;
-    auto prefetch = [&](uint64_t g) {
-        pf_U0 = pf_U1 = 0; pf_n = 0;
-        if (g < n_groups) {
-            const uint64_t da = g * G, db = da + G < S.n_docs ? da + G : S.n_docs;
-            pf_U0 = S.doc_unit_base[da]; pf_U1 = S.doc_unit_base[db];
-            const uint64_t u = pf_U0 + threadIdx.x / kTeam;
-            if (u < pf_U1) { pf_s = S.unit_start[u]; pf_n = S.unit_count[u]; pf_doc = S.units[u].doc; }
-        }
+    // spread over the whole workgroup instead of queueing behind one team.  What the build needs is three dependent
+    // reads away (range of units -> slab and count of this thread's unit -> its entries); each is issued one group
+    // ahead of the next, behind the evaluation, so none of them ever waits for the one before it:
+    //   group g + 3: its range of units                                  (`rng`)
+    //   group g + 2: this thread's first unit: slab, count, document     (`nxt`)
+    //   group g + 1: the first kPfTerms slab entries of that unit        (`pf_t`; a unit of up to 192 matches)
+    // -- the build of the common case is LDS atomics on registers.  All of it stays in VECTOR registers and every load
+    // is unconditional (indices clamped, validity checked where the value is used): a scalar value or a predicate derived
+    // from a load would make the wave wait for it on the spot.
+    constexpr int kPfTerms = 12;
+    struct UnitPf { uint64_t u, U1, s; uint32_t n, doc; };      // u: this thread's first unit (valid if u < U1)
+    struct Range { uint64_t U0, U1; };
+    const uint32_t member = threadIdx.x % kTeam;
+    auto launder = [](uint64_t v) { asm volatile("" : "+v"(v)); return v; };   // (keeps a uniform index out of the scalar unit)
+    auto fetch_range = [&](uint64_t g, Range& r) {                // past the last group: an empty range
+        const uint64_t da = g < n_groups ? g * G : S.n_docs, db = da + G < S.n_docs ? da + G : S.n_docs;
+        r.U0 = S.doc_unit_base[launder(da)]; r.U1 = S.doc_unit_base[launder(db)];
     };
-    // ... and, once those have arrived (after the evaluation), the first four slab entries of that unit
-    uint32_t pf_t[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-    auto prefetch_terms = [&]() {
-        const uint32_t member = threadIdx.x % kTeam;
+    auto fetch_unit = [&](const Range& r, UnitPf& m) {           // r: fetch_range, arrived
+        m.u = r.U0 + threadIdx.x / kTeam; m.U1 = r.U1;
+        const uint64_t uc = m.u < m.U1 ? m.u : 0;                 // (unit 0 exists: every document has at least one)
+        m.s = S.unit_start[uc]; m.n = S.unit_count[uc]; m.doc = S.units[uc].doc;
+    };
+    uint32_t pf_t[kPfTerms];
+    auto fetch_terms = [&](const UnitPf& m) {                    // m: fetch_unit, arrived
+        const uint32_t n = m.u < m.U1 ? m.n : 0u;
+        uint64_t at[kPfTerms];
 #pragma unroll
-        for (int q = 0; q < 4; q++) pf_t[q] = member + q * kTeam < pf_n ? S.term[pf_s + member + q * kTeam] : 0xFFFFFFFFu;
+        for (int q = 0; q < kPfTerms; q++) at[q] = member + q * kTeam < n ? m.s + member + q * kTeam : 0;    // (entry 0 of the pool exists)
+        __builtin_amdgcn_sched_barrier(0);                       // addresses (and whatever they need reloaded) first, then the loads
+#pragma unroll
+        for (int q = 0; q < kPfTerms; q++) pf_t[q] = S.term[at[q]];
     };
-    prefetch(blockIdx.x);
-    prefetch_terms();
+    // phase clocks of the timing studies (GFT_SOLVE_DEBUG & 8)
+    unsigned long long tl[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = DBG ? clock64() : 0;
+    auto mark = [&](int ph) {
+        if (DBG && (dbg & 8)) { const unsigned long long now = clock64(); tl[ph] += now - tprev; tprev = now; }
+    };
+    UnitPf cur, nxt;
+    Range rng;
+    fetch_range(blockIdx.x, rng);
+    fetch_unit(rng, cur);
+    fetch_range((uint64_t)blockIdx.x + gridDim.x, rng);
+    fetch_unit(rng, nxt);
+    fetch_range((uint64_t)blockIdx.x + 2 * (uint64_t)gridDim.x, rng);
+    fetch_terms(cur);
     for (uint64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
         const uint64_t d0 = g * G;
         const uint32_t nd = (uint32_t)(S.n_docs - d0 < (uint64_t)G ? S.n_docs - d0 : (uint64_t)G);
 
         // ---- 1. presence matrix ------------------------------------------------------------------------------
+        mark(7);
         if (!(dbg & 1)) {
-            const uint32_t member = threadIdx.x % kTeam;
-            const uint64_t U0 = pf_U0, U1 = pf_U1;
-            for (uint64_t u = U0 + threadIdx.x / kTeam; u < U1; u += kTeams) {
-                const bool pf = u < U0 + kTeams;                   // first (normally only) unit of this team
-                const uint64_t s = pf ? pf_s : S.unit_start[u];
-                const uint32_t n = pf ? pf_n : S.unit_count[u];
-                const uint32_t j = (uint32_t)((pf ? pf_doc : S.units[u].doc) - d0);
-                // twelve slab entries per lane are in flight at a time (the first four came with the prefetch): a unit of
-                // up to 192 matches is one round trip
-                for (uint32_t i = member; i < n; i += 12 * kTeam) {
-                    uint32_t t[12];
+            bool pf = true;                                       // first (normally only) unit of this team: prefetched
+            for (uint64_t u = cur.u; u < cur.U1; u += kTeams, pf = false) {
+                const uint64_t s = pf ? cur.s : S.unit_start[u];
+                const uint32_t n = pf ? cur.n : S.unit_count[u];
+                const uint32_t j = (uint32_t)((pf ? cur.doc : S.units[u].doc) - d0);
+                // kPfTerms slab entries per lane are in flight at a time
+                for (uint32_t i = member; i < n; i += kPfTerms * kTeam) {
+                    uint32_t t[kPfTerms];
+                    if (pf && i == member) {
 #pragma unroll
-                    for (int q = 0; q < 12; q++)
-                        t[q] = (q < 4 && pf && i == member) ? pf_t[q] : i + q * kTeam < n ? S.term[s + i + q * kTeam] : 0xFFFFFFFFu;
+                        for (int q = 0; q < kPfTerms; q++) t[q] = pf_t[q];
+                    } else {
 #pragma unroll
-                    for (int q = 0; q < 12; q++)
-                        if (t[q] != 0xFFFFFFFFu) {
+                        for (int q = 0; q < kPfTerms; q++) t[q] = i + q * kTeam < n ? S.term[s + i + q * kTeam] : 0u;
+                    }
+#pragma unroll
+                    for (int q = 0; q < kPfTerms; q++)
+                        if (i + q * kTeam < n) {
                             const size_t bp = (size_t)t[q] * G + j;              // bit j of element t
                             if (P_LDS) __hip_atomic_fetch_or(&Pw[bp >> 5], 1u << (bp & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             else atomicOr(&Pw[bp >> 5], 1u << (bp & 31));
@@ -407,10 +516,19 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
                 }
             }
         }
-        if (!P_LDS) __threadfence_block();
-        __syncthreads();
+        mark(0);
+        if (P_LDS) lds_barrier();
+        else { __threadfence_block(); __syncthreads(); }       // (P in HBM: the other waves' atomics must be visible)
+        mark(1);
 
-        prefetch(g + gridDim.x);
+        // the next group's slab entries, the unit of the group after it, the range of the one after that: in flight
+        // during the evaluation (no __syncthreads() from here to the next build: lds_barrier does not wait for them).
+        // Straight-line and unconditional, so that the loaded registers ARE the loop-carried ones: a copy of a register
+        // that a load is still filling makes the wave wait for the load on the spot.
+        cur = nxt;
+        fetch_terms(cur);
+        fetch_unit(rng, nxt);
+        fetch_range(g + 3 * (uint64_t)gridDim.x, rng);
 
         // ---- 2. expressions, tile by tile over the bitmap words ------------------------------------------------------
         const uint64_t valid = nd == 64 ? ~0ull : ((1ull << nd) - 1);
@@ -418,39 +536,41 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
             const uint32_t tw = bm_words - w0 < tile_words ? bm_words - w0 : tile_words;
             const uint32_t e0 = w0 << 5;                                          // first expression of the tile
             const uint32_t ne = S.n_exprs - e0 < (tw << 5) ? S.n_exprs - e0 : (tw << 5);
-            // 2a. evaluation in sorted order (gft_set_programs): 64 programs of similar length per wave.  Sixteen blocks
-            // at a time, longest first, dealt to the waves in a snake over the four SIMDs so that the SIMDs get similar sums
+            // 2a. evaluation in sorted order: 64 programs of similar length and one interpreter class per wave, sixteen
+            // blocks at a time, dealt to the waves by gft_set_programs so that the four SIMDs get similar sums of work
             const uint32_t nblk = (ne + 63) / 64;
             for (uint32_t b16 = 0; b16 < nblk && !(dbg & 2); b16 += kWaves) {
-                const uint32_t row = wave >> 2, c4 = wave & 3;
-                const uint32_t b = b16 + row * 4 + ((row & 1) ? 3 - c4 : c4);
+                const uint32_t b = uniform_word(S.wave_blk, (e0 >> 6) + b16 + wave);
                 const uint32_t i = b * 64 + lane;
-                if (b < nblk) {                                                   // wave-uniform
+                if (b < nblk) {
                     const bool has = i < ne;                                      // lanes past the tile: no program
                     const uint32_t e = PROG_LDS ? lorder[e0 + (has ? i : 0)] : S.order[e0 + (has ? i : 0)];
                     const uint64_t po = PROG_LDS ? loff[e] : S.fprog_off[e];
                     const uint32_t len = (uint32_t)((PROG_LDS ? loff[e + 1] : S.fprog_off[e + 1]) - po);
                     // programs in LDS: linear; in global memory: the block's 4-word chunks transposed ([chunk][lane]) so
                     // that the lanes of a wave read consecutive 16-byte pieces
-                    const uint4* prog = reinterpret_cast<const uint4*>(PROG_LDS ? lprog + po : S.fprog_t + S.fblk_off[(e0 >> 6) + b]) +
+                    const uint4* prog = reinterpret_cast<const uint4*>(PROG_LDS ? lprog + po : S.fprog_t + uniform_word(S.fblk_off, (e0 >> 6) + b)) +
                                         (PROG_LDS ? 0 : lane);
                     const uint32_t stride = PROG_LDS ? 1u : 64u;
-                    const bool deep = S.blk_deep[(e0 >> 6) + b] != 0;              // wave-uniform
+                    const uint32_t cls = uniform_word(S.blk_class, (e0 >> 6) + b);
                     const uint32_t chunks = has ? len / 4 : 0;
-                    const AT r = deep ? run_program<P_LDS, true, INORD, PT, AT>(S, P, prog, stride, chunks, (AT)valid, d0)
-                                      : run_program<P_LDS, false, INORD, PT, AT>(S, P, prog, stride, chunks, (AT)valid, d0);
-                    if (has) R[e - e0] = r;
+                    const AT r = cls == 0   ? run_program<P_LDS, 0, RARE, PT, AT>(S, P, prog, stride, chunks, AT(valid), d0)
+                                 : cls == 1 ? run_program<P_LDS, kSolveRegStack, RARE, PT, AT>(S, P, prog, stride, chunks, AT(valid), d0)
+                                            : run_program<P_LDS, kSolveRegStackDeep, RARE, PT, AT>(S, P, prog, stride, chunks, AT(valid), d0);
+                    if (has) R[e - e0] = (uint64_t)r;
                 }
             }
-            __syncthreads();
+            mark(2);
+            lds_barrier();                                       // R is complete (LDS); P was read by atomic loads if in HBM
+            mark(3);
             // 2b. transpose in natural order: lane j ends up with the two bitmap words of document j for 64 expressions
             const uint32_t rounds = (tw + 1) / 2;
             for (uint32_t r = wave; r < rounds; r += kWaves) {
                 const uint32_t el = r * 64 + lane;
                 const uint64_t acc = (el < ne && !(dbg & 2)) ? R[el] : 0;
                 const uint64_t mine = (dbg & 4) ? 0 : wave_transpose64(acc);
-                O[lane * tile_words + r * 2] = (uint32_t)mine;
-                if (r * 2 + 1 < tw) O[lane * tile_words + r * 2 + 1] = (uint32_t)(mine >> 32);
+                O[lane * ostride + r * 2] = (uint32_t)mine;
+                if (r * 2 + 1 < tw) O[lane * ostride + r * 2 + 1] = (uint32_t)(mine >> 32);
             }
             // ---- 3. (LDS) the last tile's evaluation was the last reader of P: wipe it for the next group in the same
             // phase -- a handful of wide stores per lane, no re-read of the matches
@@ -458,16 +578,19 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
                 uint4* P4 = reinterpret_cast<uint4*>(P);
                 for (uint32_t i = threadIdx.x; i < (uint32_t)(((size_t)S.n_slots * sizeof(PT) + 15) / 16); i += kSolveBlockThreads) P4[i] = make_uint4(0, 0, 0, 0);
             }
-            __syncthreads();
+            mark(4);
+            lds_barrier();
+            mark(5);
             // rows of the tile -> global bitmap.  No barrier behind it: O is written again only after the barrier that
             // follows the next evaluation, and the next group's presence build touches P alone
-            for (uint32_t i = threadIdx.x; i < nd * tw; i += kSolveBlockThreads) {
-                const uint32_t j = i / tw, c = i - j * tw;
-                S.bitmap[(d0 + j) * bm_words + w0 + c] = O[j * tile_words + c];
+            // (a wave stores whole rows -- two at a time while a row is at most 32 words -- so no index is divided)
+            {
+                const uint32_t per = tw <= 32 ? 2u : 1u, c = per == 2 ? lane & 31u : lane;
+                for (uint32_t j = wave * per + (per == 2 ? lane >> 5 : 0u); j < nd; j += kWaves * per)
+                    if (c < tw) S.bitmap[(d0 + j) * bm_words + w0 + c] = O[j * ostride + c];
             }
+            mark(6);
         }
-
-        prefetch_terms();
 
         // ---- 3. (HBM) clear the touched entries of P for the next group ----------------------------------------------
         if (!P_LDS) {
@@ -491,13 +614,15 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
             __syncthreads();
         }
     }
+    if (DBG && (dbg & 8) && lane == 0 && S.dbg_out)
+        for (int ph = 0; ph < 8; ph++) atomicAdd(&S.dbg_out[wave * 8 + ph], tl[ph]);
 }
 
 }  // namespace
 
 size_t solve_lds_bytes(uint32_t n_slots, uint32_t tile_words, uint32_t group_docs, bool p_in_lds, uint32_t prog_words,
                        uint32_t n_exprs, bool prog_in_lds) {
-    return (p_in_lds ? (((size_t)n_slots * (group_docs / 8) + 15) & ~(size_t)15) : 0) + (size_t)64 * tile_words * 4 +
+    return (p_in_lds ? (((size_t)n_slots * (group_docs / 8) + 15) & ~(size_t)15) : 0) + (size_t)64 * (tile_words | 1u) * 4 +
            (size_t)tile_words * 32 * 8 + (prog_in_lds ? ((size_t)prog_words + 2 * (size_t)n_exprs + 1) * 4 : 0);
 }
 
@@ -505,7 +630,7 @@ namespace {
 template <int G>
 hipError_t launch_g(const SolveParams& S, bool p_in_lds, bool prog_in_lds, unsigned grid, size_t lds, hipStream_t st) {
     using Kern = void (*)(const SolveParams);
-    const bool io = S.has_inord != 0;
+    const bool io = S.has_rare != 0;
     const Kern fn = p_in_lds ? (prog_in_lds ? (io ? k_solve_groups<true, true, G, true> : k_solve_groups<true, true, G, false>)
                                             : (io ? k_solve_groups<true, false, G, true> : k_solve_groups<true, false, G, false>))
                              : (prog_in_lds ? (io ? k_solve_groups<false, true, 64, true> : k_solve_groups<false, true, 64, false>)

@@ -164,6 +164,62 @@ def test_solver_fixtures_on_gpu(eng):
         assert bool(got[d, 0] >> d & 1) is c[2], c
 
 
+def test_not_over_a_one_leaf_inord_group(eng):
+    """`not (inord("a"))`: a group of one leaf needs no position algebra (no INORD word is emitted), but the NOT on top of
+    it survives the push-down to the leaves -- in a program set WITHOUT any other INORD group the solver must still take
+    the variant that knows NOT words"""
+    o = both(eng, ["a", "b"])
+    exprs = ['not (inord("a"))', '"b" and not (inord("a"))', 'not (inord("a")) or "b"', '"a"']
+    o.set_expressions(exprs, True)
+    progs, _ = _programs(o, eng, exprs, True)
+    eng.set_programs(progs)
+    blob, off = docs(["a", "b", "ab", "", "xx"])
+    got = eng.process(blob, off)
+    assert np.array_equal(got, o.process(blob, off))
+    assert [int(x) & 0xF for x in got[:, 0]] == [0b1000, 0b0111, 0b1100, 0b0101, 0b0101]
+
+
+def _nested(rng, letters, depth):
+    """an expression whose accumulator stack gets `depth` deep in the fused form: both operands of the operator are
+    subtrees, the right one nests on"""
+    def leafpair():
+        a, b = rng.choice(letters, 2)
+        return '(%s"%s" %s "%s")' % ("not " if rng.integers(3) == 0 else "", a, "and" if rng.integers(2) else "or", b)
+    e = leafpair()
+    for _ in range(depth):
+        e = "(%s %s %s)" % (leafpair(), "and" if rng.integers(2) else "or", e)
+        if rng.integers(4) == 0:
+            e = "not " + e
+    return e
+
+
+@pytest.mark.parametrize("group_docs", [None, "16", "0"])
+def test_nested_expressions_register_and_scratch_stacks(eng, monkeypatch, group_docs):
+    """programs that nest 0..2 deep run on the two-register interpreter, 3..4 on the four-register one, deeper ones spill
+    to scratch inside it (gft_solve.hip run_program); mixed in one program set, with and without INORD groups"""
+    if group_docs:
+        monkeypatch.setenv("GFT_SOLVE_GROUP_DOCS", group_docs)
+    rng = np.random.default_rng(77)
+    letters = list("abcdefgh")
+    o = both(eng, letters)
+    for with_inord in (False, True):
+        exprs = [_nested(rng, letters, d) for d in (0, 1, 2, 3, 4, 5, 6, 9, 17, 40) for _ in range(12)]
+        exprs += ['"a"', 'not "b"', '"a" and "b" or "c"']
+        if with_inord:
+            exprs += ['inord("a" and "b") and %s' % _nested(rng, letters, 5), 'not (inord("c" and ("d" or "a")))']
+        order = rng.permutation(len(exprs))
+        exprs = [exprs[i] for i in order]
+        o.set_expressions(exprs, True)
+        progs, _ = _programs(o, eng, exprs, True)
+        eng.set_programs(progs)
+        texts = ["".join(rng.choice(letters + ["x", "y"], int(rng.integers(0, 7)))) for _ in range(300)]
+        blob, off = docs(texts)
+        want = o.process(blob, off)
+        assert np.array_equal(eng.process(blob, off), want)
+        bits = int(np.unpackbits(want.view(np.uint8)).sum())
+        assert 0 < bits < 300 * len(exprs)
+
+
 def test_many_short_terms_overflow_records(eng):
     """more than 254 distinct short-term records: LDS ids run out and the overflow table in global memory takes over
     (scan2_tables.cpp short3_big); dense matches also shrink the work units (adaptive unit size)"""

@@ -382,6 +382,12 @@ __device__ __forceinline__ AT run_program(const SolveParams& S, const PT* P, con
 // compiler as usual and waited for where they are read.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// atomic OR into the LDS word at byte offset `at` (the presence matrix starts at LDS address 0: checked in the kernel)
+using lds_word = __attribute__((address_space(3))) uint32_t;
+__device__ __forceinline__ void lds_or(uint32_t at, uint32_t bits) {
+    __hip_atomic_fetch_or(reinterpret_cast<lds_word*>((size_t)at), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // PROG_LDS: the fused programs (and their offsets) are staged in LDS once per workgroup, so the interpreter's
 // dependent word-after-word fetches cost an LDS round trip instead of an L2 one
 template <int G> struct PType { using type = uint64_t; };
@@ -408,6 +414,7 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
     PT* P = P_LDS ? reinterpret_cast<PT*>(smem) : reinterpret_cast<PT*>(S.p_scratch + (size_t)blockIdx.x * S.n_slots);
     uint32_t* O = reinterpret_cast<uint32_t*>(smem + (P_LDS ? (((size_t)S.n_slots * sizeof(PT) + 15) & ~(size_t)15) : 0));   // [64][tile_words | 1]
     uint32_t* Pw = reinterpret_cast<uint32_t*>(P);
+    if (P_LDS && (uint32_t)(uintptr_t)(lds_word*)smem != 0) __builtin_trap();   // lds_or: P at LDS address 0 (no static LDS in this file)
     const uint32_t ostride = tile_words | 1u;                   // odd row stride: the transposed columns land in different banks
     uint64_t* R = reinterpret_cast<uint64_t*>(O + 64 * ostride);      // [tile_words * 32] results by expression
     uint32_t* lprog = reinterpret_cast<uint32_t*>(R + tile_words * 32);  // [fprog_words] when PROG_LDS
@@ -466,6 +473,15 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
     auto mark = [&](int ph) {
         if (DBG && (dbg & 8)) { const unsigned long long now = clock64(); tl[ph] += now - tprev; tprev = now; }
     };
+    // rows of an output tile -> global bitmap: a wave stores whole rows -- two at a time while a row is at most 32
+    // words -- so no index is divided
+    auto store_rows = [&](uint64_t d0, uint32_t nd, uint32_t w0, uint32_t tw) {
+        const uint32_t per = tw <= 32 ? 2u : 1u, c = per == 2 ? lane & 31u : lane;
+        for (uint32_t j = wave * per + (per == 2 ? lane >> 5 : 0u); j < nd; j += kWaves * per)
+            if (c < tw) S.bitmap[(d0 + j) * bm_words + w0 + c] = O[j * ostride + c];
+    };
+    uint64_t pend_d0 = 0;
+    uint32_t pend_nd = 0, pend_w0 = 0, pend_tw = 0;             // the last tile of the group before (nd = 0: none)
     UnitPf cur, nxt;
     Range rng;
     fetch_range(blockIdx.x, rng);
@@ -486,7 +502,9 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
                 const uint64_t s = pf ? cur.s : S.unit_start[u];
                 const uint32_t n = pf ? cur.n : S.unit_count[u];
                 const uint32_t j = (uint32_t)((pf ? cur.doc : S.units[u].doc) - d0);
-                // kPfTerms slab entries per lane are in flight at a time
+                const uint32_t j_word = (j >> 5) * 4, j_bit = 1u << (j & 31);
+                // kPfTerms slab entries per lane are in flight at a time.  The LDS unit retires about two lane-atomics per
+                // cycle whatever the addresses are, so only the lanes with an entry issue one
                 for (uint32_t i = member; i < n; i += kPfTerms * kTeam) {
                     uint32_t t[kPfTerms];
                     if (pf && i == member) {
@@ -499,9 +517,17 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
 #pragma unroll
                     for (int q = 0; q < kPfTerms; q++)
                         if (i + q * kTeam < n) {
-                            const size_t bp = (size_t)t[q] * G + j;              // bit j of element t
-                            if (P_LDS) __hip_atomic_fetch_or(&Pw[bp >> 5], 1u << (bp & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            else atomicOr(&Pw[bp >> 5], 1u << (bp & 31));
+                            // (timing study 16: the same number of atomics, scattered -- same-word collisions cost nothing)
+                            const uint32_t tq = DBG && (dbg & 16) ? (t[q] + threadIdx.x * 37u) % (S.n_slots - 1) : t[q];
+                            if (G == 64 && P_LDS) {                                 // bit j of element t: word t * 2 + j / 32
+                                // (timing study 32: a plain store in place of the atomic -- what does the read-modify-write cost?)
+                                if (DBG && (dbg & 32)) *reinterpret_cast<lds_word*>((size_t)(tq * 8 + j_word)) = j_bit;
+                                else lds_or(tq * 8 + j_word, j_bit);
+                            } else {
+                                const uint32_t bp = tq * (uint32_t)G + j;          // (n_slots * G < 2^32)
+                                if (P_LDS) lds_or((bp >> 5) * 4, 1u << (bp & 31));
+                                else atomicOr(&Pw[bp >> 5], 1u << (bp & 31));
+                            }
                         }
                 }
             }
@@ -520,6 +546,9 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
         if (P_LDS) lds_barrier();
         else { __threadfence_block(); __syncthreads(); }       // (P in HBM: the other waves' atomics must be visible)
         mark(1);
+        store_rows(pend_d0, pend_nd, pend_w0, pend_tw);          // (the group before; see `pend` below)
+        pend_nd = 0;
+        mark(6);
 
         // the next group's slab entries, the unit of the group after it, the range of the one after that: in flight
         // during the evaluation (no __syncthreads() from here to the next build: lds_barrier does not wait for them).
@@ -581,14 +610,12 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
             mark(4);
             lds_barrier();
             mark(5);
-            // rows of the tile -> global bitmap.  No barrier behind it: O is written again only after the barrier that
-            // follows the next evaluation, and the next group's presence build touches P alone
-            // (a wave stores whole rows -- two at a time while a row is at most 32 words -- so no index is divided)
-            {
-                const uint32_t per = tw <= 32 ? 2u : 1u, c = per == 2 ? lane & 31u : lane;
-                for (uint32_t j = wave * per + (per == 2 ? lane >> 5 : 0u); j < nd; j += kWaves * per)
-                    if (c < tw) S.bitmap[(d0 + j) * bm_words + w0 + c] = O[j * ostride + c];
-            }
+            // rows of the tile -> global bitmap.  Those of a group's last (normally only) tile wait until the next group's
+            // presence matrix is built (`pend`): stores issued HERE would be younger than the prefetch loads in flight, and
+            // the s_waitcnt vmcnt(0) in front of the next build would wait for them to reach L2 (1 500 cycles per group).
+            // No barrier behind either: O is written again only after the barrier that follows the next evaluation.
+            if (w0 + tile_words >= bm_words) { pend_d0 = d0; pend_nd = nd; pend_w0 = w0; pend_tw = tw; }
+            else store_rows(d0, nd, w0, tw);
             mark(6);
         }
 
@@ -614,6 +641,7 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
             __syncthreads();
         }
     }
+    store_rows(pend_d0, pend_nd, pend_w0, pend_tw);
     if (DBG && (dbg & 8) && lane == 0 && S.dbg_out)
         for (int ph = 0; ph < 8; ph++) atomicAdd(&S.dbg_out[wave * 8 + ph], tl[ph]);
 }

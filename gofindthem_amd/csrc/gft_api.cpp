@@ -578,15 +578,25 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         // the benchmark; GFT_SCAN_PRIO=0 switches it off)
         P.prio = e->opt_scan_prio;
         P.dbg_counters = nullptr;
-        if (P.dbg & 2) {
-            HIP_TRY(e->d_dbg.ensure(32), "debug alloc");
-            HIP_TRY(hipMemsetAsync(e->d_dbg.p, 0, 32, st), "memset");
+        if (P.dbg & (2 | 64)) {
+            HIP_TRY(e->d_dbg.ensure(128), "debug alloc");
+            HIP_TRY(hipMemsetAsync(e->d_dbg.p, 0, 128, st), "memset");
             P.dbg_counters = e->d_dbg.as<uint64_t>();
         }
         {
             ProfScope ps(e, "scan");
             // gft_scan2 serves both paths (ordered for CSR results, unordered + balanced for the solver)
             HIP_TRY(launch_scan2(P, e->scan2_k2_waves, e->n_cus, st), "scan kernel launch");
+        }
+        if (P.dbg & 64) {
+            // phase clocks: a wave's cycles per unit (0 first bytes, 1 filter, 2 candidate list, 3 stage A, 4 stage B, 5 flush,
+            // 7 unit record), averaged over all units
+            uint64_t t[16];
+            HIP_TRY(hipMemcpyAsync(t, e->d_dbg.p, sizeof t, hipMemcpyDeviceToHost, st), "debug read-back");
+            HIP_TRY(hipStreamSynchronize(st), "debug read-back");
+            fprintf(stderr, "[gft scan debug] wave cycles per unit: first bytes %.0f, filter %.0f, list %.0f, stage A %.0f, stage B %.0f, flush %.0f, unit record %.0f\n",
+                    (double)t[4] / n_units, (double)t[5] / n_units, (double)t[6] / n_units, (double)t[7] / n_units, (double)t[8] / n_units,
+                    (double)t[9] / n_units, (double)t[11] / n_units);
         }
         if (e->deferred) return GFT_OK;                       // (deferred_check reads the cursor after the solver)
         uint64_t ct[3] = {0, 0, 0};

@@ -510,6 +510,11 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
     lds_u32* lfilt = (lds_u32*)256;
     if ((uint32_t)(uintptr_t)(lds_u8*)smem != 0) __builtin_trap();   // see lds_u8
 
+    // phase clocks of the timing studies (GFT_SCAN_DEBUG & 64): cycles of this wave per phase, summed into dbg_counters[4..11]
+    unsigned long long tl[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = DBG ? clock64() : 0;
+    auto mark = [&](int ph) {
+        if (DBG && (P.dbg & 64)) { const unsigned long long now = clock64(); tl[ph] += now - tprev; tprev = now; }
+    };
     uint64_t slab_next = 0, wave_matches = 0;   // wave-uniform
     bool told_nonascii = false;                  // (one atomic per wave, not one per unit: they all hit the same word)
     uint32_t slab_left = 0;
@@ -526,6 +531,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
                       (uint32_t)__builtin_amdgcn_readfirstlane(un_n.hi)};
         const uint64_t doc_abs = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(abs_n >> 32)) << 32 |
                                  (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)abs_n);
+        mark(7);
         const bool more_units = u + stride < P.n_units;
         if (more_units) un_n = P.units[u + stride];
         const Ctx c{P, cls, filt, P.short3_bytes ? short3 : nullptr, fpt, lrec, P.text + doc_abs, doc_abs, kp2,
@@ -561,6 +567,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
                                k3 = my_lo >= 3 ? lcls[(hist >> 8) & 0xFF] : P.pad_class;
                 cp = k1; pm1 = mad24s(k2, kp, k1); pm2 = mad24s(k3, kp, k2);
             }
+            mark(0);
             uint32_t acc = 0, hib = 0;                           // hib: OR of the lane's text (a byte >= 0x80 anywhere?)
             const uint32_t ndw = C >> 2;                         // dwords per lane (wave-uniform, <= 32)
             const uint32_t npieces = (ndw + 3) >> 2;
@@ -603,6 +610,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
             m3 = nvalid >= 128 ? m3 : (nvalid > 96 ? m3 & ((1u << (nvalid - 96)) - 1) : 0);
         }
 
+        mark(1);
         if (P.prio) __builtin_amdgcn_s_setprio(1);
         if (more_units) abs_n = P.doc_off[un_n.doc];
 
@@ -660,6 +668,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
                     // end a term of length >= 4 are compacted in place to the front of the list (write index <= read index)
                     // (kStageAWays candidates per lane and trip: their loads and table lookups are in flight together;
                     // lanes past the end of the list work on a copy of entry 0 and stay silent)
+                    mark(2);
                     if (P.prio) __builtin_amdgcn_s_setprio(2);
                     uint32_t ns = 0;
                     // (the list entries and text of trip t + 1 are fetched while trip t is worked on)
@@ -707,6 +716,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     if (DBG && (P.dbg & 2)) { if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(KARG(dbg_counters) + 2), (unsigned long long)ns); }
+                    mark(3);
                     if (P.prio) __builtin_amdgcn_s_setprio(3);
                     // stage B: the survivors, densely packed over the lanes, go to the L2 bucket table; the room behind
                     // them in the candidate list parks the entries of multi-term buckets
@@ -732,6 +742,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     l0 = l1;
+                    mark(4);
                 }
                 const uint32_t nh = nf;
                 if (nh <= kScan2FifoCap) {
@@ -758,6 +769,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
                     done = true;
                 }
                 __builtin_amdgcn_wave_barrier();
+                mark(5);
             }
             if (ftotal == 0 && lane == 0) { KARG(unit_start)[u] = slab_next; KARG(unit_count)[u] = 0; }
             if (done) continue;
@@ -803,6 +815,8 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
     }
     if (lane == 0 && wave_matches)
         atomicAdd(reinterpret_cast<unsigned long long*>(KARG(n_matches)), (unsigned long long)wave_matches);
+    if (DBG && (P.dbg & 64) && lane == 0 && KARG(dbg_counters))
+        for (int ph = 0; ph < 8; ph++) atomicAdd(reinterpret_cast<unsigned long long*>(KARG(dbg_counters) + 4 + ph), tl[ph]);
 }
 
 }  // namespace

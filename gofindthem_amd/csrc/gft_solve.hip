@@ -444,6 +444,11 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
     // -- the build of the common case is LDS atomics on registers.  All of it stays in VECTOR registers and every load
     // is unconditional (indices clamped, validity checked where the value is used): a scalar value or a predicate derived
     // from a load would make the wave wait for it on the spot.
+    // PIPE: the kernel variant with the NOT / INORD path has no registers to spare (the compiler would spill the ones the
+    // prefetch is landing in, and wait for them on the spot): there only the range of units travels ahead, the unit and its
+    // entries are read where they are needed, two round trips in front of every build (keeping the unit in flight as
+    // well already costs more in spills than it hides: 0.81 against 0.66 ms with 50 % INORD expressions)
+    constexpr bool PIPE = !RARE;
     constexpr int kPfTerms = 12;
     struct UnitPf { uint64_t u, U1, s; uint32_t n, doc; };      // u: this thread's first unit (valid if u < U1)
     struct Range { uint64_t U0, U1; };
@@ -485,17 +490,20 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
     UnitPf cur, nxt;
     Range rng;
     fetch_range(blockIdx.x, rng);
-    fetch_unit(rng, cur);
-    fetch_range((uint64_t)blockIdx.x + gridDim.x, rng);
-    fetch_unit(rng, nxt);
-    fetch_range((uint64_t)blockIdx.x + 2 * (uint64_t)gridDim.x, rng);
-    fetch_terms(cur);
+    if (PIPE) {
+        fetch_unit(rng, cur);
+        fetch_range((uint64_t)blockIdx.x + gridDim.x, rng);
+        fetch_unit(rng, nxt);
+        fetch_range((uint64_t)blockIdx.x + 2 * (uint64_t)gridDim.x, rng);
+        fetch_terms(cur);
+    }
     for (uint64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
         const uint64_t d0 = g * G;
         const uint32_t nd = (uint32_t)(S.n_docs - d0 < (uint64_t)G ? S.n_docs - d0 : (uint64_t)G);
 
         // ---- 1. presence matrix ------------------------------------------------------------------------------
         mark(7);
+        if (!PIPE) { fetch_unit(rng, cur); fetch_terms(cur); }
         if (!(dbg & 1)) {
             bool pf = true;                                       // first (normally only) unit of this team: prefetched
             for (uint64_t u = cur.u; u < cur.U1; u += kTeams, pf = false) {
@@ -554,10 +562,12 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
         // during the evaluation (no __syncthreads() from here to the next build: lds_barrier does not wait for them).
         // Straight-line and unconditional, so that the loaded registers ARE the loop-carried ones: a copy of a register
         // that a load is still filling makes the wave wait for the load on the spot.
-        cur = nxt;
-        fetch_terms(cur);
-        fetch_unit(rng, nxt);
-        fetch_range(g + 3 * (uint64_t)gridDim.x, rng);
+        if (PIPE) {
+            cur = nxt;
+            fetch_terms(cur);
+            fetch_unit(rng, nxt);
+            fetch_range(g + 3 * (uint64_t)gridDim.x, rng);
+        } else fetch_range(g + gridDim.x, rng);
 
         // ---- 2. expressions, tile by tile over the bitmap words ------------------------------------------------------
         const uint64_t valid = nd == 64 ? ~0ull : ((1ull << nd) - 1);

@@ -37,6 +37,13 @@ rocprofv3 --kernel-trace --stats -d $O/stats_c5 -o run --output-format csv -- py
 find $O/stats_c5 -name "*kernel_stats.csv" -exec cp {} $O/r2_c5_kernel_stats.csv \;
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT -d $O/sq_c5 -o run --output-format csv -- python3 bench.py --steps 3 --warmup 1 --cpu-docs 0 $C5 > $O/sq_c5.log 2>&1
 python3 tools/sq_summary.py $O/sq_c5 --docs 200000 > $O/r2_c5_sq_counters.json
+# the same configuration with 50 % INORD expressions (the solver variant with the position algebra)
+python3 bench.py --steps 10 --warmup 2 --inord 0.5 --cpu-docs 20000 > $O/bench_inord.log 2>&1
+tail -1 $O/bench_inord.log > $O/r2_inord_bench.json
+# phase clocks of the timing-study kernel variants: cycles per phase (solver: per group and wave; scan: per unit)
+python3 tools/probe_solve.py --docs 1000000 --modes 8 2>&1 | grep "solve debug\|GFT_SOLVE" | tail -18 > $O/r2_solve_phase_clocks.txt || true
+python3 tools/probe_solve.py --docs 1000000 --inord 0.5 --modes 8 2>&1 | grep "solve debug\|GFT_SOLVE" | tail -18 > $O/r2_solve_phase_clocks_inord.txt || true
+GFT_SCAN_KERNEL=scan2 python3 tools/probe_scan.py --docs 1000000 --unordered --modes 64,0 --reps 3 2>&1 | grep "scan debug\|GFT_SCAN" | tail -3 > $O/r2_scan_phase_clocks.txt || true
 ./tools/ubench/ubench > $O/r2_ubench_valu.txt 2>&1 || true
 ./tools/ubench/fbench > $O/r2_ubench_filter_lds.txt 2>&1 || true
 ./tools/ubench/gbench > $O/r2_ubench_gather.txt 2>&1 || true

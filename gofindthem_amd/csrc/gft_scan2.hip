@@ -486,7 +486,8 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
     uint8_t* short3 = smem + 256 + (size_t)P.filter_words * 4;
     uint8_t* fpt = short3 + P.short3_bytes;
     uint32_t* lrec = reinterpret_cast<uint32_t*>(fpt + (FPT_LDS ? kScan2FptSize : 0));
-    uint8_t* wave_lds_all = reinterpret_cast<uint8_t*>(lrec) + ((P.shorts_words * 4 + 15) & ~15u);
+    uint32_t* wg_next = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(lrec) + ((P.shorts_words * 4 + 15) & ~15u));   // work counter
+    uint8_t* wave_lds_all = reinterpret_cast<uint8_t*>(wg_next) + 16;
 
     for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) cls[i] = P.cls[i];
     for (uint32_t i = threadIdx.x; i < P.filter_words; i += blockDim.x) filt[i] = P.filter[i];
@@ -495,11 +496,11 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
     for (uint32_t i = threadIdx.x; FPT_LDS && i < kScan2FptSize / 4; i += blockDim.x)
         reinterpret_cast<uint32_t*>(fpt)[i] = reinterpret_cast<const uint32_t*>(P.fpt)[i];
     for (uint32_t i = threadIdx.x; i < P.shorts_words; i += blockDim.x) lrec[i] = P.shorts_packed[i];
+    if (threadIdx.x == 0) *wg_next = blockDim.x >> 6;            // (every wave starts with the item of its own number)
     __syncthreads();
 
     // (the wave index is the same in all lanes: as a scalar, the unit bookkeeping below stays off the vector ALU)
     const uint32_t lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t kWaves = blockDim.x >> 6;
     // per-wave LDS region: [fifo / ordered staging: kScan2FifoCap x 8 B][candidate list: cand_cap x 2 B]
     uint8_t* wave_lds = wave_lds_all + (size_t)wave * (kScan2FifoCap * 8 + P.cand_cap * 2);
     uint2* fifo = reinterpret_cast<uint2*>(wave_lds);
@@ -519,21 +520,34 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
     bool told_nonascii = false;                  // (one atomic per wave, not one per unit: they all hit the same word)
     uint32_t slab_left = 0;
 
-    // the next unit's record and document offset are fetched while the current unit is processed
-    const uint64_t stride = (uint64_t)gridDim.x * kWaves;
-    uint64_t u = (uint64_t)blockIdx.x * kWaves + wave;
+    // Work distribution.  The workgroup owns the units  b * waves + k * (grid * waves) + [0, waves)  of every round k -- the
+    // 4 096 waves of the grid move through the text side by side -- and its waves take them one by one from a counter in
+    // LDS (item i = round i / waves, slot i % waves), so a wave that drew cheap documents simply takes more: with one fixed
+    // slot per wave the slowest of the 4 096 waves took 8.7 % longer than the average one at 244 units per wave, 50 % at
+    // 30, while the sums over a whole workgroup scatter by 1.6 %.  (A counter in global memory does not work: same-address
+    // atomics retire at ~ 15 ns each across the device, 45 000 tickets for 9 % of the units cost 0.46 ms.)
+    // The next unit's record and document offset are fetched while the current unit is processed.
+    const uint32_t wg_waves = blockDim.x >> 6;
+    const uint64_t round_units = (uint64_t)gridDim.x * wg_waves, wg_first = (uint64_t)blockIdx.x * wg_waves;
+    auto unit_of = [&](uint32_t item) { return (uint64_t)(item / wg_waves) * round_units + wg_first + item % wg_waves; };
+    uint64_t u = wg_first + wave, nu = 0;                         // wave-uniform
     Unit un_n{0, 0, 0};
     uint64_t abs_n = 0;
     if (u < P.n_units) { un_n = P.units[u]; abs_n = P.doc_off[un_n.doc]; }
-    for (; u < P.n_units; u += stride) {
+    for (; u < P.n_units; u = nu) {
         // the unit's record is the same in all lanes: in scalar registers the bookkeeping below costs no VALU slots
         const Unit un{(uint32_t)__builtin_amdgcn_readfirstlane(un_n.doc), (uint32_t)__builtin_amdgcn_readfirstlane(un_n.lo),
                       (uint32_t)__builtin_amdgcn_readfirstlane(un_n.hi)};
         const uint64_t doc_abs = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(abs_n >> 32)) << 32 |
                                  (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)abs_n);
+        {
+            uint32_t item = 0;
+            if (lane == 0) item = __hip_atomic_fetch_add(wg_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            nu = unit_of((uint32_t)__builtin_amdgcn_readfirstlane(item));
+        }
         mark(7);
-        const bool more_units = u + stride < P.n_units;
-        if (more_units) un_n = P.units[u + stride];
+        const bool more_units = nu < P.n_units;
+        if (more_units) un_n = P.units[nu];
         const Ctx c{P, cls, filt, P.short3_bytes ? short3 : nullptr, fpt, lrec, P.text + doc_abs, doc_abs, kp2,
                     doc_abs < 7, doc_abs < 23, un.lo, un.hi, doc_abs + un.hi + 4 > P.text_bytes, DBG ? P.dbg : 0u};
         // A term whose window ends up to kScan2MaxOff bytes before the unit may itself end inside it: those positions
@@ -815,14 +829,19 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
     }
     if (lane == 0 && wave_matches)
         atomicAdd(reinterpret_cast<unsigned long long*>(KARG(n_matches)), (unsigned long long)wave_matches);
-    if (DBG && (P.dbg & 64) && lane == 0 && KARG(dbg_counters))
-        for (int ph = 0; ph < 8; ph++) atomicAdd(reinterpret_cast<unsigned long long*>(KARG(dbg_counters) + 4 + ph), tl[ph]);
+    if (DBG && (P.dbg & 64) && lane == 0 && KARG(dbg_counters)) {
+        unsigned long long all = 0;
+        for (int ph = 0; ph < 8; ph++) { atomicAdd(reinterpret_cast<unsigned long long*>(KARG(dbg_counters) + 4 + ph), tl[ph]); all += tl[ph]; }
+        atomicMax(reinterpret_cast<unsigned long long*>(KARG(dbg_counters) + 12), all);      // the wave that finishes last
+        atomicAdd(reinterpret_cast<unsigned long long*>(KARG(dbg_counters) + 13), 1ull);
+    }
 }
 
 }  // namespace
 
 static size_t scan2_fixed_lds(uint32_t filter_words, uint32_t short3_bytes, uint32_t shorts_words, uint32_t fpt_lds_bytes) {
-    return 256 + (size_t)filter_words * 4 + short3_bytes + fpt_lds_bytes + (((size_t)shorts_words * 4 + 15) & ~(size_t)15);
+    return 256 + (size_t)filter_words * 4 + short3_bytes + fpt_lds_bytes + (((size_t)shorts_words * 4 + 15) & ~(size_t)15) +
+           16;       // the workgroup's work counter
 }
 
 bool scan2_plan(uint32_t filter_words, uint32_t short3_bytes, uint32_t shorts_words, uint32_t fpt_lds_bytes, size_t lds_max,

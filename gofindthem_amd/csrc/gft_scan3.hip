@@ -455,7 +455,8 @@ __global__ void __launch_bounds__(kScan3Threads) k_scan3(const Scan3Params P) {
     extern __shared__ __align__(16) uint8_t smem[];
     const uint32_t off_filt = 256, off_s3 = off_filt + P.filter_words * 4, off_rec = off_s3 + P.short3_bytes,
                    off_bloom = off_rec + ((P.srec_words * 4 + 15) & ~15u),
-                   off_wave = off_bloom + (BLOOM_LDS ? 4u << P.bloom_lg : 0u);
+                   off_next = off_bloom + (BLOOM_LDS ? 4u << P.bloom_lg : 0u),      // the workgroup's work counter
+                   off_wave = off_next + 16;
     {
         uint32_t* s32 = reinterpret_cast<uint32_t*>(smem);
         for (uint32_t i = threadIdx.x; i < 64; i += blockDim.x) s32[i] = reinterpret_cast<const uint32_t*>(P.cls)[i];
@@ -463,6 +464,7 @@ __global__ void __launch_bounds__(kScan3Threads) k_scan3(const Scan3Params P) {
         for (uint32_t i = threadIdx.x; i < P.short3_bytes / 4; i += blockDim.x) s32[off_s3 / 4 + i] = reinterpret_cast<const uint32_t*>(P.short3)[i];
         for (uint32_t i = threadIdx.x; i < P.srec_words; i += blockDim.x) s32[off_rec / 4 + i] = P.srec[i];
         for (uint32_t i = threadIdx.x; BLOOM_LDS && i < (1u << P.bloom_lg); i += blockDim.x) s32[off_bloom / 4 + i] = P.bloom[i];
+        if (threadIdx.x == 0) s32[off_next / 4] = blockDim.x >> 6;   // (every wave starts with the item of its own number)
     }
     __syncthreads();
     if ((uint32_t)(uintptr_t)(lds_u8*)smem != 0) __builtin_trap();   // see lds_u8
@@ -487,19 +489,29 @@ __global__ void __launch_bounds__(kScan3Threads) k_scan3(const Scan3Params P) {
     bool told_nonascii = false;                  // (one atomic per wave, not one per unit: they all hit the same word)
     uint32_t slab_left = 0;
 
-    // the next unit's record and document offset are fetched while the current unit is processed
-    const uint64_t stride = (uint64_t)gridDim.x * kWaves;
-    uint64_t u = (uint64_t)blockIdx.x * kWaves + wave;
+    // Work distribution as in gft_scan2.hip: in round k the workgroup owns the units  k * (grid * waves) + b * waves +
+    // [0, waves), and its waves take them one by one from a counter in LDS (item i = round i / waves, slot i % waves), so
+    // a wave that drew cheap documents simply takes more.
+    // The next unit's record and document offset are fetched while the current unit is processed.
+    uint32_t* wg_next = reinterpret_cast<uint32_t*>(smem + off_next);
+    const uint64_t round_units = (uint64_t)gridDim.x * kWaves, wg_first = (uint64_t)blockIdx.x * kWaves;
+    auto unit_of = [&](uint32_t item) { return (uint64_t)(item / kWaves) * round_units + wg_first + item % kWaves; };
+    uint64_t u = wg_first + wave, nu = 0;                         // wave-uniform
     Unit un_n{0, 0, 0};
     uint64_t abs_n = 0;
     if (u < P.n_units) { un_n = P.units[u]; abs_n = P.doc_off[un_n.doc]; }
-    for (; u < P.n_units; u += stride) {
+    for (; u < P.n_units; u = nu) {
         const Unit un{(uint32_t)__builtin_amdgcn_readfirstlane(un_n.doc), (uint32_t)__builtin_amdgcn_readfirstlane(un_n.lo),
                       (uint32_t)__builtin_amdgcn_readfirstlane(un_n.hi)};
         const uint64_t doc_abs = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(abs_n >> 32)) << 32 |
                                  (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)abs_n);
-        const bool more_units = u + stride < P.n_units;
-        if (more_units) un_n = P.units[u + stride];
+        {
+            uint32_t item = 0;
+            if (lane == 0) item = __hip_atomic_fetch_add(wg_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            nu = unit_of((uint32_t)__builtin_amdgcn_readfirstlane(item));
+        }
+        const bool more_units = nu < P.n_units;
+        if (more_units) un_n = P.units[nu];
         const Ctx c{P, P.text + doc_abs, doc_abs, doc_abs < 7, doc_abs < 23, un.lo, un.hi, doc_abs + un.hi + 8 > P.text_bytes};
         const uint32_t own = un.hi - un.lo;
         const uint32_t nr = (own + 1023) >> 10;                      // rounds (<= 8)
@@ -717,7 +729,8 @@ __global__ void __launch_bounds__(kScan3Threads) k_scan3(const Scan3Params P) {
 }  // namespace
 
 static size_t scan3_fixed_lds(uint32_t filter_words, uint32_t short3_bytes, uint32_t srec_words, uint32_t bloom_lds_bytes) {
-    return 256 + (size_t)filter_words * 4 + short3_bytes + (((size_t)srec_words * 4 + 15) & ~(size_t)15) + bloom_lds_bytes;
+    return 256 + (size_t)filter_words * 4 + short3_bytes + (((size_t)srec_words * 4 + 15) & ~(size_t)15) + bloom_lds_bytes +
+           16;       // the workgroup's work counter
 }
 
 bool scan3_plan(uint32_t filter_words, uint32_t short3_bytes, uint32_t srec_words, uint32_t bloom_lds_bytes, size_t lds_max,

@@ -114,6 +114,9 @@ struct gft_engine {
     DevBuf d_prog, d_prog_off;            // public postfix words (INORD group subtrees are read from these)
     DevBuf d_fprog, d_fprog_off, d_groups; // fused internal form + INORD group table
     DevBuf d_solve_dbg;                    // GFT_SOLVE_DEBUG & 8: phase clocks
+    bool hint_single = false;              // the batch before was one unit per document (k_units_single may serve the next)
+    bool deferred_single = false;          // ... and this one took that path
+    uint64_t deferred_n_docs = 0;
     DevBuf d_order, d_blk_class, d_wave_blk;            // evaluation order of the programs (gft_set_programs)
     uint32_t last_solve_group_docs = 64;   // documents per solver group of the last launch (0 = presence matrix in HBM)
     DevBuf d_fprog_t, d_fblk_off;          // fused programs per sorted block of 64, transposed (read when they do not fit LDS)
@@ -399,6 +402,7 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
     hipStream_t st = e->stream;
     *n_matches = 0;
     e->deferred = false;
+    e->deferred_single = false;
     e->scan_valid_docs = ~0ull;           // the pool is about to be overwritten
     HIP_TRY(e->d_match_off.ensure((n_docs + 1) * 8), "match_off alloc");
     if (n_docs == 0) {
@@ -441,6 +445,16 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         }
         n_units = hub[n_docs]; text_lo = h_doc_off[0]; text_hi = h_doc_off[n_docs];
         HIP_TRY(hipMemcpyAsync(e->d_unit_base.p, hub.data(), (n_docs + 1) * 8, hipMemcpyHostToDevice, st), "unit upload");
+    } else if (defer_ok && !need_csr && e->hint_single && e->pool_cap > 0 &&
+               std::min(std::min(e->d_units.cap / sizeof(Unit), e->d_unit_start.cap / 8), e->d_unit_count.cap / 4) >= n_docs) {
+        // The batch before was one unit per document: this one gets its unit table from ONE launch on that assumption
+        // (k_units_single) instead of count + prefix sum + fill + clamp; deferred_check learns whether it held.
+        ProfScope ps(e, "aux");
+        HIP_TRY(launch_units_single(d_doc_off, n_docs, unit_max, e->d_units.as<Unit>(), e->d_unit_base.as<uint64_t>(),
+                                    e->d_ctl.as<uint32_t>(), st), "unit table");
+        n_units = n_docs; text_lo = 0; text_hi = ~0ull;
+        e->deferred = true; e->deferred_single = true;
+        e->deferred_unit_cap = n_docs; e->deferred_n_docs = n_docs;
     } else {
         {
             ProfScope ps(e, "aux");
@@ -454,14 +468,16 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         // into it -- deferred_check sees the true count and has the batch run again
         const uint64_t cap_units = std::min(std::min(e->d_units.cap / sizeof(Unit), e->d_unit_start.cap / 8), e->d_unit_count.cap / 4);
         e->deferred = defer_ok && !need_csr && cap_units >= n_docs && e->pool_cap > 0;
+        e->hint_single = false;                                  // (set again by deferred_check / the read-back below)
         if (e->deferred) {
             n_units = cap_units; text_lo = 0; text_hi = ~0ull;       // (the text blob is readable 64 bytes past its end: gft.h)
-            e->deferred_unit_cap = cap_units;
+            e->deferred_unit_cap = cap_units; e->deferred_n_docs = n_docs;
         } else {
             uint64_t rb[7] = {0, 0, 0, 0, 0, 0, 0};
             HIP_TRY(hipMemcpyAsync(rb, e->d_ctl.p, sizeof rb, hipMemcpyDeviceToHost, st), "readback");
             HIP_TRY(hipStreamSynchronize(st), "sync");
             n_units = rb[4]; text_lo = rb[5]; text_hi = rb[6];
+            e->hint_single = n_units == n_docs;
             const uint32_t bad_doc = (uint32_t)rb[0];
             if (text_hi < text_lo) return fail(e, GFT_E_INVALID, "doc_off is not ascending");
             if (bad_doc) return fail(e, GFT_E_INVALID, "doc_off is not ascending, or a document is longer than 4 GiB - 1 bytes (positions are 32-bit)");
@@ -478,6 +494,8 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         ProfScope ps(e, "aux");
         if (host_units) {
             if (n_units) HIP_TRY(hipMemcpyAsync(e->d_units.p, hun.data(), n_units * sizeof(Unit), hipMemcpyHostToDevice, st), "unit upload");
+        } else if (e->deferred_single) {
+            // (k_units_single has filled the table)
         } else if (e->deferred) {
             HIP_TRY(hipMemsetAsync(e->d_units.p, 0, n_units * sizeof(Unit), st), "memset");      // empty units behind the real ones
             HIP_TRY(launch_unit_fill(d_doc_off, n_docs, e->d_unit_base.as<uint64_t>(), e->d_units.as<Unit>(), st, n_units), "unit_fill");
@@ -695,6 +713,12 @@ int deferred_check(gft_engine* e, bool* again) {
     HIP_TRY(hipStreamSynchronize(e->stream), "process pipeline");
     const uint64_t cursor = rb[1], total = rb[2], n_units = rb[4], text_lo = rb[5], text_hi = rb[6];
     e->last_nonascii = (uint32_t)rb[3] != 0;
+    if (e->deferred_single && (uint32_t)(rb[3] >> 32)) {         // a document of more than one unit: the general path
+        e->hint_single = false;
+        *again = true;
+        return GFT_OK;
+    }
+    e->hint_single = n_units == e->deferred_n_docs;              // (the next batch may take the one-launch unit table)
     e->last_text_lo = text_lo; e->last_text_hi = text_hi;
     if (text_hi < text_lo) return fail(e, GFT_E_INVALID, "doc_off is not ascending");
     if ((uint32_t)rb[0]) return fail(e, GFT_E_INVALID, "doc_off is not ascending, or a document is longer than 4 GiB - 1 bytes (positions are 32-bit)");

@@ -70,6 +70,27 @@ __global__ void __launch_bounds__(256) k_unit_fill(const uint64_t* __restrict__ 
     }
 }
 
+// The whole unit table in one launch for the batch in which every document is ONE unit (the common shape: documents up to
+// unit_max bytes): units[d] = {d, 0, length}, unit_base[d] = d, and the three numbers k_pack_ctl reports.  A longer
+// document only raises ctl32[7]: the host finds it with the batch's one read-back and runs the batch again on the
+// general path (count, prefix sum, fill).
+__global__ void __launch_bounds__(256) k_units_single(const uint64_t* __restrict__ doc_off, uint64_t n_docs, uint32_t unit_max,
+                                                      Unit* __restrict__ units, uint64_t* __restrict__ unit_base,
+                                                      uint32_t* __restrict__ ctl32) {
+    const uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d == 0) {
+        uint64_t* ctl64 = reinterpret_cast<uint64_t*>(ctl32);
+        unit_base[n_docs] = n_docs;
+        ctl64[4] = n_docs; ctl64[5] = doc_off[0]; ctl64[6] = doc_off[n_docs];
+    }
+    if (d >= n_docs) return;
+    uint64_t n = doc_off[d + 1] - doc_off[d];
+    if (n > 0xFFFFFFFFull) { atomicOr(ctl32, 1u); n = 0; }       // (as k_unit_count)
+    if (n > unit_max) { atomicOr(ctl32 + 7, 1u); n = unit_max; }  // (no kernel ever sees a unit longer than unit_max)
+    units[d] = Unit{(uint32_t)d, 0u, (uint32_t)n};
+    unit_base[d] = d;
+}
+
 // unit_base[i] = min(unit_base[i], cap): after a unit table that was too small, every consumer stays inside it
 __global__ void __launch_bounds__(256) k_clamp_u64(uint64_t* __restrict__ v, uint64_t n, uint64_t cap) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -526,6 +547,13 @@ hipError_t launch_unit_fill(const uint64_t* d_doc_off, uint64_t n_docs, const ui
                             hipStream_t st, uint64_t max_units) {
     if (!n_docs) return hipSuccess;
     k_unit_fill<<<dim3((unsigned)((n_docs + 255) / 256)), dim3(256), 0, st>>>(d_doc_off, n_docs, d_unit_base, d_units, max_units);
+    return hipGetLastError();
+}
+
+hipError_t launch_units_single(const uint64_t* d_doc_off, uint64_t n_docs, uint32_t unit_max, Unit* d_units, uint64_t* d_unit_base,
+                               uint32_t* d_ctl32, hipStream_t st) {
+    if (!n_docs) return hipSuccess;
+    k_units_single<<<dim3((unsigned)((n_docs + 255) / 256)), dim3(256), 0, st>>>(d_doc_off, n_docs, unit_max, d_units, d_unit_base, d_ctl32);
     return hipGetLastError();
 }
 

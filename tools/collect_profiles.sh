@@ -43,7 +43,7 @@ tail -1 $O/bench_inord.log > $O/r2_inord_bench.json
 # phase clocks of the timing-study kernel variants: cycles per phase (solver: per group and wave; scan: per unit)
 python3 tools/probe_solve.py --docs 1000000 --modes 8 2>&1 | grep "solve debug\|GFT_SOLVE" | tail -18 > $O/r2_solve_phase_clocks.txt || true
 python3 tools/probe_solve.py --docs 1000000 --inord 0.5 --modes 8 2>&1 | grep "solve debug\|GFT_SOLVE" | tail -18 > $O/r2_solve_phase_clocks_inord.txt || true
-GFT_SCAN_KERNEL=scan2 python3 tools/probe_scan.py --docs 1000000 --unordered --modes 64,0 --reps 3 2>&1 | grep "scan debug\|GFT_SCAN" | tail -3 > $O/r2_scan_phase_clocks.txt || true
+GFT_SCAN_KERNEL=scan2 python3 tools/probe_scan.py --docs 1000000 --unordered --modes 64,0 --reps 3 2>&1 | grep "scan debug\|GFT_SCAN" | tail -4 > $O/r2_scan_phase_clocks.txt || true
 ./tools/ubench/ubench > $O/r2_ubench_valu.txt 2>&1 || true
 ./tools/ubench/fbench > $O/r2_ubench_filter_lds.txt 2>&1 || true
 ./tools/ubench/gbench > $O/r2_ubench_gather.txt 2>&1 || true

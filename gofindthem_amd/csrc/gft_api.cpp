@@ -1620,6 +1620,43 @@ int gft_debug_emulate_scan(const uint8_t* terms_blob, const uint64_t* term_off, 
     return GFT_OK;
 }
 
+int gft_debug_eval_programs(const uint32_t* prog_words, const uint64_t* prog_off, uint32_t n_exprs, uint32_t n_slots,
+                            const uint8_t* present, uint8_t* out_hit, uint32_t* out_depth) {
+    if (!prog_words || !prog_off || !out_hit || (n_slots && !present) || n_slots > (1u << kDwFieldBits)) return GFT_E_INVALID;
+    gft_engine scratch;                              // (only its error string is used, by check_program)
+    for (uint32_t i = 0; i < n_exprs; i++) {
+        if (prog_off[i + 1] < prog_off[i]) return GFT_E_INVALID;
+        const int rc = check_program(&scratch, prog_words + prog_off[i], prog_off[i + 1] - prog_off[i], n_slots, i);
+        if (rc) return rc;
+        std::vector<uint32_t> fw, groups;
+        const uint32_t depth = fuse_program(prog_words + prog_off[i], prog_off[i + 1] - prog_off[i], prog_off[i], fw, groups);
+        if (out_depth) out_depth[i] = depth;
+        // the device's data flow on one document (gft_kernels.hpp "What the kernel reads", gft_solve.hip run_program)
+        bool acc = false;
+        std::vector<bool> stack;
+        for (uint32_t f : fw) {
+            const uint32_t w = fused_to_device(f);
+            if (w & kDwRare) {
+                if (!(w & kDwNeg)) return GFT_E_UNSUPPORTED;         // an INORD group: needs positions
+                acc = !acc;
+                continue;
+            }
+            const bool v = (present[(w & kDwFieldMask) >> kDwFieldShift] != 0) != ((w & kDwNeg) != 0);
+            if ((w & kDwPop) && stack.empty()) return GFT_E_INVALID;
+            const bool x = (w & kDwPop) ? (bool)stack.back() : v;
+            const bool A = (w & kDwSel) ? x : (w & kDwOnes) != 0, B = (w & kDwOr) ? x : false;
+            const bool before = acc;
+            acc = (acc && A) || B;
+            if (w & kDwPop) stack.pop_back();
+            if (w & kDwPush) stack.push_back(before);
+            if (stack.size() > depth) return GFT_E_INVALID;           // fuse_program's own depth figure must hold
+        }
+        if (!stack.empty()) return GFT_E_INVALID;
+        out_hit[i] = acc ? 1 : 0;
+    }
+    return GFT_OK;
+}
+
 int gft_profile_enable(gft_engine* e, int on) {
     if (!e) return GFT_E_INVALID;
     GFT_LOCK(e);

@@ -120,7 +120,8 @@ int gft_scan_device(gft_engine* e, const uint8_t* d_text_blob, const uint64_t* d
 
 /* Limits of the device solver that the reference does not have (GFT_E_UNSUPPORTED, the message names the expression):
  * an INORD group with more than 64 leaves-with-thresholds alive at once or nested deeper than 32, an operand stack deeper
- * than 128 (left-deep chains of any length are fine: they need no stack), keywords longer than 7 424 bytes (gft_build). */
+ * than 128 (left-deep chains of any length are fine: they need no stack), more than 2^25 slots (terms + extra literals;
+ * the solver's program words carry a 25-bit slot), keywords longer than 7 424 bytes (gft_build). */
 int gft_set_programs(gft_engine* e, const uint32_t* prog_words, const uint64_t* prog_off, uint32_t n_exprs,
                      uint32_t n_extra);
 uint32_t gft_n_exprs(const gft_engine* e);
@@ -291,6 +292,15 @@ int gft_process_device_multi(gft_engine* e, const uint8_t* const* d_text, const 
 int gft_debug_emulate_scan(const uint8_t* terms_blob, const uint64_t* term_off, uint32_t n_terms, const uint8_t* text,
                            uint32_t len, uint32_t lo, uint32_t flags, uint32_t scan_flags, uint32_t* out_term,
                            uint32_t* out_pos, uint64_t cap, uint64_t* needed);
+
+/* The solver's program compiler alone, on the host: every program goes through the same steps as in gft_set_programs
+ * (check, fusion with Sethi-Ullman operand order, control-bit device words) and its device words are then interpreted for
+ * ONE document whose presence set is `present` (one byte per slot, non-zero = the slot's term occurs).  out_hit[i] = the
+ * expression's truth value, out_depth[i] (nullable) = the accumulator-stack depth its fused form needs.  Programs with an
+ * INORD group of more than one leaf need positions: GFT_E_UNSUPPORTED.  No HIP device is needed; tests use it to check the
+ * compiler against the oracle's tree evaluation. */
+int gft_debug_eval_programs(const uint32_t* prog_words, const uint64_t* prog_off, uint32_t n_exprs, uint32_t n_slots,
+                            const uint8_t* present, uint8_t* out_hit, uint32_t* out_depth);
 
 #ifdef __cplusplus
 }

@@ -81,6 +81,31 @@ def one_process(eng, seed, it):
     n_exprs = int(rng.choice([1, 31, 33, 200, 2100]))
     exprs = make_expressions(tl, n_exprs, inord_fraction=float(rng.choice([0.0, 0.3, 1.0])), seed=int(rng.integers(1 << 30)),
                              cover=bool(rng.integers(2)) and n_exprs <= len(tl) <= 60 * n_exprs)
+    # ... and expressions whose operands are subtrees on both sides of an operator, nested to the right, to the left or
+    # balanced: the accumulator stack of the fused programs (two registers, four registers, scratch beyond)
+    def lit(t):
+        return '"%s"' % t.decode("latin-1")
+
+    def pair():
+        a, b = tl[int(rng.integers(len(tl)))], tl[int(rng.integers(len(tl)))]
+        return "(%s%s %s %s)" % ("not " if rng.integers(3) == 0 else "", lit(a), "and" if rng.integers(2) else "or", lit(b))
+
+    def nested(depth, side):
+        if side == 2:
+            return pair() if depth == 0 else "(%s %s %s)" % (nested(depth - 1, 2), "and" if rng.integers(2) else "or", nested(depth - 1, 2))
+        e = pair()
+        for _ in range(depth):
+            op = "and" if rng.integers(2) else "or"
+            e = "(%s %s %s)" % ((pair(), op, e) if side == 0 else (e, op, pair()))
+            if rng.integers(4) == 0:
+                e = "not " + e
+        return e
+    if all(32 <= c < 127 and c not in b'"\\' for t in tl for c in t):
+        extra = [nested(int(rng.choice([1, 2, 3, 6, 20])), int(rng.integers(2))) for _ in range(int(rng.integers(0, 40)))]
+        extra += [nested(int(rng.integers(1, 6)), 2) for _ in range(int(rng.integers(0, 6)))]
+        for e in extra:
+            exprs.insert(int(rng.integers(len(exprs) + 1)), e)
+        n_exprs = len(exprs)
     o.set_expressions(exprs, case_sensitive=False)
     progs = [tree_to_program(dsl_ref.parse(e, False)[0], lambda lit: eng.term_id(lit)) for e in exprs]
     try:

@@ -287,6 +287,42 @@ def _lib_load():
     return _lib.load()
 
 
+def test_folded_batches_in_sequence():
+    """ProcessDevice over batches that stay ASCII, leave it harmlessly (lower-case Latin-1: ASCII folding is the whole of
+    strings.ToLower, the batch stays on the device) and leave it for good (upper-case non-ASCII letters: the finder
+    repeats the batch through the host's ToLower), in every order: the engine keeps state from batch to batch (sizes,
+    the one-launch unit table, the non-ASCII flag) and none of it may leak into the next result."""
+    import torch
+    L = _lib_load()
+    f = Finder(GpuEngine(), EmptyRgxEngine(), False)
+    exprs = ['"école"', '"ecole" or "straße"', '"la" and not "k"']
+    f.AddExpressions(exprs)
+    o = Oracle(sorted({"école", "ecole", "straße", "la", "k"}))
+    o.set_expressions(exprs, False)
+    safe = ["vive la école", "LA STRAßE", "plain ECOLE", "", "à la carte"] * 40      # lower-case Latin-1 only: device path
+    unsafe = ["Vive la École", "LA STRASSE École"] * 30                               # upper-case É: host path
+    ascii_ = ["ECOLE la", "k LA"] * 10
+
+    def run(texts, want_flag):
+        t, off = _device_batch(texts)
+        bm = torch.zeros((len(texts), 1), dtype=torch.int32, device="cuda")
+        f.ProcessDevice(t.data_ptr(), off.data_ptr(), len(texts), bm.data_ptr())
+        lb, lo = pack_strings([s.lower() for s in texts])
+        assert np.array_equal(bm.cpu().numpy().astype(np.uint32), o.process(lb, lo, fold=False))
+        if want_flag is not None:
+            assert L.gft_last_nonascii(f.engine_handle()) == want_flag
+
+    for _ in range(3):
+        run(safe, 0)
+    for _ in range(3):
+        run(unsafe, None)     # (the finder has repeated the batch on the host path; results above are what counts)
+    run(ascii_, 0)
+    run(ascii_, 0)
+    run(safe, 0)
+    run(unsafe, None)
+    run(safe, 0)
+
+
 def test_process_device_one_read_back_per_batch_and_regrowth():
     """gft_process_device sizes the unit table and the match pool from the previous batch and reads the control block
     back once, after the solver; a batch that outgrows them (longer documents -> more units, a denser dictionary hit

@@ -114,7 +114,10 @@ struct gft_engine {
     DevBuf d_prog, d_prog_off;            // public postfix words (INORD group subtrees are read from these)
     DevBuf d_fprog, d_fprog_off, d_groups; // fused internal form + INORD group table
     DevBuf d_solve_dbg;                    // GFT_SOLVE_DEBUG & 8: phase clocks
-    bool hint_single = false;              // the batch before was one unit per document (k_units_single may serve the next)
+    // batches in a row that were one unit per document (k_units_single serves the next one from 2 on; a batch that took
+    // that path and held a longer document after all sets it well below zero, so that a corpus whose batches alternate does
+    // not pay for the miss every other time)
+    int single_streak = 0;
     bool deferred_single = false;          // ... and this one took that path
     uint64_t deferred_n_docs = 0;
     DevBuf d_order, d_blk_class, d_wave_blk;            // evaluation order of the programs (gft_set_programs)
@@ -445,7 +448,7 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         }
         n_units = hub[n_docs]; text_lo = h_doc_off[0]; text_hi = h_doc_off[n_docs];
         HIP_TRY(hipMemcpyAsync(e->d_unit_base.p, hub.data(), (n_docs + 1) * 8, hipMemcpyHostToDevice, st), "unit upload");
-    } else if (defer_ok && !need_csr && e->hint_single && e->pool_cap > 0 &&
+    } else if (defer_ok && !need_csr && e->single_streak >= 2 && e->pool_cap > 0 &&
                std::min(std::min(e->d_units.cap / sizeof(Unit), e->d_unit_start.cap / 8), e->d_unit_count.cap / 4) >= n_docs) {
         // The batch before was one unit per document: this one gets its unit table from ONE launch on that assumption
         // (k_units_single) instead of count + prefix sum + fill + clamp; deferred_check learns whether it held.
@@ -468,7 +471,6 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         // into it -- deferred_check sees the true count and has the batch run again
         const uint64_t cap_units = std::min(std::min(e->d_units.cap / sizeof(Unit), e->d_unit_start.cap / 8), e->d_unit_count.cap / 4);
         e->deferred = defer_ok && !need_csr && cap_units >= n_docs && e->pool_cap > 0;
-        e->hint_single = false;                                  // (set again by deferred_check / the read-back below)
         if (e->deferred) {
             n_units = cap_units; text_lo = 0; text_hi = ~0ull;       // (the text blob is readable 64 bytes past its end: gft.h)
             e->deferred_unit_cap = cap_units; e->deferred_n_docs = n_docs;
@@ -477,7 +479,7 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
             HIP_TRY(hipMemcpyAsync(rb, e->d_ctl.p, sizeof rb, hipMemcpyDeviceToHost, st), "readback");
             HIP_TRY(hipStreamSynchronize(st), "sync");
             n_units = rb[4]; text_lo = rb[5]; text_hi = rb[6];
-            e->hint_single = n_units == n_docs;
+            e->single_streak = n_units == n_docs ? e->single_streak + 1 : std::min(e->single_streak, 0);
             const uint32_t bad_doc = (uint32_t)rb[0];
             if (text_hi < text_lo) return fail(e, GFT_E_INVALID, "doc_off is not ascending");
             if (bad_doc) return fail(e, GFT_E_INVALID, "doc_off is not ascending, or a document is longer than 4 GiB - 1 bytes (positions are 32-bit)");
@@ -714,11 +716,11 @@ int deferred_check(gft_engine* e, bool* again) {
     const uint64_t cursor = rb[1], total = rb[2], n_units = rb[4], text_lo = rb[5], text_hi = rb[6];
     e->last_nonascii = (uint32_t)rb[3] != 0;
     if (e->deferred_single && (uint32_t)(rb[3] >> 32)) {         // a document of more than one unit: the general path
-        e->hint_single = false;
+        e->single_streak = -8;
         *again = true;
         return GFT_OK;
     }
-    e->hint_single = n_units == e->deferred_n_docs;              // (the next batch may take the one-launch unit table)
+    e->single_streak = n_units == e->deferred_n_docs ? e->single_streak + 1 : std::min(e->single_streak, 0);
     e->last_text_lo = text_lo; e->last_text_hi = text_hi;
     if (text_hi < text_lo) return fail(e, GFT_E_INVALID, "doc_off is not ascending");
     if ((uint32_t)rb[0]) return fail(e, GFT_E_INVALID, "doc_off is not ascending, or a document is longer than 4 GiB - 1 bytes (positions are 32-bit)");

@@ -118,6 +118,7 @@ struct gft_engine {
     // that path and held a longer document after all sets it well below zero, so that a corpus whose batches alternate does
     // not pay for the miss every other time)
     int single_streak = 0;
+    uint64_t last_static_slabs = 0;        // pool entries the waves of the last scan launch owned from the start (gft_scan2 / 3)
     bool deferred_single = false;          // ... and this one took that path
     uint64_t deferred_n_docs = 0;
     DevBuf d_order, d_blk_class, d_wave_blk;            // evaluation order of the programs (gft_set_programs)
@@ -509,6 +510,13 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
 
     // 2. automaton walk into the slab pool; grow the pool and re-run if it overflowed (never truncate)
     int rc = e->deferred ? GFT_OK : ensure_pool(e, std::max<uint64_t>(1u << 20, (text_hi - text_lo) / 16));
+    if (!rc && !e->deferred && (e->use_scan2 || e->use_scan3)) {
+        // (every wave of the grid owns a slab from the start: the pool holds those twice over, or a small batch on a fresh
+        // engine would overflow it before it had written a match)
+        const uint64_t wpw = e->use_scan3 ? e->scan3_waves : e->scan2_k2_waves, min_slab = e->use_scan3 ? 2 * kScan3MinRoom : 64;
+        const uint64_t waves = std::min<uint64_t>(std::max<uint64_t>((n_units + wpw - 1) / wpw, 1), e->n_cus) * wpw;
+        rc = ensure_pool(e, 2 * waves * min_slab);
+    }
     if (rc) return rc;
     uint64_t total = 0;
     for (int attempt = 0; attempt < 3 && e->use_scan3; attempt++) {
@@ -541,6 +549,8 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         // slab slack is at most one slab per resident wave: keep it below half the pool
         const uint64_t n_waves = (uint64_t)e->n_cus * e->scan3_waves;
         P.slab = (uint32_t)std::min<uint64_t>(kScan2Slab, std::max<uint64_t>(2 * kScan3MinRoom, e->pool_cap / (2 * n_waves)));
+        // every wave of the grid owns one slab from the start; the cursor counts what is taken behind those
+        e->last_static_slabs = std::min<uint64_t>(std::max<uint64_t>((n_units + e->scan3_waves - 1) / e->scan3_waves, 1), e->n_cus) * e->scan3_waves * P.slab;
         e->csr_sorted_in_gather = need_csr;
         {
             ProfScope ps(e, "scan");
@@ -550,7 +560,7 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         uint64_t ct[3] = {0, 0, 0};
         HIP_TRY(hipMemcpyAsync(ct, e->d_ctl.as<uint8_t>() + 8, 24, hipMemcpyDeviceToHost, st), "readback");
         HIP_TRY(hipStreamSynchronize(st), "scan kernel");
-        const uint64_t cursor = ct[0];
+        const uint64_t cursor = ct[0] + e->last_static_slabs;
         total = ct[1];
         e->last_nonascii = (uint32_t)ct[2] != 0;
         if (cursor <= e->pool_cap) break;
@@ -584,6 +594,8 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         // slab slack is at most one slab per resident wave: keep it below half the pool
         const uint64_t n_waves = (uint64_t)e->n_cus * e->scan2_k2_waves;
         P.slab = (uint32_t)std::min<uint64_t>(kScan2Slab, std::max<uint64_t>(64, e->pool_cap / (2 * n_waves)));
+        // every wave of the grid owns one slab from the start; the cursor counts what is taken behind those
+        e->last_static_slabs = std::min<uint64_t>(std::max<uint64_t>((n_units + e->scan2_k2_waves - 1) / e->scan2_k2_waves, 1), e->n_cus) * e->scan2_k2_waves * P.slab;
         // the balanced path serves both callers: the solver reads presence / successor positions in any order, and
         // CSR results are put into emission order by the gather (k_gather_sorted).  GFT_SCAN_ORDERED=1 sends every unit
         // through the kernel's per-lane staging path (normally the fallback for units whose matches overflow the LDS
@@ -626,7 +638,7 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         uint64_t ct[3] = {0, 0, 0};
         HIP_TRY(hipMemcpyAsync(ct, e->d_ctl.as<uint8_t>() + 8, 24, hipMemcpyDeviceToHost, st), "readback");
         HIP_TRY(hipStreamSynchronize(st), "scan kernel");
-        const uint64_t cursor = ct[0];
+        const uint64_t cursor = ct[0] + e->last_static_slabs;
         total = ct[1];
         e->last_nonascii = (uint32_t)ct[2] != 0;
         if (P.dbg & 2) {
@@ -665,6 +677,7 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         P.cursor = e->d_ctl.as<uint64_t>() + 1; P.pool_cap = e->pool_cap;
         P.pool_term = e->d_pool_term.as<uint32_t>(); P.pool_pos = e->d_pool_pos.as<uint32_t>();
         P.unit_start = e->d_unit_start.as<uint64_t>(); P.unit_count = e->d_unit_count.as<uint32_t>();
+        e->last_static_slabs = 0;                                // (this kernel's cursor counts matches)
         {
             ProfScope ps(e, "scan");
             HIP_TRY(launch_scan_units(P, e->n_cus, st), "scan kernel launch");
@@ -713,7 +726,7 @@ int deferred_check(gft_engine* e, bool* again) {
     uint64_t rb[7] = {0, 0, 0, 0, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(rb, e->d_ctl.p, sizeof rb, hipMemcpyDeviceToHost, e->stream), "readback");
     HIP_TRY(hipStreamSynchronize(e->stream), "process pipeline");
-    const uint64_t cursor = rb[1], total = rb[2], n_units = rb[4], text_lo = rb[5], text_hi = rb[6];
+    const uint64_t cursor = rb[1] + e->last_static_slabs, total = rb[2], n_units = rb[4], text_lo = rb[5], text_hi = rb[6];
     e->last_nonascii = (uint32_t)rb[3] != 0;
     if (e->deferred_single && (uint32_t)(rb[3] >> 32)) {         // a document of more than one unit: the general path
         e->single_streak = -8;

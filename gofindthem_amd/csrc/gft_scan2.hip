@@ -486,7 +486,9 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
     uint8_t* short3 = smem + 256 + (size_t)P.filter_words * 4;
     uint8_t* fpt = short3 + P.short3_bytes;
     uint32_t* lrec = reinterpret_cast<uint32_t*>(fpt + (FPT_LDS ? kScan2FptSize : 0));
-    uint32_t* wg_next = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(lrec) + ((P.shorts_words * 4 + 15) & ~15u));   // work counter
+    // the workgroup's 16 bytes of bookkeeping (work counter, waves done, match count: a 64-bit LDS atomic), 16-byte aligned
+    // whatever the sizes of the tables in front of it
+    uint32_t* wg_next = reinterpret_cast<uint32_t*>(smem + (((size_t)(reinterpret_cast<uint8_t*>(lrec) - smem) + P.shorts_words * 4 + 15) & ~(size_t)15));
     uint8_t* wave_lds_all = reinterpret_cast<uint8_t*>(wg_next) + 16;
 
     for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) cls[i] = P.cls[i];
@@ -496,8 +498,10 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
     for (uint32_t i = threadIdx.x; FPT_LDS && i < kScan2FptSize / 4; i += blockDim.x)
         reinterpret_cast<uint32_t*>(fpt)[i] = reinterpret_cast<const uint32_t*>(P.fpt)[i];
     for (uint32_t i = threadIdx.x; i < P.shorts_words; i += blockDim.x) lrec[i] = P.shorts_packed[i];
-    if (threadIdx.x == 0) *wg_next = blockDim.x >> 6;            // (every wave starts with the item of its own number)
+    if (threadIdx.x == 0) { wg_next[0] = blockDim.x >> 6; wg_next[1] = wg_next[2] = wg_next[3] = 0; }   // [0] work counter (every
+                                                                 // wave starts with the item of its own number), [1] waves done, [2..3] matches
     __syncthreads();
+    if (DBG && (P.dbg & 128)) return;                            // timing study: launch + table staging alone
 
     // (the wave index is the same in all lanes: as a scalar, the unit bookkeeping below stays off the vector ALU)
     const uint32_t lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -516,9 +520,14 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
     auto mark = [&](int ph) {
         if (DBG && (P.dbg & 64)) { const unsigned long long now = clock64(); tl[ph] += now - tprev; tprev = now; }
     };
-    uint64_t slab_next = 0, wave_matches = 0;   // wave-uniform
+    // Match pool: every wave of the grid owns one slab from the start (wave g: [g * slab, (g + 1) * slab)), further slabs come
+    // from the cursor behind those.  Same-address atomics retire at ~ 15 ns each across the device: 4 096 waves asking for
+    // their first slab in the same microsecond, and adding their match counts when they all finish, were 0.1 ms of every
+    // launch -- a fifth of a 125 000-document batch.  (The host adds the static slabs to the cursor it reads back.)
+    const uint64_t static_slabs = (uint64_t)gridDim.x * (blockDim.x >> 6) * KARG(slab);
+    uint64_t slab_next = ((uint64_t)blockIdx.x * (blockDim.x >> 6) + wave) * KARG(slab), wave_matches = 0;   // wave-uniform
     bool told_nonascii = false;                  // (one atomic per wave, not one per unit: they all hit the same word)
-    uint32_t slab_left = 0;
+    uint32_t slab_left = KARG(slab);
 
     // Work distribution.  The workgroup owns the units  b * waves + k * (grid * waves) + [0, waves)  of every round k -- the
     // 4 096 waves of the grid move through the text side by side -- and its waves take them one by one from a counter in
@@ -764,7 +773,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
                         const uint32_t want = nh > KARG(slab) ? nh : KARG(slab);
                         uint64_t nb = 0;
                         if (lane == 0) nb = atomicAdd(reinterpret_cast<unsigned long long*>(KARG(cursor)), (unsigned long long)want);
-                        slab_next = __shfl(nb, 0, 64);
+                        slab_next = static_slabs + __shfl(nb, 0, 64);
                         slab_left = want;
                     }
                     const uint64_t base = slab_next;
@@ -800,7 +809,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
             const uint32_t want = total > KARG(slab) ? total : KARG(slab);
             uint64_t nb = 0;
             if (lane == 0) nb = atomicAdd(reinterpret_cast<unsigned long long*>(KARG(cursor)), (unsigned long long)want);
-            slab_next = __shfl(nb, 0, 64);
+            slab_next = static_slabs + __shfl(nb, 0, 64);
             slab_left = want;
         }
         const uint64_t base = slab_next;
@@ -827,8 +836,18 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
             }
         }
     }
-    if (lane == 0 && wave_matches)
-        atomicAdd(reinterpret_cast<unsigned long long*>(KARG(n_matches)), (unsigned long long)wave_matches);
+    // the match count: summed in LDS, one global atomic per workgroup by the wave that finishes last
+    if (lane == 0) {
+        if (wave_matches)
+            __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(wg_next + 2), (unsigned long long)wave_matches, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t done = __hip_atomic_fetch_add(wg_next + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (done + 1 == (blockDim.x >> 6)) {
+            const unsigned long long all = __hip_atomic_load(reinterpret_cast<unsigned long long*>(wg_next + 2), __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (all) atomicAdd(reinterpret_cast<unsigned long long*>(KARG(n_matches)), all);
+        }
+    }
     if (DBG && (P.dbg & 64) && lane == 0 && KARG(dbg_counters)) {
         unsigned long long all = 0;
         for (int ph = 0; ph < 8; ph++) { atomicAdd(reinterpret_cast<unsigned long long*>(KARG(dbg_counters) + 4 + ph), tl[ph]); all += tl[ph]; }
@@ -840,8 +859,8 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
 }  // namespace
 
 static size_t scan2_fixed_lds(uint32_t filter_words, uint32_t short3_bytes, uint32_t shorts_words, uint32_t fpt_lds_bytes) {
-    return 256 + (size_t)filter_words * 4 + short3_bytes + fpt_lds_bytes + (((size_t)shorts_words * 4 + 15) & ~(size_t)15) +
-           16;       // the workgroup's work counter
+    return ((256 + (size_t)filter_words * 4 + short3_bytes + fpt_lds_bytes + (size_t)shorts_words * 4 + 15) & ~(size_t)15) +
+           16;       // the workgroup's bookkeeping (aligned)
 }
 
 bool scan2_plan(uint32_t filter_words, uint32_t short3_bytes, uint32_t shorts_words, uint32_t fpt_lds_bytes, size_t lds_max,

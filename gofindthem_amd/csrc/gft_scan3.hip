@@ -455,7 +455,7 @@ __global__ void __launch_bounds__(kScan3Threads) k_scan3(const Scan3Params P) {
     extern __shared__ __align__(16) uint8_t smem[];
     const uint32_t off_filt = 256, off_s3 = off_filt + P.filter_words * 4, off_rec = off_s3 + P.short3_bytes,
                    off_bloom = off_rec + ((P.srec_words * 4 + 15) & ~15u),
-                   off_next = off_bloom + (BLOOM_LDS ? 4u << P.bloom_lg : 0u),      // the workgroup's work counter
+                   off_next = (off_bloom + (BLOOM_LDS ? 4u << P.bloom_lg : 0u) + 15u) & ~15u,   // the workgroup's bookkeeping (16 B, aligned)
                    off_wave = off_next + 16;
     {
         uint32_t* s32 = reinterpret_cast<uint32_t*>(smem);
@@ -464,7 +464,10 @@ __global__ void __launch_bounds__(kScan3Threads) k_scan3(const Scan3Params P) {
         for (uint32_t i = threadIdx.x; i < P.short3_bytes / 4; i += blockDim.x) s32[off_s3 / 4 + i] = reinterpret_cast<const uint32_t*>(P.short3)[i];
         for (uint32_t i = threadIdx.x; i < P.srec_words; i += blockDim.x) s32[off_rec / 4 + i] = P.srec[i];
         for (uint32_t i = threadIdx.x; BLOOM_LDS && i < (1u << P.bloom_lg); i += blockDim.x) s32[off_bloom / 4 + i] = P.bloom[i];
-        if (threadIdx.x == 0) s32[off_next / 4] = blockDim.x >> 6;   // (every wave starts with the item of its own number)
+        if (threadIdx.x == 0) {                                      // [0] work counter (every wave starts with the item of its own
+            s32[off_next / 4] = blockDim.x >> 6;                     // number), [1] waves done, [2..3] matches
+            s32[off_next / 4 + 1] = s32[off_next / 4 + 2] = s32[off_next / 4 + 3] = 0;
+        }
     }
     __syncthreads();
     if ((uint32_t)(uintptr_t)(lds_u8*)smem != 0) __builtin_trap();   // see lds_u8
@@ -485,9 +488,12 @@ __global__ void __launch_bounds__(kScan3Threads) k_scan3(const Scan3Params P) {
     lds_u32* lbloom = (lds_u32*)(uintptr_t)off_bloom;
     const bool have_short = P.short3_bytes != 0;
 
-    uint64_t slab_next = 0, wave_matches = 0;   // wave-uniform
+    // match pool as in gft_scan2.hip: every wave of the grid owns one slab from the start, further slabs come from the cursor
+    // behind those; the match count goes through LDS, one global atomic per workgroup
+    const uint64_t static_slabs = (uint64_t)gridDim.x * kWaves * KARG(slab);
+    uint64_t slab_next = ((uint64_t)blockIdx.x * kWaves + wave) * KARG(slab), wave_matches = 0;   // wave-uniform
     bool told_nonascii = false;                  // (one atomic per wave, not one per unit: they all hit the same word)
-    uint32_t slab_left = 0;
+    uint32_t slab_left = KARG(slab);
 
     // Work distribution as in gft_scan2.hip: in round k the workgroup owns the units  k * (grid * waves) + b * waves +
     // [0, waves), and its waves take them one by one from a counter in LDS (item i = round i / waves, slot i % waves), so
@@ -585,7 +591,7 @@ __global__ void __launch_bounds__(kScan3Threads) k_scan3(const Scan3Params P) {
         if (ftotal && slab_left < kScan3MinRoom) {
             uint64_t nb = 0;
             if (lane == 0) nb = atomicAdd(reinterpret_cast<unsigned long long*>(KARG(cursor)), (unsigned long long)KARG(slab));
-            slab_next = __shfl(nb, 0, 64);
+            slab_next = static_slabs + __shfl(nb, 0, 64);
             slab_left = KARG(slab);
         }
         Out fifo{nullptr, nullptr, 0, 0};
@@ -713,7 +719,7 @@ __global__ void __launch_bounds__(kScan3Threads) k_scan3(const Scan3Params P) {
             const uint32_t want = nh > KARG(slab) ? nh : KARG(slab);
             uint64_t nb = 0;
             if (lane == 0) nb = atomicAdd(reinterpret_cast<unsigned long long*>(KARG(cursor)), (unsigned long long)want);
-            slab_next = __shfl(nb, 0, 64);
+            slab_next = static_slabs + __shfl(nb, 0, 64);
             slab_left = want;
         }
         // (a unit whose cells lie beyond the pool wrote nothing: the host sees the cursor and runs the batch again)
@@ -722,15 +728,25 @@ __global__ void __launch_bounds__(kScan3Threads) k_scan3(const Scan3Params P) {
         slab_left -= nh;
         wave_matches += nh;
     }
-    if (lane == 0 && wave_matches)
-        atomicAdd(reinterpret_cast<unsigned long long*>(KARG(n_matches)), (unsigned long long)wave_matches);
+    if (lane == 0) {
+        uint32_t* wg = reinterpret_cast<uint32_t*>(smem + off_next);
+        if (wave_matches)
+            __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(wg + 2), (unsigned long long)wave_matches, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t done = __hip_atomic_fetch_add(wg + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (done + 1 == kWaves) {
+            const unsigned long long all = __hip_atomic_load(reinterpret_cast<unsigned long long*>(wg + 2), __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (all) atomicAdd(reinterpret_cast<unsigned long long*>(KARG(n_matches)), all);
+        }
+    }
 }
 
 }  // namespace
 
 static size_t scan3_fixed_lds(uint32_t filter_words, uint32_t short3_bytes, uint32_t srec_words, uint32_t bloom_lds_bytes) {
-    return 256 + (size_t)filter_words * 4 + short3_bytes + (((size_t)srec_words * 4 + 15) & ~(size_t)15) + bloom_lds_bytes +
-           16;       // the workgroup's work counter
+    return ((256 + (size_t)filter_words * 4 + short3_bytes + (((size_t)srec_words * 4 + 15) & ~(size_t)15) + bloom_lds_bytes + 15) & ~(size_t)15) +
+           16;       // the workgroup's bookkeeping (aligned)
 }
 
 bool scan3_plan(uint32_t filter_words, uint32_t short3_bytes, uint32_t srec_words, uint32_t bloom_lds_bytes, size_t lds_max,

@@ -526,7 +526,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
     // launch -- a fifth of a 125 000-document batch.  (The host adds the static slabs to the cursor it reads back.)
     const uint64_t static_slabs = (uint64_t)gridDim.x * (blockDim.x >> 6) * KARG(slab);
     uint64_t slab_next = ((uint64_t)blockIdx.x * (blockDim.x >> 6) + wave) * KARG(slab), wave_matches = 0;   // wave-uniform
-    bool told_nonascii = false;                  // (one atomic per wave, not one per unit: they all hit the same word)
+    bool told_nonascii = false;                  // (at most one LDS atomic per wave, not one per unit)
     uint32_t slab_left = KARG(slab);
 
     // Work distribution.  The workgroup owns the units  b * waves + k * (grid * waves) + [0, waves)  of every round k -- the
@@ -625,7 +625,12 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
                 if (k == 0) m0 = v; else if (k == 1) m1 = v; else if (k == 2) m2 = v; else m3 = v;
             }
             // ASCII folding is not strings.ToLower once the text leaves ASCII (finder.go:140-142): tell the host
-            if (P.fold && P.nonascii && !told_nonascii && __any((hib & 0x80808080u) != 0)) { told_nonascii = true; if (lane == 0) atomicOr(P.nonascii, 1u); }
+            if (P.fold && P.nonascii && !told_nonascii && __any((hib & 0x80808080u) != 0)) {
+                // (one global atomic per workgroup: bit 31 of its "waves done" word says that somebody has told already)
+                told_nonascii = true;
+                if (lane == 0 && !(__hip_atomic_fetch_or(wg_next + 1, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 31))
+                    atomicOr(P.nonascii, 1u);
+            }
             // positions past the lane's range carry garbage flags
             m0 = nvalid >= 32 ? m0 : (nvalid ? m0 & ((1u << nvalid) - 1) : 0);
             m1 = nvalid >= 64 ? m1 : (nvalid > 32 ? m1 & ((1u << (nvalid - 32)) - 1) : 0);
@@ -841,7 +846,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
         if (wave_matches)
             __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(wg_next + 2), (unsigned long long)wave_matches, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_WORKGROUP);
-        const uint32_t done = __hip_atomic_fetch_add(wg_next + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t done = __hip_atomic_fetch_add(wg_next + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) & 0x7FFFFFFFu;
         if (done + 1 == (blockDim.x >> 6)) {
             const unsigned long long all = __hip_atomic_load(reinterpret_cast<unsigned long long*>(wg_next + 2), __ATOMIC_RELAXED,
                                                              __HIP_MEMORY_SCOPE_WORKGROUP);

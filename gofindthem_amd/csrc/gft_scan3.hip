@@ -492,14 +492,15 @@ __global__ void __launch_bounds__(kScan3Threads) k_scan3(const Scan3Params P) {
     // behind those; the match count goes through LDS, one global atomic per workgroup
     const uint64_t static_slabs = (uint64_t)gridDim.x * kWaves * KARG(slab);
     uint64_t slab_next = ((uint64_t)blockIdx.x * kWaves + wave) * KARG(slab), wave_matches = 0;   // wave-uniform
-    bool told_nonascii = false;                  // (one atomic per wave, not one per unit: they all hit the same word)
+    bool told_nonascii = false;                  // (at most one LDS atomic per wave, not one per unit)
     uint32_t slab_left = KARG(slab);
 
     // Work distribution as in gft_scan2.hip: in round k the workgroup owns the units  k * (grid * waves) + b * waves +
     // [0, waves), and its waves take them one by one from a counter in LDS (item i = round i / waves, slot i % waves), so
     // a wave that drew cheap documents simply takes more.
     // The next unit's record and document offset are fetched while the current unit is processed.
-    uint32_t* wg_next = reinterpret_cast<uint32_t*>(smem + off_next);
+    uint32_t* wg_book = reinterpret_cast<uint32_t*>(__builtin_assume_aligned(smem + off_next, 16));   // work counter, waves done, matches
+    uint32_t* wg_next = wg_book;
     const uint64_t round_units = (uint64_t)gridDim.x * kWaves, wg_first = (uint64_t)blockIdx.x * kWaves;
     auto unit_of = [&](uint32_t item) { return (uint64_t)(item / kWaves) * round_units + wg_first + item % kWaves; };
     uint64_t u = wg_first + wave, nu = 0;                         // wave-uniform
@@ -563,7 +564,12 @@ __global__ void __launch_bounds__(kScan3Threads) k_scan3(const Scan3Params P) {
                 if (r == 3) { m0 = acc; acc = 0; }
             }
             // ASCII folding is not strings.ToLower once the text leaves ASCII (finder.go:140-142): tell the host
-            if (P.fold && P.nonascii && !told_nonascii && __any((hib & 0x80808080u) != 0)) { told_nonascii = true; if (lane == 0) atomicOr(P.nonascii, 1u); }
+            if (P.fold && P.nonascii && !told_nonascii && __any((hib & 0x80808080u) != 0)) {
+                // (one global atomic per workgroup: bit 31 of its "waves done" word says that somebody has told already)
+                told_nonascii = true;
+                if (lane == 0 && !(__hip_atomic_fetch_or(wg_book + 1, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 31))
+                    atomicOr(P.nonascii, 1u);
+            }
             // probe t of the unit sits in round t / 512, lane (t / 8) % 64, bit 8 * (round % 4) + t % 8 of m0 (rounds 0-3) or
             // m1 (rounds 4-7); probes of the last round that start at or beyond the unit's end carry garbage
             const uint32_t lr = nr - 1;                               // the last round
@@ -729,11 +735,11 @@ __global__ void __launch_bounds__(kScan3Threads) k_scan3(const Scan3Params P) {
         wave_matches += nh;
     }
     if (lane == 0) {
-        uint32_t* wg = reinterpret_cast<uint32_t*>(smem + off_next);
+        uint32_t* wg = wg_book;
         if (wave_matches)
             __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(wg + 2), (unsigned long long)wave_matches, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_WORKGROUP);
-        const uint32_t done = __hip_atomic_fetch_add(wg + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t done = __hip_atomic_fetch_add(wg + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) & 0x7FFFFFFFu;
         if (done + 1 == kWaves) {
             const unsigned long long all = __hip_atomic_load(reinterpret_cast<unsigned long long*>(wg + 2), __ATOMIC_RELAXED,
                                                              __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -52,6 +52,7 @@ struct gft_engine {
     // host -> device staging of large caller buffers: two pinned bounce buffers, filled by a few copy threads while the
     // previous one is on the wire (a hipMemcpy from pageable memory stages through one thread)
     void* pin[2] = {nullptr, nullptr};
+    uint64_t* pin_rb = nullptr;            // pinned landing place of the per-batch read-back of the control block
     hipEvent_t pin_ev[2] = {nullptr, nullptr};
     bool own_stream = false;
     unsigned n_cus = 256;
@@ -723,8 +724,10 @@ int deferred_check(gft_engine* e, bool* again) {
     *again = false;
     if (!e->deferred) return GFT_OK;
     e->deferred = false;
-    uint64_t rb[7] = {0, 0, 0, 0, 0, 0, 0};
-    HIP_TRY(hipMemcpyAsync(rb, e->d_ctl.p, sizeof rb, hipMemcpyDeviceToHost, e->stream), "readback");
+    // (into pinned memory: a copy to pageable memory is staged by the runtime, ten microseconds on every batch)
+    if (!e->pin_rb) HIP_TRY(hipHostMalloc((void**)&e->pin_rb, 64, hipHostMallocDefault), "pinned alloc");
+    uint64_t* rb = e->pin_rb;
+    HIP_TRY(hipMemcpyAsync(rb, e->d_ctl.p, 7 * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream), "readback");
     HIP_TRY(hipStreamSynchronize(e->stream), "process pipeline");
     const uint64_t cursor = rb[1] + e->last_static_slabs, total = rb[2], n_units = rb[4], text_lo = rb[5], text_hi = rb[6];
     e->last_nonascii = (uint32_t)rb[3] != 0;
@@ -1030,6 +1033,7 @@ void gft_engine_destroy(gft_engine* e) {
         for (DevBuf* b : all) b->release();
         for (int k = 0; k < 2; k++) {
             if (e->pin[k]) (void)hipHostFree(e->pin[k]);
+            if (k == 0 && e->pin_rb) (void)hipHostFree(e->pin_rb);
             if (e->pin_ev[k]) (void)hipEventDestroy(e->pin_ev[k]);
         }
         if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);

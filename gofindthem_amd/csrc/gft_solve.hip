@@ -293,7 +293,8 @@ __device__ __forceinline__ AT run_program(const SolveParams& S, const PT* P, con
     auto ld = [&](uint32_t w) -> AT {
         constexpr uint32_t kDown = sizeof(PT) == 8 ? 0 : sizeof(PT) == 4 ? 1 : sizeof(PT) == 2 ? 2 : 3;
         const uint32_t byte = (w & kDwFieldMask) >> kDown;
-        if (P_LDS) return (AT)*reinterpret_cast<const PT*>(reinterpret_cast<const uint8_t*>(P) + byte);
+        // (P sits at LDS address 0 -- checked in the kernel --, so the byte offset IS the address: no add of the base)
+        if (P_LDS) return (AT)*reinterpret_cast<const __attribute__((address_space(3))) PT*>((size_t)byte);
         return (AT)__hip_atomic_load(&P[byte / sizeof(PT)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     AT acc = AT(0), s0 = AT(0), s1 = AT(0), s2 = AT(0), s3 = AT(0), deep[DEEP ? kMaxBoolDepth : 1];

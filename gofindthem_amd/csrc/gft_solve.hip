@@ -85,7 +85,14 @@ __device__ int64_t wave_succ_min(const DocHits& M, uint32_t my_slot, int64_t my_
             const uint64_t s = M.unit_start[u];
             const uint32_t n = M.unit_count[u];
             uint32_t i = 0;
-            for (; i + 4 <= n; i += 4) {                         // four matches in flight per lane
+            for (; i + 8 <= n; i += 8) {                         // eight matches in flight per lane (the walk is latency-bound)
+                uint32_t t[8], p[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) { t[q] = M.term[s + i + q]; p[q] = M.pos[s + i + q]; }
+#pragma unroll
+                for (int q = 0; q < 8; q++) test(t[q], p[q]);
+            }
+            for (; i + 4 <= n; i += 4) {
                 uint32_t t[4], p[4];
 #pragma unroll
                 for (int q = 0; q < 4; q++) { t[q] = M.term[s + i + q]; p[q] = M.pos[s + i + q]; }

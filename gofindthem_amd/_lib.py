@@ -7,6 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GFT_LIBRARY") or os.path.join(HERE, "libgft.so")   # GFT_LIBRARY: another build (tools/asan_host.sh)
 
 GFT_OK, GFT_E_INVALID, GFT_E_NOT_BUILT, GFT_E_HIP, GFT_E_UNSUPPORTED, GFT_E_PARSE, GFT_E_ENGINE = 0, -1, -2, -3, -4, -5, -6
+GFT_E_NOMEM, GFT_E_INTERNAL, GFT_W_NO_RCCL = -7, -8, 1
 GFT_POS_START, GFT_POS_END = 0, 1
 GFT_FOLD_ASCII = 1
 GFT_SCAN_UNIQUE = 2
@@ -30,6 +31,7 @@ SYMBOLS = {
     "gft_engine_destroy": (None, [_vp]),
     "gft_engine_create_multi": (_i, [C.POINTER(_vp), _vp, _i]),
     "gft_n_devices": (_i, [_vp]),
+    "gft_gather_mode": (C.c_char_p, [_vp]),
     "gft_device_engine": (_vp, [_vp, _i]),
     "gft_split_docs": (_i, [_vp, _vp, _u64, _vp]),
     "gft_process_device_multi": (_i, [_vp, _vp, _vp, _vp, _u32, _vp]),

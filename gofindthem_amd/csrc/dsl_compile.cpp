@@ -6,6 +6,8 @@
 
 #include "../../include/gft.h"
 
+#include "gft_guard.hpp"
+
 namespace gft {
 namespace dsl {
 
@@ -606,13 +608,13 @@ void json_list(const std::vector<std::string>& v, std::string& o) {
 
 extern "C" {
 
-int gft_regex_required_literals(const uint8_t* pattern, uint64_t len, char* out, uint64_t cap, uint64_t* needed) {
+int gft_regex_required_literals(const uint8_t* pattern, uint64_t len, char* out, uint64_t cap, uint64_t* needed) try {
     std::string doc;
     json_list(gft::dsl::RegexRequiredLiterals(std::string((const char*)pattern, (size_t)len)), doc);
     return emit_out(doc, out, cap, needed);
-}
+} GFT_CATCH(nullptr)
 
-int gft_dsl_parse(const uint8_t* expr, uint64_t len, int case_sensitive, char* out, uint64_t cap, uint64_t* needed) {
+int gft_dsl_parse(const uint8_t* expr, uint64_t len, int case_sensitive, char* out, uint64_t cap, uint64_t* needed) try {
     using namespace gft::dsl;
     ParseResult r = Parse(std::string((const char*)expr, (size_t)len), case_sensitive != 0);
     std::string doc;
@@ -640,9 +642,9 @@ int gft_dsl_parse(const uint8_t* expr, uint64_t len, int case_sensitive, char* o
     for (size_t i = 0; i < prog.size(); i++) { if (i) doc.push_back(','); doc += std::to_string(prog[i]); }
     doc += "]}";
     return emit_out(doc, out, cap, needed);
-}
+} GFT_CATCH(nullptr)
 
-int gft_dsl_tokens(const uint8_t* expr, uint64_t len, char* out, uint64_t cap, uint64_t* needed) {
+int gft_dsl_tokens(const uint8_t* expr, uint64_t len, char* out, uint64_t cap, uint64_t* needed) try {
     using namespace gft::dsl;
     const std::string src((const char*)expr, (size_t)len);
     Scanner sc(src);
@@ -659,14 +661,14 @@ int gft_dsl_tokens(const uint8_t* expr, uint64_t len, char* out, uint64_t cap, u
     }
     doc += "]";
     return emit_out(doc, out, cap, needed);
-}
+} GFT_CATCH(nullptr)
 
-int gft_to_lower(const uint8_t* in, uint64_t len, uint8_t* out, uint64_t cap, uint64_t* needed) {
+int gft_to_lower(const uint8_t* in, uint64_t len, uint8_t* out, uint64_t cap, uint64_t* needed) try {
     const std::string r = gft::dsl::ToLower(std::string((const char*)in, (size_t)len));
     if (needed) *needed = r.size();
     if (cap < r.size() || (!out && r.size())) return GFT_E_INVALID;
     if (r.size()) memcpy(out, r.data(), r.size());
     return GFT_OK;
-}
+} GFT_CATCH(nullptr)
 
 }  // extern "C"

@@ -7,6 +7,8 @@
 #include <cstring>
 #include <thread>
 
+#include "gft_guard.hpp"
+
 namespace gft {
 
 namespace {
@@ -34,7 +36,8 @@ GpuEngine::GpuEngine(int device) {
 }
 GpuEngine::GpuEngine(const int* devices, int n_devices) {
     int rc = gft_engine_create_multi(&h_, devices, n_devices);
-    if (rc != GFT_OK) {
+    // (GFT_W_NO_RCCL: a complete handle, its gathers are device-to-device copies -- gft_gather_mode tells the caller)
+    if (rc != GFT_OK && rc != GFT_W_NO_RCCL) {
         create_err_ = h_ ? gft_last_error(h_) : "gft_engine_create_multi failed";
         if (h_) { gft_engine_destroy(h_); h_ = nullptr; }
     }
@@ -272,14 +275,18 @@ static bool all_ascii(const uint8_t* p, uint64_t n) {
     if (n < (16u << 20)) return range(p, n);
     constexpr unsigned kT = 4;
     bool ok[kT];
-    std::thread th[kT];
     const uint64_t part = (n + kT - 1) / kT;
-    for (unsigned t = 0; t < kT; t++) {
-        const uint64_t a = std::min(n, t * part), b = std::min(n, (t + 1) * part);
-        th[t] = std::thread([&ok, t, p, a, b, range] { ok[t] = range(p + a, b - a); });
+    {
+        std::vector<std::thread> th;
+        th.reserve(kT);
+        gft::JoinAll joined(th);             // (a thread that could not be started: the others are joined, the error travels up)
+        for (unsigned t = 0; t < kT; t++) {
+            const uint64_t a = std::min(n, t * part), b = std::min(n, (t + 1) * part);
+            th.emplace_back([&ok, t, p, a, b, range]() noexcept { ok[t] = range(p + a, b - a); });
+        }
     }
     bool all = true;
-    for (unsigned t = 0; t < kT; t++) { th[t].join(); all = all && ok[t]; }
+    for (unsigned t = 0; t < kT; t++) all = all && ok[t];
     return all;
 }
 
@@ -486,7 +493,7 @@ gft::Finder* gft_finder_impl(gft_finder* f) { return f ? f->finder.get() : nullp
 
 extern "C" {
 
-int gft_finder_create(gft_finder** out, int case_sensitive, int device) {
+int gft_finder_create(gft_finder** out, int case_sensitive, int device) try {
     if (!out) return GFT_E_INVALID;
     gft_finder* f = new gft_finder();
     f->case_sensitive = case_sensitive != 0;
@@ -496,9 +503,9 @@ int gft_finder_create(gft_finder** out, int case_sensitive, int device) {
     *out = f;
     if (!f->gpu->handle()) { f->err = f->gpu->create_error(); return GFT_E_HIP; }
     return GFT_OK;
-}
+} GFT_CATCH(nullptr)
 
-int gft_finder_create_multi(gft_finder** out, int case_sensitive, const int* devices, int n_devices) {
+int gft_finder_create_multi(gft_finder** out, int case_sensitive, const int* devices, int n_devices) try {
     if (!out || n_devices < 0 || (n_devices && !devices)) return GFT_E_INVALID;
     gft_finder* f = new gft_finder();
     f->case_sensitive = case_sensitive != 0;
@@ -508,7 +515,7 @@ int gft_finder_create_multi(gft_finder** out, int case_sensitive, const int* dev
     *out = f;
     if (!f->gpu->handle()) { f->err = f->gpu->create_error(); return GFT_E_HIP; }
     return GFT_OK;
-}
+} GFT_CATCH(nullptr)
 
 void gft_finder_destroy(gft_finder* f) { delete f; }
 const char* gft_finder_last_error(const gft_finder* f) { return f ? f->err.c_str() : "null finder"; }
@@ -522,16 +529,16 @@ static int finder_ret(gft_finder* f, const Error& e, int dflt) {
 }
 
 // engines can only be swapped before the first expression is added (like passing them to NewFinder)
-int gft_finder_set_substring_engine(gft_finder* f, gft_engine_build_fn build, gft_engine_find_fn find, void* user) {
+int gft_finder_set_substring_engine(gft_finder* f, gft_engine_build_fn build, gft_engine_find_fn find, void* user) try {
     if (!f) return GFT_E_INVALID;
     GFT_FLOCK(f);
     if (f->finder->expressions().size() || f->finder->GetKeywords().size()) { f->err = "engines must be set before expressions are added"; return GFT_E_INVALID; }
     f->sub_cb.reset(new CallbackSubEngine(build, find, user));
     f->finder.reset(new Finder(f->sub_cb.get(), f->rgx.get(), f->case_sensitive, f->gpu.get()));
     return GFT_OK;
-}
+} GFT_CATCH((f ? &const_cast<gft_finder*>(f)->err : nullptr))
 
-int gft_finder_set_regex_engine(gft_finder* f, gft_engine_build_fn build, gft_engine_find_fn find, void* user) {
+int gft_finder_set_regex_engine(gft_finder* f, gft_engine_build_fn build, gft_engine_find_fn find, void* user) try {
     if (!f) return GFT_E_INVALID;
     GFT_FLOCK(f);
     if (f->finder->expressions().size() || f->finder->GetRegexes().size()) { f->err = "engines must be set before expressions are added"; return GFT_E_INVALID; }
@@ -539,35 +546,35 @@ int gft_finder_set_regex_engine(gft_finder* f, gft_engine_build_fn build, gft_en
     SubstringEngine* sub = f->sub_cb ? f->sub_cb.get() : static_cast<SubstringEngine*>(f->gpu.get());
     f->finder.reset(new Finder(sub, f->rgx.get(), f->case_sensitive, f->gpu.get()));
     return GFT_OK;
-}
+} GFT_CATCH((f ? &const_cast<gft_finder*>(f)->err : nullptr))
 
 int gft_finder_add_expression(gft_finder* f, const uint8_t* expr, uint64_t expr_len, const uint8_t* tag,
-                              uint64_t tag_len) {
+                              uint64_t tag_len) try {
     if (!f || (!expr && expr_len)) return GFT_E_INVALID;
     GFT_FLOCK(f);
     Error e = f->finder->AddExpressionWithTag(std::string((const char*)expr, (size_t)expr_len),
                                               std::string(tag ? (const char*)tag : "", (size_t)(tag ? tag_len : 0)));
     return finder_ret(f, e, GFT_E_PARSE);
-}
+} GFT_CATCH((f ? &const_cast<gft_finder*>(f)->err : nullptr))
 
 uint32_t gft_finder_n_expressions(const gft_finder* f) { return f ? (uint32_t)f->finder->expressions().size() : 0; }
 
-uint32_t gft_finder_n_literals(const gft_finder* f, int which) {
+uint32_t gft_finder_n_literals(const gft_finder* f, int which) try {
     if (!f) return 0;
     return (uint32_t)(which ? f->finder->GetRegexes() : f->finder->GetKeywords()).size();
-}
+} GFT_CATCH_VALUE(0)
 
-int gft_finder_literal(const gft_finder* f, int which, uint32_t i, const uint8_t** ptr, uint32_t* len) {
+int gft_finder_literal(const gft_finder* f, int which, uint32_t i, const uint8_t** ptr, uint32_t* len) try {
     if (!f || !ptr || !len) return GFT_E_INVALID;
     GFT_FLOCK(f);
     const auto& v = which ? f->finder->GetRegexes() : f->finder->GetKeywords();
     if (i >= v.size()) return GFT_E_INVALID;
     *ptr = (const uint8_t*)v[i].data(); *len = (uint32_t)v[i].size();
     return GFT_OK;
-}
+} GFT_CATCH((f ? &const_cast<gft_finder*>(f)->err : nullptr))
 
 int gft_finder_expression(const gft_finder* f, uint32_t i, const uint8_t** str, uint32_t* str_len,
-                          const uint8_t** tag, uint32_t* tag_len, const uint8_t** tree_json, uint32_t* json_len) {
+                          const uint8_t** tag, uint32_t* tag_len, const uint8_t** tree_json, uint32_t* json_len) try {
     if (!f || i >= f->finder->expressions().size()) return GFT_E_INVALID;
     GFT_FLOCK(f);
     const auto& w = f->finder->expressions()[i];
@@ -578,18 +585,18 @@ int gft_finder_expression(const gft_finder* f, uint32_t i, const uint8_t** str, 
         *tree_json = (const uint8_t*)f->json.data(); *json_len = (uint32_t)f->json.size();
     }
     return GFT_OK;
-}
+} GFT_CATCH((f ? &const_cast<gft_finder*>(f)->err : nullptr))
 
 uint64_t gft_finder_last_regex_docs(const gft_finder* f) { return f && f->finder ? f->finder->last_regex_docs : 0; }
 
-int gft_finder_force_build(gft_finder* f) {
+int gft_finder_force_build(gft_finder* f) try {
     if (!f) return GFT_E_INVALID;
     GFT_FLOCK(f);
     return finder_ret(f, f->finder->ForceBuild(), GFT_E_ENGINE);
-}
+} GFT_CATCH_VALUE(0)
 
 int gft_finder_process_text(gft_finder* f, const uint8_t* text, uint64_t text_len, uint32_t* out_idx, uint32_t cap,
-                            uint32_t* n_true) {
+                            uint32_t* n_true) try {
     if (!f || !n_true || (!text && text_len)) return GFT_E_INVALID;
     GFT_FLOCK(f);
     std::vector<ExpressionResult> res;
@@ -598,42 +605,42 @@ int gft_finder_process_text(gft_finder* f, const uint8_t* text, uint64_t text_le
     *n_true = (uint32_t)res.size();
     for (uint32_t i = 0; i < res.size() && i < cap; i++) out_idx[i] = (uint32_t)res[i].ExpresionIndex;
     return GFT_OK;
-}
+} GFT_CATCH((f ? &const_cast<gft_finder*>(f)->err : nullptr))
 
 int gft_finder_process_texts(gft_finder* f, const uint8_t* text_blob, const uint64_t* doc_off, uint64_t n_docs,
-                             uint32_t* hit_bitmap) {
+                             uint32_t* hit_bitmap) try {
     if (!f || (n_docs && !doc_off)) return GFT_E_INVALID;
     GFT_FLOCK(f);
     return finder_ret(f, f->finder->ProcessTexts(text_blob, doc_off, n_docs, hit_bitmap), GFT_E_ENGINE);
-}
+} GFT_CATCH((f ? &const_cast<gft_finder*>(f)->err : nullptr))
 
 int gft_finder_process_device(gft_finder* f, const uint8_t* d_text_blob, const uint64_t* d_doc_off, uint64_t n_docs,
-                              uint32_t* d_hit_bitmap) {
+                              uint32_t* d_hit_bitmap) try {
     if (!f) return GFT_E_INVALID;
     GFT_FLOCK(f);
     return finder_ret(f, f->finder->ProcessDevice(d_text_blob, d_doc_off, n_docs, d_hit_bitmap), GFT_E_ENGINE);
-}
+} GFT_CATCH((f ? &const_cast<gft_finder*>(f)->err : nullptr))
 
-int gft_finder_debug_add_literal(gft_finder* f, int which, const uint8_t* lit, uint32_t len) {
+int gft_finder_debug_add_literal(gft_finder* f, int which, const uint8_t* lit, uint32_t len) try {
     if (!f) return GFT_E_INVALID;
     GFT_FLOCK(f);
     f->finder->debug_add_literal(which, std::string((const char*)lit, len));
     return GFT_OK;
-}
+} GFT_CATCH((f ? &const_cast<gft_finder*>(f)->err : nullptr))
 
-int gft_finder_debug_set_updated(gft_finder* f, int updated_sub, int updated_rgx) {
+int gft_finder_debug_set_updated(gft_finder* f, int updated_sub, int updated_rgx) try {
     if (!f) return GFT_E_INVALID;
     GFT_FLOCK(f);
     f->finder->updatedSubMachine = updated_sub != 0;
     f->finder->updatedRgxMachine = updated_rgx != 0;
     return GFT_OK;
-}
+} GFT_CATCH((f ? &const_cast<gft_finder*>(f)->err : nullptr))
 
-int gft_finder_debug_get_updated(const gft_finder* f, int* updated_sub, int* updated_rgx) {
+int gft_finder_debug_get_updated(const gft_finder* f, int* updated_sub, int* updated_rgx) try {
     if (!f || !updated_sub || !updated_rgx) return GFT_E_INVALID;
     GFT_FLOCK(f);
     *updated_sub = f->finder->updatedSubMachine; *updated_rgx = f->finder->updatedRgxMachine;
     return GFT_OK;
-}
+} GFT_CATCH((f ? &const_cast<gft_finder*>(f)->err : nullptr))
 
 }  // extern "C"

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -17,6 +18,7 @@
 #include <cstdlib>
 
 #include "ac_tables.hpp"
+#include "gft_guard.hpp"
 #include "gft_kernels.hpp"
 #include "scan2_tables.hpp"
 #include "scan3_tables.hpp"
@@ -502,10 +504,10 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
             // (k_units_single has filled the table)
         } else if (e->deferred) {
             HIP_TRY(hipMemsetAsync(e->d_units.p, 0, n_units * sizeof(Unit), st), "memset");      // empty units behind the real ones
-            HIP_TRY(launch_unit_fill(d_doc_off, n_docs, e->d_unit_base.as<uint64_t>(), e->d_units.as<Unit>(), st, n_units), "unit_fill");
+            HIP_TRY(launch_unit_fill(d_doc_off, n_docs, e->d_unit_base.as<uint64_t>(), e->d_units.as<Unit>(), unit_max, st, n_units), "unit_fill");
             HIP_TRY(launch_clamp_u64(e->d_unit_base.as<uint64_t>(), n_docs + 1, n_units, st), "unit clamp");
         } else {
-            HIP_TRY(launch_unit_fill(d_doc_off, n_docs, e->d_unit_base.as<uint64_t>(), e->d_units.as<Unit>(), st), "unit_fill");
+            HIP_TRY(launch_unit_fill(d_doc_off, n_docs, e->d_unit_base.as<uint64_t>(), e->d_units.as<Unit>(), unit_max, st), "unit_fill");
         }
     }
 
@@ -979,17 +981,18 @@ int multi_import_tables(gft_engine* e, const uint8_t* blob, uint64_t len);
 
 extern "C" {
 
-int gft_engine_create(gft_engine** out, int device) {
+int gft_engine_create(gft_engine** out, int device) try {
     if (!out) return GFT_E_INVALID;
     *out = nullptr;
-    gft_engine* e = new gft_engine();
+    std::unique_ptr<gft_engine> owner(new gft_engine());     // (released into *out on every regular way out)
+    gft_engine* e = owner.get();
     int count = 0;
     hipError_t h = hipGetDeviceCount(&count);
     if (h != hipSuccess || count == 0) {
         // keep the handle so the caller can read the message, but every compute call will fail loudly
         e->device = -1;
         e->err = std::string("no HIP device available: ") + (h != hipSuccess ? hipGetErrorString(h) : "device count is 0");
-        *out = e;
+        *out = owner.release();
         return GFT_E_HIP;
     }
     if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
@@ -1008,9 +1011,9 @@ int gft_engine_create(gft_engine** out, int device) {
     if (hipStreamCreateWithFlags(&e->stream, hipStreamDefault) == hipSuccess) e->own_stream = true;
     else e->stream = nullptr;
     refresh_options(e);
-    *out = e;
+    *out = owner.release();
     return GFT_OK;
-}
+} GFT_CATCH(nullptr)
 
 void gft_engine_destroy(gft_engine* e) {
     if (!e) return;
@@ -1043,7 +1046,7 @@ void gft_engine_destroy(gft_engine* e) {
 
 const char* gft_last_error(const gft_engine* e) { return e ? e->err.c_str() : "null engine"; }
 
-int gft_set_stream(gft_engine* e, void* hip_stream) {
+int gft_set_stream(gft_engine* e, void* hip_stream) try {
     if (!e) return GFT_E_INVALID;
     GFT_LOCK(e);
     if (e->device < 0) return fail(e, GFT_E_HIP, "no HIP device available");
@@ -1056,7 +1059,7 @@ int gft_set_stream(gft_engine* e, void* hip_stream) {
         e->own_stream = true;
     }
     return GFT_OK;
-}
+} GFT_CATCH((e ? &e->err : nullptr))
 
 // e->tab / e->s2 hold compiled tables (from gft_build or gft_import_tables): check them against the device, upload
 static int install_tables(gft_engine* e, uint32_t flags) {
@@ -1154,7 +1157,7 @@ static int install_tables(gft_engine* e, uint32_t flags) {
 }
 
 
-int gft_build(gft_engine* e, const uint8_t* terms_blob, const uint64_t* term_off, uint32_t n_terms, uint32_t flags) {
+int gft_build(gft_engine* e, const uint8_t* terms_blob, const uint64_t* term_off, uint32_t n_terms, uint32_t flags) try {
     if (!e || (n_terms && (!terms_blob || !term_off))) return e ? fail(e, GFT_E_INVALID, "null argument") : GFT_E_INVALID;
     GFT_LOCK(e);
     if (!e->peers.empty() && !e->in_multi) return multi_build(e, terms_blob, term_off, n_terms, flags);
@@ -1170,7 +1173,7 @@ int gft_build(gft_engine* e, const uint8_t* terms_blob, const uint64_t* term_off
     build_scan2_tables(e->tab, e->s2);     // suffix-window tables (scan2, kept as a cross-check)
     build_scan3_tables(e->tab, e->s3);     // stride-2 suffix-window tables (the fast path)
     return install_tables(e, flags);
-}
+} GFT_CATCH((e ? &e->err : nullptr))
 
 uint32_t gft_n_terms(const gft_engine* e) { return e ? (uint32_t)e->tab.terms.size() : 0; }
 uint32_t gft_n_states(const gft_engine* e) { return e ? e->tab.n_states : 0; }
@@ -1181,24 +1184,24 @@ const char* gft_scan_kernel(const gft_engine* e) {
     return e->use_scan3 ? "scan3" : e->use_scan2 ? "scan2" : "dfa";
 }
 
-int gft_term(const gft_engine* e, uint32_t term_id, const uint8_t** ptr, uint32_t* len) {
+int gft_term(const gft_engine* e, uint32_t term_id, const uint8_t** ptr, uint32_t* len) try {
     if (!e || !ptr || !len) return GFT_E_INVALID;
     if (term_id >= e->tab.terms.size()) return fail(e, GFT_E_INVALID, "term id out of range");
     *ptr = (const uint8_t*)e->tab.terms[term_id].data();
     *len = (uint32_t)e->tab.terms[term_id].size();
     return GFT_OK;
-}
+} GFT_CATCH((e ? &e->err : nullptr))
 
-int64_t gft_term_id(const gft_engine* e, const uint8_t* term, uint32_t len) {
+int64_t gft_term_id(const gft_engine* e, const uint8_t* term, uint32_t len) try {
     if (!e) return -1;
     std::string s((const char*)term, len);
     auto it = std::lower_bound(e->tab.terms.begin(), e->tab.terms.end(), s);
     if (it == e->tab.terms.end() || *it != s) return -1;
     return (int64_t)(it - e->tab.terms.begin());
-}
+} GFT_CATCH_VALUE(-1)
 
 
-int gft_export_tables(const gft_engine* e, uint8_t* out, uint64_t cap, uint64_t* needed) {
+int gft_export_tables(const gft_engine* e, uint8_t* out, uint64_t cap, uint64_t* needed) try {
     if (!e) return GFT_E_INVALID;
     GFT_LOCK(e);
     if (!e->built) return fail(e, GFT_E_NOT_BUILT, "gft_build has not been called");
@@ -1227,9 +1230,9 @@ int gft_export_tables(const gft_engine* e, uint8_t* out, uint64_t cap, uint64_t*
     if (!out || cap < w.b.size()) return GFT_E_INVALID;
     memcpy(out, w.b.data(), w.b.size());
     return GFT_OK;
-}
+} GFT_CATCH((e ? &e->err : nullptr))
 
-int gft_import_tables(gft_engine* e, const uint8_t* blob, uint64_t len) {
+int gft_import_tables(gft_engine* e, const uint8_t* blob, uint64_t len) try {
     if (!e || !blob) return e ? fail(e, GFT_E_INVALID, "null argument") : GFT_E_INVALID;
     GFT_LOCK(e);
     if (!e->peers.empty() && !e->in_multi) return multi_import_tables(e, blob, len);
@@ -1267,13 +1270,13 @@ int gft_import_tables(gft_engine* e, const uint8_t* blob, uint64_t len) {
     u.slot_shift = r.u32(); u.slot_seed = r.u32(); r.vec(u.slots); r.vec(u.more); r.vec(u.term_blob); r.vec(u.term_off);
     u.n_keys = r.u64(); u.n_anchors = r.u64();
     if (!r.ok || r.i != r.n) return fail(e, GFT_E_INVALID, "table blob is truncated");
-    if (const char* why = validate_tables(a, t, u)) return fail(e, GFT_E_INVALID, std::string("table blob is inconsistent: ") + why);
-    // shape checks the kernels rely on
+    // shape checks first: validate_tables indexes the tables by each other's sizes
     if (a.n_classes == 0 || a.n_classes > 256 || a.delta.size() != (size_t)a.n_states * a.n_classes || a.out_term.size() != a.n_states ||
         a.out_link.size() != a.n_states || a.term_len.size() != a.terms.size() ||
         (t.supported && (t.fpt_lg > 28 || t.fpt.size() != (t.fpt_lg ? (size_t)1 << t.fpt_lg : (size_t)kScan2FptSize) || t.slots.size() != ((size_t)1 << (32 - t.slot_shift)) || t.term_off.size() != a.terms.size() + 1 ||
                          t.filter.size() * 32 != t.filter_bits)))
         return fail(e, GFT_E_INVALID, "table blob is inconsistent");
+    if (const char* why = validate_tables(a, t, u)) return fail(e, GFT_E_INVALID, std::string("table blob is inconsistent: ") + why);
     if (!t.supported) t.why_not = "not supported by the suffix-window kernel (imported tables)";
     if (e->device < 0) return fail(e, GFT_E_HIP, "no HIP device available");
     e->built = false;
@@ -1281,10 +1284,10 @@ int gft_import_tables(gft_engine* e, const uint8_t* blob, uint64_t len) {
     e->s2 = std::move(t);
     e->s3 = std::move(u);
     return install_tables(e, flags);
-}
+} GFT_CATCH((e ? &e->err : nullptr))
 
 int gft_scan_device(gft_engine* e, const uint8_t* d_text_blob, const uint64_t* d_doc_off, uint64_t n_docs,
-                    uint32_t flags, gft_matches* out_dev) {
+                    uint32_t flags, gft_matches* out_dev) try {
     if (!e || !out_dev || (n_docs && (!d_text_blob || !d_doc_off))) return e ? fail(e, GFT_E_INVALID, "null argument") : GFT_E_INVALID;
     GFT_LOCK(e);
     if (e->device < 0) return fail(e, GFT_E_HIP, "no HIP device available");
@@ -1301,7 +1304,7 @@ int gft_scan_device(gft_engine* e, const uint8_t* d_text_blob, const uint64_t* d
     out_dev->term_id = e->d_term.as<uint32_t>();
     out_dev->pos = e->d_pos.as<uint32_t>();
     return GFT_OK;
-}
+} GFT_CATCH((e ? &e->err : nullptr))
 
 constexpr size_t kPinChunk = 32u << 20;      // bytes per bounce buffer
 constexpr unsigned kPinThreads = 4;
@@ -1322,12 +1325,15 @@ static int h2d_staged(gft_engine* e, void* dst, const void* src, size_t bytes) {
         HIP_TRY(hipEventSynchronize(e->pin_ev[k]), "staging");        // the copy out of this buffer has finished
         const uint8_t* s0 = (const uint8_t*)src + done;
         uint8_t* d0 = (uint8_t*)e->pin[k];
-        std::thread th[kPinThreads];
         const size_t part = (n + kPinThreads - 1) / kPinThreads;
-        for (unsigned t = 1; t < kPinThreads; t++)
-            th[t] = std::thread([=] { const size_t a = std::min(n, t * part), b = std::min(n, (t + 1) * part); if (b > a) memcpy(d0 + a, s0 + a, b - a); });
-        memcpy(d0, s0, std::min(n, part));
-        for (unsigned t = 1; t < kPinThreads; t++) th[t].join();
+        {
+            std::vector<std::thread> th;
+            th.reserve(kPinThreads);
+            JoinAll joined(th);              // (a copy thread that could not be started: the others are joined, the error returned)
+            for (unsigned t = 1; t < kPinThreads; t++)
+                th.emplace_back([=]() noexcept { const size_t a = std::min(n, t * part), b = std::min(n, (t + 1) * part); if (b > a) memcpy(d0 + a, s0 + a, b - a); });
+            memcpy(d0, s0, std::min(n, part));
+        }
         HIP_TRY(hipMemcpyAsync((uint8_t*)dst + done, e->pin[k], n, hipMemcpyHostToDevice, e->stream), "upload");
         HIP_TRY(hipEventRecord(e->pin_ev[k], e->stream), "staging");
         done += n;
@@ -1345,10 +1351,10 @@ static int stage_docs(gft_engine* e, const uint8_t* text_blob, const uint64_t* d
 }
 
 int gft_scan(gft_engine* e, const uint8_t* text_blob, const uint64_t* doc_off, uint64_t n_docs, uint32_t flags,
-             gft_matches* out) {
+             gft_matches* out) try {
     if (!e || !out || (n_docs && (!doc_off))) return e ? fail(e, GFT_E_INVALID, "null argument") : GFT_E_INVALID;
     GFT_LOCK(e);
-    if (!e->peers.empty() && !e->in_multi) return multi_scan(e, text_blob, doc_off, n_docs, flags, out);
+    if (!e->peers.empty() && !e->in_multi && n_docs) return multi_scan(e, text_blob, doc_off, n_docs, flags, out);   // (an empty batch -- doc_off may be NULL -- is the first device's)
     if (e->device < 0) return fail(e, GFT_E_HIP, "no HIP device available");
     if (!e->built) return fail(e, GFT_E_NOT_BUILT, "gft_build has not been called");
     DeviceGuard g(e->device);
@@ -1372,10 +1378,10 @@ int gft_scan(gft_engine* e, const uint8_t* text_blob, const uint64_t* doc_off, u
     out->n_docs = n_docs; out->n_matches = nm;
     out->match_off = e->h_match_off.data(); out->term_id = e->h_term.data(); out->pos = e->h_pos.data();
     return GFT_OK;
-}
+} GFT_CATCH((e ? &e->err : nullptr))
 
 int gft_set_programs(gft_engine* e, const uint32_t* prog_words, const uint64_t* prog_off, uint32_t n_exprs,
-                     uint32_t n_extra) {
+                     uint32_t n_extra) try {
     if (!e || (n_exprs && (!prog_words || !prog_off))) return e ? fail(e, GFT_E_INVALID, "null argument") : GFT_E_INVALID;
     GFT_LOCK(e);
     if (!e->peers.empty() && !e->in_multi) return multi_set_programs(e, prog_words, prog_off, n_exprs, n_extra);
@@ -1511,10 +1517,10 @@ int gft_set_programs(gft_engine* e, const uint32_t* prog_words, const uint64_t* 
         e->n_rare_words += (w >> 28) == kFopInord || (w >> 28) == kFopNot;
     }
     return GFT_OK;
-}
+} GFT_CATCH((e ? &e->err : nullptr))
 
 int gft_process_device(gft_engine* e, const uint8_t* d_text_blob, const uint64_t* d_doc_off, uint64_t n_docs,
-                       uint32_t flags, const gft_extra_matches* d_extra, uint32_t* d_hit_bitmap) {
+                       uint32_t flags, const gft_extra_matches* d_extra, uint32_t* d_hit_bitmap) try {
     if (!e || (n_docs && (!d_text_blob || !d_doc_off))) return e ? fail(e, GFT_E_INVALID, "null argument") : GFT_E_INVALID;
     GFT_LOCK(e);
     if (e->device < 0) return fail(e, GFT_E_HIP, "no HIP device available");
@@ -1539,7 +1545,7 @@ int gft_process_device(gft_engine* e, const uint8_t* d_text_blob, const uint64_t
     }
     HIP_TRY(hipStreamSynchronize(e->stream), "process pipeline");
     return refine_nonascii(e, d_text_blob, flags);
-}
+} GFT_CATCH((e ? &e->err : nullptr))
 
 namespace {
 // caller-supplied matches (host arrays) -> device copies; pdx stays null when there are none
@@ -1563,7 +1569,7 @@ int upload_extra(gft_engine* e, const gft_extra_matches* extra, uint64_t n_docs,
 }
 }  // namespace
 
-int gft_process_again(gft_engine* e, uint64_t n_docs, const gft_extra_matches* extra, uint32_t* hit_bitmap) {
+int gft_process_again(gft_engine* e, uint64_t n_docs, const gft_extra_matches* extra, uint32_t* hit_bitmap) try {
     if (!e) return GFT_E_INVALID;
     GFT_LOCK(e);
     if (!e->peers.empty() && !e->in_multi) return multi_process_again(e, n_docs, extra, hit_bitmap);
@@ -1585,13 +1591,13 @@ int gft_process_again(gft_engine* e, uint64_t n_docs, const gft_extra_matches* e
     }
     HIP_TRY(hipStreamSynchronize(e->stream), "solve pipeline");
     return GFT_OK;
-}
+} GFT_CATCH((e ? &e->err : nullptr))
 
 int gft_process(gft_engine* e, const uint8_t* text_blob, const uint64_t* doc_off, uint64_t n_docs, uint32_t flags,
-                const gft_extra_matches* extra, uint32_t* hit_bitmap) {
+                const gft_extra_matches* extra, uint32_t* hit_bitmap) try {
     if (!e || (n_docs && !doc_off)) return e ? fail(e, GFT_E_INVALID, "null argument") : GFT_E_INVALID;
     GFT_LOCK(e);
-    if (!e->peers.empty() && !e->in_multi) return multi_process(e, text_blob, doc_off, n_docs, flags, extra, hit_bitmap);
+    if (!e->peers.empty() && !e->in_multi && n_docs) return multi_process(e, text_blob, doc_off, n_docs, flags, extra, hit_bitmap);
     if (e->device < 0) return fail(e, GFT_E_HIP, "no HIP device available");
     if (!e->built) return fail(e, GFT_E_NOT_BUILT, "gft_build has not been called");
     if (!e->have_programs) return fail(e, GFT_E_NOT_BUILT, "gft_set_programs has not been called");
@@ -1618,11 +1624,11 @@ int gft_process(gft_engine* e, const uint8_t* text_blob, const uint64_t* doc_off
     }
     HIP_TRY(hipStreamSynchronize(e->stream), "process pipeline");
     return GFT_OK;
-}
+} GFT_CATCH((e ? &e->err : nullptr))
 
 int gft_debug_emulate_scan(const uint8_t* terms_blob, const uint64_t* term_off, uint32_t n_terms, const uint8_t* text,
                            uint32_t len, uint32_t lo, uint32_t flags, uint32_t scan_flags, uint32_t* out_term,
-                           uint32_t* out_pos, uint64_t cap, uint64_t* needed) {
+                           uint32_t* out_pos, uint64_t cap, uint64_t* needed) try {
     if ((n_terms && (!terms_blob || !term_off)) || (len && !text) || lo > len || !needed) return GFT_E_INVALID;
     std::vector<std::string> terms;
     for (uint32_t i = 0; i < n_terms; i++) terms.emplace_back((const char*)terms_blob + term_off[i], (size_t)(term_off[i + 1] - term_off[i]));
@@ -1637,10 +1643,10 @@ int gft_debug_emulate_scan(const uint8_t* terms_blob, const uint64_t* term_off, 
     if (hits.size() > cap || (hits.size() && (!out_term || !out_pos))) return GFT_E_INVALID;
     for (size_t i = 0; i < hits.size(); i++) { out_term[i] = hits[i].term; out_pos[i] = hits[i].pos; }
     return GFT_OK;
-}
+} GFT_CATCH(nullptr)
 
 int gft_debug_eval_programs(const uint32_t* prog_words, const uint64_t* prog_off, uint32_t n_exprs, uint32_t n_slots,
-                            const uint8_t* present, uint8_t* out_hit, uint32_t* out_depth) {
+                            const uint8_t* present, uint8_t* out_hit, uint32_t* out_depth) try {
     if (!prog_words || !prog_off || !out_hit || (n_slots && !present) || n_slots > (1u << kDwFieldBits)) return GFT_E_INVALID;
     gft_engine scratch;                              // (only its error string is used, by check_program)
     for (uint32_t i = 0; i < n_exprs; i++) {
@@ -1674,16 +1680,16 @@ int gft_debug_eval_programs(const uint32_t* prog_words, const uint64_t* prog_off
         out_hit[i] = acc ? 1 : 0;
     }
     return GFT_OK;
-}
+} GFT_CATCH(nullptr)
 
-int gft_profile_enable(gft_engine* e, int on) {
+int gft_profile_enable(gft_engine* e, int on) try {
     if (!e) return GFT_E_INVALID;
     GFT_LOCK(e);
     e->profiling = on != 0;
     return GFT_OK;
-}
+} GFT_CATCH((e ? &e->err : nullptr))
 
-int gft_profile_reset(gft_engine* e) {
+int gft_profile_reset(gft_engine* e) try {
     if (!e) return GFT_E_INVALID;
     GFT_LOCK(e);
     if (e->device < 0) return GFT_OK;
@@ -1694,9 +1700,9 @@ int gft_profile_reset(gft_engine* e) {
         kv.second.ev.clear();
     }
     return GFT_OK;
-}
+} GFT_CATCH((e ? &e->err : nullptr))
 
-int gft_profile_read(gft_engine* e, const char* name, double* total_ms, uint64_t* launches) {
+int gft_profile_read(gft_engine* e, const char* name, double* total_ms, uint64_t* launches) try {
     if (!e || !name || !total_ms || !launches) return GFT_E_INVALID;
     GFT_LOCK(e);
     *total_ms = 0; *launches = 0;
@@ -1712,7 +1718,7 @@ int gft_profile_read(gft_engine* e, const char* name, double* total_ms, uint64_t
     }
     *launches = it->second.ev.size();
     return GFT_OK;
-}
+} GFT_CATCH((e ? &e->err : nullptr))
 
 }  // extern "C"
 
@@ -1785,11 +1791,18 @@ int fan_out(gft_engine* e, F f) {
     const std::vector<gft_engine*> eng = all_engines(e);
     std::vector<int> rc(eng.size(), GFT_OK);
     std::vector<std::thread> th;
-    for (size_t i = 1; i < eng.size(); i++) th.emplace_back([&, i] { rc[i] = f(i, eng[i]); });
-    e->in_multi = true;
-    rc[0] = f(0, e);
-    e->in_multi = false;
-    for (auto& t : th) t.join();
+    th.reserve(eng.size());
+    {
+        JoinAll joined(th);                  // (also when a thread could not be started, or device 0's share threw)
+        // a thread's body never lets an exception out (that would be std::terminate): it becomes the device's status
+        auto guarded = [&](size_t i) noexcept {
+            try { rc[i] = f(i, eng[i]); } catch (...) { rc[i] = translate_exception(&eng[i]->err); }
+        };
+        struct InMulti { gft_engine* e; explicit InMulti(gft_engine* e_) : e(e_) { e->in_multi = true; } ~InMulti() { e->in_multi = false; } };
+        for (size_t i = 1; i < eng.size(); i++) th.emplace_back(guarded, i);
+        InMulti im(e);
+        guarded(0);
+    }
     for (size_t i = 0; i < eng.size(); i++)
         if (rc[i]) {
             if (i) e->err = "device " + std::to_string(eng[i]->device) + ": " + eng[i]->err;
@@ -1810,15 +1823,20 @@ int replicate_tables(gft_engine* e, uint32_t flags) {
     // the compiled tables are copied, not compiled again; every device uploads its own copy
     std::vector<std::thread> th;
     std::vector<int> rc(e->peers.size(), GFT_OK);
-    for (size_t i = 0; i < e->peers.size(); i++)
-        th.emplace_back([&, i] {
-            gft_engine* p = e->peers[i];
-            GFT_LOCK(p);
-            p->built = false;
-            p->tab = e->tab; p->s2 = e->s2; p->s3 = e->s3;
-            rc[i] = install_tables(p, flags);
-        });
-    for (auto& t : th) t.join();
+    th.reserve(e->peers.size());
+    {
+        JoinAll joined(th);
+        for (size_t i = 0; i < e->peers.size(); i++)
+            th.emplace_back([&, i]() noexcept {
+                gft_engine* p = e->peers[i];
+                try {
+                    GFT_LOCK(p);
+                    p->built = false;
+                    p->tab = e->tab; p->s2 = e->s2; p->s3 = e->s3;
+                    rc[i] = install_tables(p, flags);
+                } catch (...) { rc[i] = translate_exception(&p->err); }
+            });
+    }
     for (size_t i = 0; i < rc.size(); i++)
         if (rc[i]) { e->err = "device " + std::to_string(e->peers[i]->device) + ": " + e->peers[i]->err; return rc[i]; }
     return GFT_OK;
@@ -1919,8 +1937,8 @@ int multi_scan(gft_engine* e, const uint8_t* text_blob, const uint64_t* doc_off,
         at += part[i].n_matches;
     }
     e->h_match_off.swap(mo); e->h_term.swap(ti); e->h_pos.swap(po);
-    e->last_nonascii = false;
-    for (gft_engine* g : all_engines(e)) e->last_nonascii = e->last_nonascii || g->last_nonascii;
+    // (device 0's own flag is this handle's: it stays, the peers' are OR-ed in)
+    for (gft_engine* g : e->peers) e->last_nonascii = e->last_nonascii || g->last_nonascii;
     out->n_docs = n_docs; out->n_matches = total;
     out->match_off = e->h_match_off.data(); out->term_id = e->h_term.data(); out->pos = e->h_pos.data();
     return GFT_OK;
@@ -1930,7 +1948,7 @@ int multi_scan(gft_engine* e, const uint8_t* text_blob, const uint64_t* doc_off,
 
 extern "C" {
 
-int gft_engine_create_multi(gft_engine** out, const int* devices, int n_devices) {
+int gft_engine_create_multi(gft_engine** out, const int* devices, int n_devices) try {
     if (!out || n_devices < 0 || (n_devices && !devices)) return GFT_E_INVALID;
     *out = nullptr;
     std::vector<int> devs(devices, devices + n_devices);
@@ -1961,33 +1979,40 @@ int gft_engine_create_multi(gft_engine** out, const int* devices, int n_devices)
     const bool distinct = std::adjacent_find(uniq.begin(), uniq.end()) == uniq.end();
     if (devs.size() > 1 && distinct) {
         RcclApi& api = rccl_api();
-        if (api.ok()) {
-            std::vector<ncclComm_t> comms(devs.size());
-            const ncclResult_t r = api.CommInitAll(comms.data(), (int)devs.size(), devs.data());
-            if (r == ncclSuccess) for (ncclComm_t c : comms) e->comms.push_back((void*)c);
-            else e->err = std::string("ncclCommInitAll: ") + api.GetErrorString(r) + " (bitmaps will be gathered by device-to-device copies)";
+        if (!api.ok()) {
+            e->err = "RCCL (librccl.so) could not be loaded: bitmaps will be gathered by device-to-device copies";
+            return GFT_W_NO_RCCL;
         }
+        std::vector<ncclComm_t> comms(devs.size());
+        const ncclResult_t r = api.CommInitAll(comms.data(), (int)devs.size(), devs.data());
+        if (r != ncclSuccess) {
+            // the handle is complete without communicators, but the caller is TOLD that its gathers are not RCCL's
+            e->err = std::string("ncclCommInitAll: ") + api.GetErrorString(r) + " (bitmaps will be gathered by device-to-device copies)";
+            return GFT_W_NO_RCCL;
+        }
+        for (ncclComm_t c : comms) e->comms.push_back((void*)c);
     }
     return GFT_OK;
-}
+} GFT_CATCH(nullptr)
 
 int gft_n_devices(const gft_engine* e) { return e ? (int)e->peers.size() + 1 : 0; }
+const char* gft_gather_mode(const gft_engine* e) { return !e || e->peers.empty() ? "" : e->comms.empty() ? "copy" : "rccl"; }
 
 gft_engine* gft_device_engine(gft_engine* e, int i) {
     if (!e || i < 0 || i > (int)e->peers.size()) return nullptr;
     return i == 0 ? e : e->peers[(size_t)i - 1];
 }
 
-int gft_split_docs(const gft_engine* e, const uint64_t* doc_off, uint64_t n_docs, uint64_t* cut) {
+int gft_split_docs(const gft_engine* e, const uint64_t* doc_off, uint64_t n_docs, uint64_t* cut) try {
     if (!e || !cut || (n_docs && !doc_off)) return GFT_E_INVALID;
     std::vector<uint64_t> c;
     split_by_bytes(doc_off, n_docs, e->peers.size() + 1, c);
     memcpy(cut, c.data(), c.size() * 8);
     return GFT_OK;
-}
+} GFT_CATCH((e ? &e->err : nullptr))
 
 int gft_process_device_multi(gft_engine* e, const uint8_t* const* d_text, const uint64_t* const* d_doc_off, const uint64_t* n_docs,
-                             uint32_t flags, uint32_t* d_bitmap_root) {
+                             uint32_t flags, uint32_t* d_bitmap_root) try {
     if (!e || !d_text || !d_doc_off || !n_docs) return e ? fail(e, GFT_E_INVALID, "null argument") : GFT_E_INVALID;
     GFT_LOCK(e);
     if (!e->built) return fail(e, GFT_E_NOT_BUILT, "gft_build has not been called");
@@ -2036,9 +2061,8 @@ int gft_process_device_multi(gft_engine* e, const uint8_t* const* d_text, const 
             HIP_TRY(hipStreamSynchronize(e->stream), "bitmap gather");
         }
     }
-    e->last_nonascii = false;
-    for (gft_engine* g : eng) e->last_nonascii = e->last_nonascii || g->last_nonascii;
+    for (gft_engine* g : e->peers) e->last_nonascii = e->last_nonascii || g->last_nonascii;   // (device 0's own flag stays)
     return GFT_OK;
-}
+} GFT_CATCH((e ? &e->err : nullptr))
 
 }  // extern "C"

@@ -56,13 +56,19 @@ __global__ void k_pack_ctl(const uint64_t* __restrict__ unit_base, const uint64_
 // the true count afterwards and runs the batch again with a table that holds it)
 __global__ void __launch_bounds__(256) k_unit_fill(const uint64_t* __restrict__ doc_off, uint64_t n_docs,
                                                    const uint64_t* __restrict__ unit_base, Unit* __restrict__ units,
-                                                   uint64_t max_units) {
+                                                   uint64_t max_units, uint32_t unit_max) {
     uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= n_docs) return;
     uint64_t n = doc_off[d + 1] - doc_off[d];
+    // as k_unit_count: a document of 4 GiB or more (descending offsets wrap to that) has been flagged there and gets ONE
+    // EMPTY unit -- the scan kernels trust hi - lo <= unit_max, and on the deferred path they are launched before the host
+    // has read the flag
+    if (n > 0xFFFFFFFFull) n = 0;
     uint64_t b = unit_base[d];
     uint32_t k = (uint32_t)(unit_base[d + 1] - b);
+    if (k == 0) return;
     uint64_t per = (n + k - 1) / k;
+    if (per > unit_max) per = unit_max;                 // (never taken when cnt came from k_unit_count with the same unit_max)
     for (uint32_t i = 0; i < k; i++) {
         uint64_t lo = (uint64_t)i * per, hi = lo + per < n ? lo + per : n;
         if (lo > n) lo = n;
@@ -544,9 +550,9 @@ hipError_t launch_pack_ctl(const uint64_t* d_unit_base, const uint64_t* d_doc_of
 }
 
 hipError_t launch_unit_fill(const uint64_t* d_doc_off, uint64_t n_docs, const uint64_t* d_unit_base, Unit* d_units,
-                            hipStream_t st, uint64_t max_units) {
+                            uint32_t unit_max, hipStream_t st, uint64_t max_units) {
     if (!n_docs) return hipSuccess;
-    k_unit_fill<<<dim3((unsigned)((n_docs + 255) / 256)), dim3(256), 0, st>>>(d_doc_off, n_docs, d_unit_base, d_units, max_units);
+    k_unit_fill<<<dim3((unsigned)((n_docs + 255) / 256)), dim3(256), 0, st>>>(d_doc_off, n_docs, d_unit_base, d_units, max_units, unit_max);
     return hipGetLastError();
 }
 

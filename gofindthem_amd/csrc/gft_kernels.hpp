@@ -341,8 +341,9 @@ hipError_t launch_unit_count(const uint64_t* d_doc_off, uint64_t n_docs, uint32_
                              uint32_t* d_bad, hipStream_t st);
 // d_out[0..2] = number of units, first and last text offset (read back by the host in one copy)
 hipError_t launch_pack_ctl(const uint64_t* d_unit_base, const uint64_t* d_doc_off, uint64_t n_docs, uint64_t* d_out, hipStream_t st);
+// unit_max: as given to launch_unit_count (no unit is longer than that, whatever the offsets say)
 hipError_t launch_unit_fill(const uint64_t* d_doc_off, uint64_t n_docs, const uint64_t* d_unit_base, Unit* d_units,
-                            hipStream_t st, uint64_t max_units = ~0ull);
+                            uint32_t unit_max, hipStream_t st, uint64_t max_units = ~0ull);
 hipError_t launch_units_single(const uint64_t* d_doc_off, uint64_t n_docs, uint32_t unit_max, Unit* d_units, uint64_t* d_unit_base,
                                uint32_t* d_ctl32, hipStream_t st);
 hipError_t launch_clamp_u64(uint64_t* d_v, uint64_t n, uint64_t cap, hipStream_t st);

@@ -9,6 +9,8 @@
 #include <thread>
 #include <unordered_map>
 
+#include "gft_guard.hpp"
+
 namespace gft {
 namespace gdsl {
 
@@ -420,15 +422,29 @@ void parallel_for(uint64_t n, F&& body) {            // body(index, worker)
     if (nt <= 1) { for (uint64_t i = 0; i < n; i++) body(i, 0u); return; }
     std::atomic<uint64_t> next(0);
     std::vector<std::thread> pool;
-    for (unsigned t = 0; t < nt; t++)
-        pool.emplace_back([&, t] {
-            for (;;) {
-                const uint64_t b = next.fetch_add(64);
-                if (b >= n) return;
-                for (uint64_t i = b; i < std::min(n, b + 64); i++) body(i, t);
-            }
-        });
-    for (auto& th : pool) th.join();
+    pool.reserve(nt);
+    // an exception inside a worker would be std::terminate: the first one is carried to the calling thread and thrown
+    // again there (the entry point's barrier turns it into a status), the other workers stop taking work
+    std::exception_ptr first;
+    std::mutex first_mu;
+    {
+        gft::JoinAll joined(pool);           // (also when a worker could not be started)
+        for (unsigned t = 0; t < nt; t++)
+            pool.emplace_back([&, t]() noexcept {
+                try {
+                    for (;;) {
+                        const uint64_t b = next.fetch_add(64);
+                        if (b >= n) return;
+                        for (uint64_t i = b; i < std::min(n, b + 64); i++) body(i, t);
+                    }
+                } catch (...) {
+                    next.store(n);
+                    std::lock_guard<std::mutex> g(first_mu);
+                    if (!first) first = std::current_exception();
+                }
+            });
+    }
+    if (first) std::rethrow_exception(first);
 }
 void resolve_tags(const gdsl::Expression& e, const std::unordered_map<std::string, uint32_t>& ids) {
     if (e.Type == gdsl::UNIT_EXPR) { auto it = ids.find(e.Tag.Name); e.tag_id = it == ids.end() ? -1 : (int32_t)it->second; }
@@ -646,24 +662,24 @@ bool tagmap_from_json(const json::Value& v, gdsl::TagMap& m, std::string& err) {
 
 extern "C" {
 
-int gft_group_create(gft_group** out, gft_finder* finder) {
+int gft_group_create(gft_group** out, gft_finder* finder) try {
     if (!out || !finder) return GFT_E_INVALID;
     gft_group* g = new gft_group();
     g->g.reset(new GroupFinder(gft_finder_impl(finder)));
     *out = g;
     return GFT_OK;
-}
+} GFT_CATCH(nullptr)
 void gft_group_destroy(gft_group* g) { delete g; }
 const char* gft_group_last_error(const gft_group* g) { return g ? g->err.c_str() : "null group finder"; }
 
-int gft_group_add_rule(gft_group* g, const uint8_t* name, uint64_t name_len, const uint8_t* expr, uint64_t expr_len) {
+int gft_group_add_rule(gft_group* g, const uint8_t* name, uint64_t name_len, const uint8_t* expr, uint64_t expr_len) try {
     if (!g) return GFT_E_INVALID;
     GFT_GLOCK(g);
     g->err = g->g->AddRule(std::string((const char*)name, name_len), {std::string((const char*)expr, expr_len)});
     return g->err.empty() ? GFT_OK : GFT_E_PARSE;
-}
+} GFT_CATCH((g ? &const_cast<gft_group*>(g)->err : nullptr))
 
-int gft_group_state(const gft_group* g, char* out, uint64_t cap, uint64_t* needed) {
+int gft_group_state(const gft_group* g, char* out, uint64_t cap, uint64_t* needed) try {
     if (!g) return GFT_E_INVALID;
     GFT_GLOCK(g);
     std::string o = "{\"rules\":{";
@@ -687,11 +703,11 @@ int gft_group_state(const gft_group* g, char* out, uint64_t cap, uint64_t* neede
     str_array({g->g->tags().begin(), g->g->tags().end()}, o);
     o += "}";
     return put(o, out, cap, needed);
-}
+} GFT_CATCH((g ? &const_cast<gft_group*>(g)->err : nullptr))
 
 int gft_group_process_jsons(gft_group* g, const uint8_t* json_blob, const uint64_t* doc_off, uint64_t n_docs,
                             const uint8_t* include_json, uint64_t include_len, const uint8_t* exclude_json,
-                            uint64_t exclude_len, int what, char* out, uint64_t cap, uint64_t* needed) {
+                            uint64_t exclude_len, int what, char* out, uint64_t cap, uint64_t* needed) try {
     if (!g || (n_docs && (!json_blob || !doc_off))) return GFT_E_INVALID;
     GFT_GLOCK(g);
     std::vector<std::string> inc, exc;
@@ -717,15 +733,15 @@ int gft_group_process_jsons(gft_group* g, const uint8_t* json_blob, const uint64
     for (size_t d = 0; d < parts.size(); d++) { if (d) o += ","; o += parts[d]; }
     o += "]";
     return put(o, out, cap, needed);
-}
+} GFT_CATCH((g ? &const_cast<gft_group*>(g)->err : nullptr))
 
-int gft_group_last_result(const gft_group* g, char* out, uint64_t cap, uint64_t* needed) {
+int gft_group_last_result(const gft_group* g, char* out, uint64_t cap, uint64_t* needed) try {
     if (!g) return GFT_E_INVALID;
     GFT_GLOCK(g);
     return put(g->result, out, cap, needed);
-}
+} GFT_CATCH((g ? &const_cast<gft_group*>(g)->err : nullptr))
 
-int gft_group_evaluate(gft_group* g, const uint8_t* tagmap, uint64_t len, char* out, uint64_t cap, uint64_t* needed) {
+int gft_group_evaluate(gft_group* g, const uint8_t* tagmap, uint64_t len, char* out, uint64_t cap, uint64_t* needed) try {
     if (!g || !tagmap) return GFT_E_INVALID;
     GFT_GLOCK(g);
     json::Value v;
@@ -738,17 +754,17 @@ int gft_group_evaluate(gft_group* g, const uint8_t* tagmap, uint64_t len, char* 
     std::string o;
     rules_json(rr, o);
     return put(o, out, cap, needed);
-}
+} GFT_CATCH((g ? &const_cast<gft_group*>(g)->err : nullptr))
 
-int gft_group_last_batch(const gft_group* g, uint64_t* leaves, uint64_t* bytes) {
+int gft_group_last_batch(const gft_group* g, uint64_t* leaves, uint64_t* bytes) try {
     if (!g) return GFT_E_INVALID;
     GFT_GLOCK(g);
     if (leaves) *leaves = g->g->last_leaves;
     if (bytes) *bytes = g->g->last_bytes;
     return GFT_OK;
-}
+} GFT_CATCH((g ? &const_cast<gft_group*>(g)->err : nullptr))
 
-int gft_group_dsl_parse(const uint8_t* expr, uint64_t len, char* out, uint64_t cap, uint64_t* needed) {
+int gft_group_dsl_parse(const uint8_t* expr, uint64_t len, char* out, uint64_t cap, uint64_t* needed) try {
     gdsl::ParseResult pr = gdsl::Parse(std::string((const char*)expr, len));
     std::string o;
     if (!pr.err.empty()) { o = "{\"error\":"; dsl::json_str(pr.err, o); o += "}"; }
@@ -760,9 +776,9 @@ int gft_group_dsl_parse(const uint8_t* expr, uint64_t len, char* out, uint64_t c
         o += "}";
     }
     return put(o, out, cap, needed);
-}
+} GFT_CATCH(nullptr)
 
-int gft_group_dsl_tokens(const uint8_t* expr, uint64_t len, char* out, uint64_t cap, uint64_t* needed) {
+int gft_group_dsl_tokens(const uint8_t* expr, uint64_t len, char* out, uint64_t cap, uint64_t* needed) try {
     const std::string src((const char*)expr, len);
     gdsl::Scanner sc(src);
     std::string o = "[";
@@ -780,6 +796,6 @@ int gft_group_dsl_tokens(const uint8_t* expr, uint64_t len, char* out, uint64_t 
     }
     o += "]";
     return put(o, out, cap, needed);
-}
+} GFT_CATCH(nullptr)
 
 }  // extern "C"

@@ -40,6 +40,10 @@ class Engine:
         else:
             rc = self._L.gft_engine_create(C.byref(h), device)
         self._h = h
+        self.warning = None
+        if rc == _lib.GFT_W_NO_RCCL:          # a complete handle whose gathers are device-to-device copies, not RCCL's
+            self.warning = self._L.gft_last_error(h).decode()
+            rc = 0
         if rc != 0:
             msg = self._L.gft_last_error(h).decode() if h else "engine_create failed"
             self.close()
@@ -55,6 +59,10 @@ class Engine:
     def _check(self, rc):
         if rc != 0:
             raise GftError(rc, self._L.gft_last_error(self._h).decode())
+
+    def gather_mode(self):
+        """"rccl" / "copy" / "" -- how gft_process_device_multi moves the shards' bitmaps (gft_gather_mode)"""
+        return self._L.gft_gather_mode(self._h).decode()
 
     def set_stream(self, stream_ptr):
         self._check(self._L.gft_set_stream(self._h, stream_ptr))

@@ -6,7 +6,9 @@
  * INTEGRATION.md).  Paths cited below are relative to the reference repository.
  *
  * Conventions
- *   - every function returns GFT_OK (0) or a negative gft_status; gft_last_error() gives the message.
+ *   - every function returns GFT_OK (0) or a negative gft_status; gft_last_error() gives the message.  (One positive
+ *     value exists, GFT_W_NO_RCCL, a warning of gft_engine_create_multi.)  No C++ exception ever crosses this boundary:
+ *     every entry point translates whatever its host code throws into GFT_E_NOMEM / GFT_E_INTERNAL.
  *   - the caller owns its input buffers; the library never retains them after a call returns (cgo rule).
  *   - "blob + offsets": n byte strings are passed as one contiguous blob and n+1 uint64 offsets.
  *   - term ids index the engine's own dictionary order: unique terms sorted bytewise (the reference's
@@ -36,7 +38,13 @@ typedef enum gft_status {
     GFT_E_HIP = -3,         /* HIP runtime error (message has the HIP error string) */
     GFT_E_UNSUPPORTED = -4, /* input exceeds a documented limit of the device path */
     GFT_E_PARSE = -5,       /* DSL error; message is the reference parser's error text */
-    GFT_E_ENGINE = -6       /* an injected engine (host mirror) reported an error */
+    GFT_E_ENGINE = -6,      /* an injected engine (host mirror) reported an error */
+    GFT_E_NOMEM = -7,       /* the host side ran out of memory (std::bad_alloc / a container beyond max_size) */
+    GFT_E_INTERNAL = -8,    /* any other C++ exception on the host side: caught at the ABI, never propagated (the reference
+                             * returns errors, it does not panic: finder/finder.go:149-158) */
+    GFT_W_NO_RCCL = 1       /* gft_engine_create_multi only, a WARNING: the handle is valid and complete, but RCCL could not
+                             * be loaded or ncclCommInitAll failed (gft_last_error says why) -- gft_process_device_multi
+                             * gathers the bitmaps with device-to-device copies instead of ncclSend / ncclRecv */
 } gft_status;
 
 /* gft_build flags */
@@ -274,6 +282,10 @@ int gft_profile_reset(gft_engine* e);
  * are already resident on their devices go through gft_process_device_multi.  A device may be named twice (tests). */
 int gft_engine_create_multi(gft_engine** out, const int* devices, int n_devices);
 int gft_n_devices(const gft_engine* e);
+/* how gft_process_device_multi moves the shards' bitmaps to the first device: "rccl" (ncclSend / ncclRecv over xGMI),
+ * "copy" (device-to-device copies: RCCL unavailable, or a device named twice) or "" (single-device handle).
+ * NOTE: the "rccl" branch has not run on hardware yet -- the build's GPU boxes have one device. */
+const char* gft_gather_mode(const gft_engine* e);
 gft_engine* gft_device_engine(gft_engine* e, int i);     /* the per-device engine (its stream, its profile counters) */
 /* the document cuts gft_process would use: device i gets documents [cut[i], cut[i+1]); cut has n_devices + 1 entries */
 int gft_split_docs(const gft_engine* e, const uint64_t* doc_off, uint64_t n_docs, uint64_t* cut);

@@ -355,6 +355,45 @@ def test_process_device_one_read_back_per_batch_and_regrowth():
     run(docs[:50])
 
 
+def test_process_device_refuses_descending_offsets_on_the_deferred_path():
+    """gft_process_device launches the scan BEFORE the host has read the bad-offsets flag once it runs deferred (from the
+    second batch of a sequence on): offsets that descend -- a document "length" that wraps to >= 4 GiB -- must come back
+    as GFT_E_INVALID with every unit still inside its document (k_unit_fill / k_units_single give such a document an empty
+    unit), never as a read beyond the text.  Both unit-table paths: the general one (first deferred batches) and the
+    one-launch table for batches of single-unit documents (from the third batch on)."""
+    import torch
+    from gofindthem_amd.workload import Workload, make_expressions
+    w = Workload(300)
+    terms = w.terms()
+    exprs = make_expressions(terms, 40, inord_fraction=0.3, cover=True)
+    f = Finder(GpuEngine(), EmptyRgxEngine(), False)
+    f.AddExpressions(exprs)
+    o = Oracle(sorted(set(t.decode() for t in terms)))
+    o.set_expressions(exprs, False)
+    text, off = w.docs_host(0, 1500)
+    docs = [bytes(text[int(off[d]):int(off[d + 1])]).decode() for d in range(1500)]
+
+    def run(off_dev, t, n, want):
+        bm = torch.zeros((n, 2), dtype=torch.int32, device="cuda")
+        if want is None:
+            with pytest.raises(FinderError) as ei:
+                f.ProcessDevice(t.data_ptr(), off_dev.data_ptr(), n, bm.data_ptr())
+            assert "ascending" in str(ei.value)
+        else:
+            f.ProcessDevice(t.data_ptr(), off_dev.data_ptr(), n, bm.data_ptr())
+            assert np.array_equal(bm.cpu().numpy().astype(np.uint32), want)
+
+    t, good = _device_batch(docs)
+    lb, lo = pack_strings(docs)
+    want = o.process(lb, lo, fold=True)
+    for step in range(5):
+        run(good, t, 1500, want)                       # sizes learnt, then deferred, then the one-launch unit table
+        bad = good.clone()
+        bad[700] = bad[701] + 3                        # document 699 runs backwards: its length wraps
+        run(bad, t, 1500, None)
+    run(good, t, 1500, want)
+
+
 def test_keyword_and_regex_with_the_same_literal_known_deviation():
     """The one documented difference from the reference.  A keyword "aa" and a regex r"aa" feed ONE map key
     in the reference (finder/finder.go:181-196): its list is the keyword positions followed by the regex positions,

@@ -121,3 +121,34 @@ def test_device_resident_shards_and_the_gather():
     o.set_expressions(exprs, False)
     assert np.array_equal(bm.cpu().numpy().astype(np.uint32), o.process(text, off, fold=True))
     f.close()
+
+
+def test_non_ascii_text_in_the_first_shard_only_is_reported():
+    """gft_last_nonascii on a multi-device handle is the OR over ALL shards -- the first device's own flag included (it is
+    the handle's own field and used to be cleared before it was read): an upper-case non-ASCII letter in shard 0 only must
+    still send the caller to the host's ToLower (finder/finder.go:140-142)."""
+    L = _lib.load()
+    e = Engine(devices=_devices())
+    try:
+        e.build([b"ecole", "\u00e9cole".encode()])
+        first = ["\u00c9COLE nationale"] + ["plain ascii text"] * 3          # upper-case E-acute: ASCII folding is not ToLower
+        rest = ["nothing but ascii here, and plenty of it " * 4] * 4
+        blob, off = pack_strings(first + rest)
+        cut = np.zeros(3, np.uint64)
+        assert L.gft_split_docs(e._h, off.ctypes.data, len(first) + len(rest), cut.ctypes.data) == 0
+        assert 1 <= int(cut[1]) < len(first) + len(rest)                 # the non-ASCII document is in shard 0, shard 1 is ASCII
+        e.scan(blob, off, fold=True)
+        assert L.gft_last_nonascii(e._h) == 1
+        ascii_blob, ascii_off = pack_strings(rest + rest)
+        e.scan(ascii_blob, ascii_off, fold=True)
+        assert L.gft_last_nonascii(e._h) == 0
+        # ... and in the last shard only
+        blob2, off2 = pack_strings(rest + first[::-1])
+        e.scan(blob2, off2, fold=True)
+        assert L.gft_last_nonascii(e._h) == 1
+        # an empty batch with no offsets at all is fine on a multi-device handle too
+        m = L.gft_scan  # (through the wrapper: n_docs = 0)
+        mo, ti, po = e.scan(np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+        assert mo.tolist() == [0] and ti.size == 0
+    finally:
+        e.close()

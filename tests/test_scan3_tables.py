@@ -110,3 +110,28 @@ def test_workload_documents():
     text, off = w.docs_host(0, 6)
     for d in range(6):
         check(terms, bytes(text[int(off[d]):int(off[d + 1])]), fold=True)
+
+
+@pytest.mark.parametrize("seed", [3, 5, 7])
+def test_input_class_of_the_round_2_abort(seed):
+    """tests/test_gpu_parity.py::test_random_dictionaries, the parametrisations behind the one SIGABRT of round 2
+    (gpurun_out/t_s3_3.log: inside gft_scan, sixth case onwards): all 256 byte values in the dictionary (seed 3), terms
+    of up to 40 / 200 bytes (seeds 5 / 7), documents of up to 70 000 bytes.  The same dictionaries and documents through
+    the table compiler and the host emulation of the kernel walk -- this file runs under AddressSanitizer + UBSan in
+    tools/asan_host.sh, so an unchecked index or size in the compiler shows here."""
+    rng = np.random.default_rng(seed)
+    alpha = [b"ab", b"abc", b"abcdefgh", bytes(range(256)), b"abcdefghijklmnopqrstuvwxyz "][seed % 5]
+    n_terms = [1, 5, 40, 300, 1000, 17, 3000, 64][seed]
+    maxlen = [3, 9, 9, 6, 5, 40, 12, 200][seed]
+    terms = set()
+    for _ in range(n_terms):
+        L = int(rng.integers(1, maxlen + 1))
+        terms.add(bytes(alpha[i] for i in rng.integers(0, len(alpha), L)))
+    terms = sorted(terms)
+    for n in (0, 1, 7, 65, 4097, 8449, 70000):
+        text = bytes(alpha[i] for i in rng.integers(0, len(alpha), n))
+        for lo in sorted({0, min(n, 3), n // 2, min(n, 8192), max(n - 1, 0)}):
+            for pos_end in (False, True):
+                assert emulate(terms, text, lo=lo, pos_end=pos_end) == oracle_pairs(terms, text, lo=lo, pos_end=pos_end), (n, lo)
+    planted = b" ".join(terms[i] for i in rng.integers(0, len(terms), 400))
+    assert emulate(terms, planted) == oracle_pairs(terms, planted)

@@ -91,6 +91,7 @@ SYMBOLS = {
     "gft_to_lower": (_i, [C.c_char_p, _u64, _vp, _u64, C.POINTER(_u64)]),
     "gft_debug_emulate_scan": (_i, [_vp, _vp, _u32, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _u64, C.POINTER(_u64)]),
     "gft_debug_eval_programs": (_i, [_vp, _vp, _u32, _u32, _vp, _vp, _vp]),
+    "gft_debug_host_solve": (_i, [_vp, _u64, _vp, _vp, _vp, _u32, C.POINTER(_i)]),
     "gft_profile_enable": (_i, [_vp, _i]),
     "gft_profile_read": (_i, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(_u64)]),
     "gft_profile_reset": (_i, [_vp]),

@@ -15,7 +15,7 @@ LIB = os.path.join(HERE, "libgft.so")
 ARCH = "gfx950"
 
 HIP_SOURCES = ["gft_kernels.hip", "gft_solve.hip", "gft_scan2.hip", "gft_scan3.hip"]
-CXX_SOURCES = ["gft_api.cpp", "ac_tables.cpp", "scan2_tables.cpp", "scan3_tables.cpp", "dsl_compile.cpp", "finder_host.cpp", "json_mini.cpp", "group_host.cpp"]
+CXX_SOURCES = ["gft_api.cpp", "ac_tables.cpp", "scan2_tables.cpp", "scan3_tables.cpp", "dsl_compile.cpp", "finder_host.cpp", "json_mini.cpp", "group_host.cpp", "host_solve.cpp"]
 
 
 def _newer(target, deps):

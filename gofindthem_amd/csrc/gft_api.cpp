@@ -20,6 +20,7 @@
 #include "ac_tables.hpp"
 #include "gft_guard.hpp"
 #include "gft_kernels.hpp"
+#include "host_solve.hpp"
 #include "scan2_tables.hpp"
 #include "scan3_tables.hpp"
 
@@ -85,7 +86,6 @@ struct gft_engine {
     uint32_t scan2_short3_bytes = 0;
     uint32_t scan2_k2_waves = 0, scan2_cand_cap = 0;    // scan2_plan
     uint64_t scan_valid_docs = ~0ull;                   // documents of the last gft_process scan still in the pool (~0: none)
-    bool csr_sorted_in_gather = false;                  // this call: balanced scan + sort in the gather
     uint32_t scan2_unit_max = kScan2UnitMax;            // bytes per work unit (adapts to the match density)
     // a scan launched without knowing the unit count / pool need (gft_process*: one read-back per batch, after the solver)
     bool deferred = false;
@@ -114,6 +114,18 @@ struct gft_engine {
     // programs
     bool have_programs = false;
     uint32_t n_exprs = 0, n_extra = 0;
+    // what the HOST solves (host_solve.hpp): expressions beyond the device solver's limits, and INORD expressions in the
+    // documents where one of their slots has a position list that is not ascending (a keyword and a regex with the same
+    // literal: finder/finder.go:181-196).  Host copy of the public programs + what gft_set_programs learnt about them.
+    std::vector<uint32_t> h_prog;
+    std::vector<uint64_t> h_prog_off;
+    std::vector<ProgramTraits> traits;
+    std::vector<uint32_t> host_only;       // expressions that are always solved on the host (over a device limit)
+    std::vector<uint32_t> inord_exprs;     // expressions with a multi-leaf INORD group (candidates for irregular documents)
+    std::vector<uint8_t> inord_slot;       // [n_slots]: 1 = the slot is read inside such a group
+    uint64_t last_n_units = 0, last_total = 0;   // of the last completed scan (csr_from_pool)
+    bool csr_valid = false;                // d_match_off / d_term / d_pos hold the last scan's canonical CSR
+    DevBuf d_patch;                        // bit patches of host-solved results for a device-resident bitmap
     DevBuf d_prog, d_prog_off;            // public postfix words (INORD group subtrees are read from these)
     DevBuf d_fprog, d_fprog_off, d_groups; // fused internal form + INORD group table
     DevBuf d_solve_dbg;                    // GFT_SOLVE_DEBUG & 8: phase clocks
@@ -212,8 +224,11 @@ int upload(gft_engine* e, DevBuf& buf, const std::vector<T>& v, const char* what
 }
 
 // validates one postfix program and measures its stack needs
-int check_program(const gft_engine* e, const uint32_t* w, uint64_t len, uint32_t n_slots, uint32_t idx) {
+// traits != nullptr: a program beyond the device solver's limits is not refused but marked (it is solved on the host),
+// and the slots of its multi-leaf INORD groups are listed
+int check_program(const gft_engine* e, const uint32_t* w, uint64_t len, uint32_t n_slots, uint32_t idx, ProgramTraits* traits = nullptr) {
     uint32_t sp = 0, psp = 0;
+    std::vector<uint32_t> group_slots;
     std::vector<uint32_t> pcnt;   // pair counts of the INORD operand stack
     bool in_group = false;
     auto bad = [&](const char* m) {
@@ -226,7 +241,7 @@ int check_program(const gft_engine* e, const uint32_t* w, uint64_t len, uint32_t
         case GFT_OP_UNIT:
             if ((w[pc] & GFT_SLOT_MASK) >= n_slots) return bad("slot out of range");
             sp++;
-            if (fl) { pcnt.push_back(1); in_group = true; }
+            if (fl) { pcnt.push_back(1); in_group = true; group_slots.push_back(w[pc] & GFT_SLOT_MASK); }
             break;
         case GFT_OP_AND:
         case GFT_OP_OR:
@@ -245,20 +260,32 @@ int check_program(const gft_engine* e, const uint32_t* w, uint64_t len, uint32_t
         case GFT_OP_INORD:
             if (sp < 1 || pcnt.size() != 1) return bad("malformed INORD group");
             pcnt.clear(); in_group = false;
+            // (a group of ONE leaf is true exactly when the leaf is present: no position is ever compared)
+            if (traits && group_slots.size() > 1) traits->inord_slots.insert(traits->inord_slots.end(), group_slots.begin(), group_slots.end());
+            group_slots.clear();
             break;
         default:
             return bad("unknown opcode");
         }
-        if (sp > kMaxBoolDepth)
-            return fail(e, GFT_E_UNSUPPORTED, "program " + std::to_string(idx) + ": operand stack deeper than " +
-                                                   std::to_string(kMaxBoolDepth));
+        if (sp > kMaxBoolDepth) {
+            if (!traits)
+                return fail(e, GFT_E_UNSUPPORTED, "program " + std::to_string(idx) + ": operand stack deeper than " +
+                                                       std::to_string(kMaxBoolDepth));
+            traits->over_limit = true;
+        }
         uint32_t tot = 0;
         for (uint32_t c : pcnt) tot += c;
         psp = (uint32_t)pcnt.size();
-        if (tot > kMaxPairs || psp > kMaxPairDepth)
-            return fail(e, GFT_E_UNSUPPORTED, "program " + std::to_string(idx) + ": INORD group too wide for the device solver");
+        if (tot > kMaxPairs || psp > kMaxPairDepth) {
+            if (!traits) return fail(e, GFT_E_UNSUPPORTED, "program " + std::to_string(idx) + ": INORD group too wide for the device solver");
+            traits->over_limit = true;
+        }
     }
     if (sp != 1 || !pcnt.empty()) return bad("program does not reduce to one value");
+    if (traits) {
+        std::sort(traits->inord_slots.begin(), traits->inord_slots.end());
+        traits->inord_slots.erase(std::unique(traits->inord_slots.begin(), traits->inord_slots.end()), traits->inord_slots.end());
+    }
     return GFT_OK;
 }
 
@@ -398,6 +425,33 @@ int ensure_pool(gft_engine* e, uint64_t entries) {
     return GFT_OK;
 }
 
+// slabs of the last completed scan -> canonical CSR in e->d_match_off / d_term / d_pos (document order, the reference's
+// emission order inside a document).  The unit table, the slabs and the counts of that scan are still in the engine
+// (last_n_units, last_total); positions must have been written (want_pos).
+int csr_from_pool(gft_engine* e, uint64_t n_docs) {
+    hipStream_t st = e->stream;
+    const uint64_t n_units = e->last_n_units, total = e->last_total;
+    HIP_TRY(e->d_term.ensure(std::max<uint64_t>(total, 1) * 4), "result alloc");
+    HIP_TRY(e->d_pos.ensure(std::max<uint64_t>(total, 1) * 4), "result alloc");
+    HIP_TRY(e->d_unit_out.ensure((n_units + 1) * 8), "unit alloc");
+    HIP_TRY(e->d_partial.ensure(scan_partials_needed(std::max(n_units, n_docs)) * 8), "unit alloc");
+    ProfScope ps(e, "aux");
+    HIP_TRY(launch_exclusive_scan(e->d_unit_count.as<uint32_t>(), n_units, e->d_unit_out.as<uint64_t>(),
+                                  e->d_partial.as<uint64_t>(), st), "unit_out scan");
+    // (the suffix-window kernels leave a unit's matches in any order -- shifted anchors report a term from another position
+    // than its end, also on scan2's per-lane path: the gather sorts them)
+    const bool sort_units = e->use_scan2 || e->use_scan3;
+    HIP_TRY(launch_gather(e->d_unit_start.as<uint64_t>(), e->d_unit_count.as<uint32_t>(),
+                          e->d_unit_out.as<uint64_t>(), n_units, e->d_pool_term.as<uint32_t>(),
+                          e->d_pool_pos.as<uint32_t>(), e->d_term.as<uint32_t>(), e->d_pos.as<uint32_t>(),
+                          e->d_unit_base.as<uint64_t>(), n_docs, e->d_match_off.as<uint64_t>(), e->n_cus, st,
+                          sort_units ? e->d_units.as<Unit>() : nullptr,
+                          e->d_term_len.as<uint32_t>(), (e->build_flags & GFT_POS_END) ? 1u : 0u),
+            "gather");
+    e->csr_valid = true;
+    return GFT_OK;
+}
+
 // The device pipeline shared by scan and process.  On success the canonical CSR sits in e->d_match_off /
 // d_term / d_pos and *n_matches is set.
 constexpr uint64_t kHostUnitDocs = 1024;   // batches up to this many documents get their unit table from the host
@@ -411,10 +465,12 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
     e->deferred = false;
     e->deferred_single = false;
     e->scan_valid_docs = ~0ull;           // the pool is about to be overwritten
+    e->csr_valid = false;
     HIP_TRY(e->d_match_off.ensure((n_docs + 1) * 8), "match_off alloc");
     if (n_docs == 0) {
         HIP_TRY(hipMemsetAsync(e->d_match_off.p, 0, 8, st), "memset");
         HIP_TRY(hipStreamSynchronize(st), "sync");
+        e->last_n_units = e->last_total = 0;
         return GFT_OK;
     }
     const uint32_t warm = e->tab.max_term_len ? e->tab.max_term_len - 1 : 0;
@@ -554,7 +610,6 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         P.slab = (uint32_t)std::min<uint64_t>(kScan2Slab, std::max<uint64_t>(2 * kScan3MinRoom, e->pool_cap / (2 * n_waves)));
         // every wave of the grid owns one slab from the start; the cursor counts what is taken behind those
         e->last_static_slabs = std::min<uint64_t>(std::max<uint64_t>((n_units + e->scan3_waves - 1) / e->scan3_waves, 1), e->n_cus) * e->scan3_waves * P.slab;
-        e->csr_sorted_in_gather = need_csr;
         {
             ProfScope ps(e, "scan");
             HIP_TRY(launch_scan3(P, e->scan3_waves, e->n_cus, st), "scan kernel launch");
@@ -603,7 +658,6 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         // CSR results are put into emission order by the gather (k_gather_sorted).  GFT_SCAN_ORDERED=1 sends every unit
         // through the kernel's per-lane staging path (normally the fallback for units whose matches overflow the LDS
         // fifo): a second implementation of the verification, kept as a cross-check
-        e->csr_sorted_in_gather = need_csr;
         P.ordered = (need_csr && e->opt_scan_ordered) ? 1 : 0;
         // presence-only mode: positions are only read by INORD groups (and by CSR callers)
         P.want_pos = (need_csr || e->n_inord_groups > 0) ? 1 : 0;
@@ -698,25 +752,9 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
     }
 
     *n_matches = total;
+    e->last_n_units = n_units; e->last_total = total;
     if (!need_csr) return GFT_OK;   // the solver reads the slabs in place (doc -> units -> pool)
-
-    // 3. slabs -> canonical CSR
-    HIP_TRY(e->d_term.ensure(std::max<uint64_t>(total, 1) * 4), "result alloc");
-    HIP_TRY(e->d_pos.ensure(std::max<uint64_t>(total, 1) * 4), "result alloc");
-    {
-        ProfScope ps(e, "aux");
-        HIP_TRY(launch_exclusive_scan(e->d_unit_count.as<uint32_t>(), n_units, e->d_unit_out.as<uint64_t>(),
-                                      e->d_partial.as<uint64_t>(), st), "unit_out scan");
-        HIP_TRY(launch_gather(e->d_unit_start.as<uint64_t>(), e->d_unit_count.as<uint32_t>(),
-                              e->d_unit_out.as<uint64_t>(), n_units, e->d_pool_term.as<uint32_t>(),
-                              e->d_pool_pos.as<uint32_t>(), e->d_term.as<uint32_t>(), e->d_pos.as<uint32_t>(),
-                              e->d_unit_base.as<uint64_t>(), n_docs, e->d_match_off.as<uint64_t>(), e->n_cus, st,
-                              ((e->use_scan2 || e->use_scan3) && e->csr_sorted_in_gather) ? e->d_units.as<Unit>() : nullptr,
-                              e->d_term_len.as<uint32_t>(), (e->build_flags & GFT_POS_END) ? 1u : 0u),
-                "gather");
-    }
-    *n_matches = total;
-    return GFT_OK;
+    return csr_from_pool(e, n_docs);
 }
 
 // After the last kernel of a batch whose scan was launched blind (scan_pipeline, defer_ok): ONE read-back of the control
@@ -740,6 +778,7 @@ int deferred_check(gft_engine* e, bool* again) {
     }
     e->single_streak = n_units == e->deferred_n_docs ? e->single_streak + 1 : std::min(e->single_streak, 0);
     e->last_text_lo = text_lo; e->last_text_hi = text_hi;
+    e->last_n_units = n_units; e->last_total = total;
     if (text_hi < text_lo) return fail(e, GFT_E_INVALID, "doc_off is not ascending");
     if ((uint32_t)rb[0]) return fail(e, GFT_E_INVALID, "doc_off is not ascending, or a document is longer than 4 GiB - 1 bytes (positions are 32-bit)");
     // (the DFA kernel's cursor counts matches, the suffix-window kernels' slabs: both must fit the pool)
@@ -868,6 +907,111 @@ int solve_pipeline(gft_engine* e, uint64_t n_docs, const gft_extra_matches* d_ex
             for (int ph = 0; ph < 8; ph++) fprintf(stderr, " %7.0f", (double)t[w * 8 + ph] / (double)n_groups);
             fprintf(stderr, "\n");
         }
+    }
+    return GFT_OK;
+}
+
+// ---- what the host solves (host_solve.hpp) ---------------------------------------------------------------------------
+struct HostPlan {
+    bool all_docs = false;                     // some expression is beyond the device solver's limits: every document
+    std::vector<uint64_t> irregular;           // documents in which a slot read by an INORD group may have a non-ascending list
+    bool empty() const { return !all_docs && irregular.empty(); }
+};
+
+// extra: the caller's matches as HOST arrays (nullable).  A slot's list is what addMatchesToSolverMap builds
+// (finder/finder.go:181-196): the scan's positions of the term, then the caller's in the order given.  It can only be out
+// of order when the caller's matches name a dictionary term (a regex with the text of a keyword), or are themselves not
+// ascending (a foreign engine's keyword hits followed by the regex engine's for the same literal).
+void plan_host(const gft_engine* e, const gft_extra_matches* extra, uint64_t n_docs, HostPlan& plan) {
+    plan.all_docs = !e->host_only.empty();
+    plan.irregular.clear();
+    if (!extra || !extra->off || e->inord_exprs.empty() || !n_docs) return;
+    const uint32_t n_terms = (uint32_t)e->tab.terms.size();
+    std::vector<std::pair<uint32_t, uint32_t>> seen;          // (slot, last position) of this document: a handful
+    for (uint64_t d = 0; d < n_docs; d++) {
+        seen.clear();
+        bool irr = false;
+        for (uint64_t i = extra->off[d]; i < extra->off[d + 1] && !irr; i++) {
+            const uint32_t sl = extra->slot[i];
+            if (sl >= e->inord_slot.size() || !e->inord_slot[sl]) continue;      // (range errors are upload_extra's to report)
+            if (sl < n_terms) { irr = true; break; }
+            size_t k = 0;
+            while (k < seen.size() && seen[k].first != sl) k++;
+            if (k == seen.size()) seen.emplace_back(sl, extra->pos[i]);
+            else { irr = extra->pos[i] < seen[k].second; seen[k].second = extra->pos[i]; }
+        }
+        if (irr) plan.irregular.push_back(d);
+    }
+}
+
+// Solve the planned (expression, document) pairs on the host from the scan's matches and the caller's, and put their bits
+// into the bitmap: h_bitmap (host rows, already downloaded) or d_bitmap (device rows, patched by a small kernel).
+int host_eval(gft_engine* e, const gft_extra_matches* extra, uint64_t n_docs, const HostPlan& plan, uint32_t* h_bitmap,
+              uint32_t* d_bitmap) {
+    if (plan.empty() || !n_docs || !e->n_exprs) return GFT_OK;
+    hipStream_t st = e->stream;
+    if (!e->csr_valid) { int rc = csr_from_pool(e, n_docs); if (rc) return rc; }
+    std::vector<uint64_t> mo(n_docs + 1);
+    HIP_TRY(hipMemcpyAsync(mo.data(), e->d_match_off.p, (n_docs + 1) * 8, hipMemcpyDeviceToHost, st), "download");
+    HIP_TRY(hipStreamSynchronize(st), "host solve");
+    // the matches of the documents in question: all of them, or the irregular documents' ranges
+    std::vector<uint64_t> docs;
+    if (plan.all_docs) { docs.resize(n_docs); for (uint64_t d = 0; d < n_docs; d++) docs[d] = d; }
+    else docs = plan.irregular;
+    std::vector<uint32_t> ti, po;
+    std::vector<uint64_t> at(docs.size() + 1, 0);           // document k's matches: [at[k], at[k + 1]) of ti / po
+    for (size_t k = 0; k < docs.size(); k++) at[k + 1] = at[k] + (mo[docs[k] + 1] - mo[docs[k]]);
+    ti.resize(at.back() + 1); po.resize(at.back() + 1);
+    if (plan.all_docs) {
+        if (at.back()) {
+            HIP_TRY(hipMemcpyAsync(ti.data(), e->d_term.p, at.back() * 4, hipMemcpyDeviceToHost, st), "download");
+            HIP_TRY(hipMemcpyAsync(po.data(), e->d_pos.p, at.back() * 4, hipMemcpyDeviceToHost, st), "download");
+        }
+    } else {
+        for (size_t k = 0; k < docs.size(); k++) {
+            const uint64_t n = at[k + 1] - at[k];
+            if (!n) continue;
+            HIP_TRY(hipMemcpyAsync(ti.data() + at[k], e->d_term.as<uint32_t>() + mo[docs[k]], n * 4, hipMemcpyDeviceToHost, st), "download");
+            HIP_TRY(hipMemcpyAsync(po.data() + at[k], e->d_pos.as<uint32_t>() + mo[docs[k]], n * 4, hipMemcpyDeviceToHost, st), "download");
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(st), "host solve");
+    const uint64_t words = (e->n_exprs + 31) / 32;
+    std::vector<uint64_t> pw;                                // patches for a device bitmap: word index, bits to clear, bits to set
+    std::vector<uint32_t> pclr, pset;
+    SlotLists lists;
+    size_t ir = 0;                                           // next irregular document
+    for (size_t k = 0; k < docs.size(); k++) {
+        const uint64_t d = docs[k];
+        while (ir < plan.irregular.size() && plan.irregular[ir] < d) ir++;
+        const bool irregular = ir < plan.irregular.size() && plan.irregular[ir] == d;
+        // sortedMatchesByKeyword of this document (finder/finder.go:181-196): the engine's matches first (emission order:
+        // ascending per term), the caller's behind them in the order given
+        lists.clear();
+        for (uint64_t i = at[k]; i < at[k + 1]; i++) lists[ti[i]].push_back((int64_t)po[i]);
+        if (extra && extra->off)
+            for (uint64_t i = extra->off[d]; i < extra->off[d + 1]; i++) lists[extra->slot[i]].push_back((int64_t)extra->pos[i]);
+        auto solve_one = [&](uint32_t x) {
+            const bool hit = host_solve(e->h_prog.data() + e->h_prog_off[x], e->h_prog_off[x + 1] - e->h_prog_off[x], lists);
+            const uint64_t w = d * words + (x >> 5);
+            const uint32_t bit = 1u << (x & 31);
+            if (h_bitmap) h_bitmap[w] = hit ? h_bitmap[w] | bit : h_bitmap[w] & ~bit;
+            else { pw.push_back(w); pclr.push_back(hit ? 0u : bit); pset.push_back(hit ? bit : 0u); }
+        };
+        for (uint32_t x : e->host_only) solve_one(x);
+        if (irregular) for (uint32_t x : e->inord_exprs) solve_one(x);
+    }
+    if (!h_bitmap && !pw.empty()) {
+        if (!d_bitmap) return fail(e, GFT_E_INVALID, "null bitmap");
+        const size_t n = pw.size();
+        HIP_TRY(e->d_patch.ensure(n * 16), "patch alloc");
+        uint8_t* base = e->d_patch.as<uint8_t>();
+        HIP_TRY(hipMemcpyAsync(base, pw.data(), n * 8, hipMemcpyHostToDevice, st), "patch upload");
+        HIP_TRY(hipMemcpyAsync(base + n * 8, pclr.data(), n * 4, hipMemcpyHostToDevice, st), "patch upload");
+        HIP_TRY(hipMemcpyAsync(base + n * 12, pset.data(), n * 4, hipMemcpyHostToDevice, st), "patch upload");
+        HIP_TRY(launch_patch_words(d_bitmap, reinterpret_cast<const uint64_t*>(base), reinterpret_cast<const uint32_t*>(base + n * 8),
+                                   reinterpret_cast<const uint32_t*>(base + n * 12), n, st), "patch");
+        HIP_TRY(hipStreamSynchronize(st), "patch");
     }
     return GFT_OK;
 }
@@ -1032,7 +1176,7 @@ void gft_engine_destroy(gft_engine* e) {
 &e->d_unit_cnt, &e->d_unit_base, &e->d_units, &e->d_partial,
                          &e->d_pool_term, &e->d_pool_pos, &e->d_unit_start, &e->d_unit_count, &e->d_unit_out,
                          &e->d_term, &e->d_pos, &e->d_match_off, &e->d_text, &e->d_doc_off, &e->d_bitmap, &e->d_xoff,
-                         &e->d_xslot, &e->d_xpos, &e->d_uq_first, &e->d_uq_cnt, &e->d_uq_off, &e->d_uq_term};
+                         &e->d_xslot, &e->d_xpos, &e->d_uq_first, &e->d_uq_cnt, &e->d_uq_off, &e->d_uq_term, &e->d_patch};
         for (DevBuf* b : all) b->release();
         for (int k = 0; k < 2; k++) {
             if (e->pin[k]) (void)hipHostFree(e->pin[k]);
@@ -1388,10 +1532,12 @@ int gft_set_programs(gft_engine* e, const uint32_t* prog_words, const uint64_t* 
     if (e->device < 0) return fail(e, GFT_E_HIP, "no HIP device available");
     if (!e->built) return fail(e, GFT_E_NOT_BUILT, "gft_build has not been called");
     const uint32_t n_slots = (uint32_t)e->tab.terms.size() + n_extra;
-    if (n_slots > GFT_SLOT_MASK || n_slots > (1u << kDwFieldBits)) return fail(e, GFT_E_UNSUPPORTED, "too many slots");
+    // (slot n_slots itself is the solver's never-present slot: it must fit a program word's field too)
+    if (n_slots > GFT_SLOT_MASK || n_slots >= (1u << kDwFieldBits)) return fail(e, GFT_E_UNSUPPORTED, "too many slots");
+    std::vector<ProgramTraits> traits(n_exprs);
     for (uint32_t i = 0; i < n_exprs; i++) {
         if (prog_off[i + 1] < prog_off[i]) return fail(e, GFT_E_INVALID, "prog_off is not ascending");
-        int rc = check_program(e, prog_words + prog_off[i], prog_off[i + 1] - prog_off[i], n_slots, i);
+        int rc = check_program(e, prog_words + prog_off[i], prog_off[i + 1] - prog_off[i], n_slots, i, &traits[i]);
         if (rc) return rc;
     }
     DeviceGuard g(e->device);
@@ -1405,7 +1551,14 @@ int gft_set_programs(gft_engine* e, const uint32_t* prog_words, const uint64_t* 
     std::vector<uint32_t> fw, groups, fdepth;
     std::vector<uint64_t> fo(1, 0);
     for (uint32_t i = 0; i < n_exprs; i++) {
-        fdepth.push_back(fuse_program(prog_words + prog_off[i], prog_off[i + 1] - prog_off[i], prog_off[i], fw, groups));
+        if (traits[i].over_limit) {
+            // beyond a limit of the device solver: the device evaluates a stand-in (one leaf on the never-present slot), the
+            // expression itself is solved on the host from the scan's matches (host_solve.hpp) and its bit patched in
+            const uint32_t stub = GFT_OP_UNIT << 28 | n_slots;
+            fdepth.push_back(fuse_program(&stub, 1, 0, fw, groups));
+        } else {
+            fdepth.push_back(fuse_program(prog_words + prog_off[i], prog_off[i + 1] - prog_off[i], prog_off[i], fw, groups));
+        }
         while (fw.size() % 4) fw.push_back((uint32_t)kFopNop << 28);       // the interpreter reads 4-word chunks
         fo.push_back(fw.size());
     }
@@ -1510,6 +1663,19 @@ int gft_set_programs(gft_engine* e, const uint32_t* prog_words, const uint64_t* 
     HIP_TRY(hipStreamSynchronize(e->stream), "program upload");
     e->n_exprs = n_exprs; e->n_extra = n_extra; e->have_programs = true;
     e->scan_valid_docs = ~0ull;          // positions may not have been written for the old program set
+    e->csr_valid = false;
+    // what the host may have to solve (host_solve.hpp)
+    e->h_prog.swap(w); e->h_prog_off.swap(o);
+    e->host_only.clear(); e->inord_exprs.clear();
+    e->inord_slot.assign((size_t)n_slots + 1, 0);
+    for (uint32_t i = 0; i < n_exprs; i++) {
+        if (traits[i].over_limit) e->host_only.push_back(i);
+        else if (!traits[i].inord_slots.empty()) {
+            e->inord_exprs.push_back(i);
+            for (uint32_t sl : traits[i].inord_slots) e->inord_slot[sl] = 1;
+        }
+    }
+    e->traits.swap(traits);
     e->fprog_words = (uint32_t)fw.size();
     e->n_inord_groups = e->n_rare_words = 0;
     for (uint32_t w : fw) {
@@ -1528,11 +1694,30 @@ int gft_process_device(gft_engine* e, const uint8_t* d_text_blob, const uint64_t
     if (!e->have_programs) return fail(e, GFT_E_NOT_BUILT, "gft_set_programs has not been called");
     if (n_docs && e->n_exprs && !d_hit_bitmap) return fail(e, GFT_E_INVALID, "null bitmap");
     DeviceGuard g(e->device);
+    // what the host solves (normally nothing): expressions beyond the device solver's limits, and INORD expressions in
+    // documents where the caller's matches make a slot's list non-ascending -- for that the caller's (device) arrays are
+    // read back, but only when some INORD group could be affected at all
+    HostPlan plan;
+    std::vector<uint64_t> xo;
+    std::vector<uint32_t> xs, xp;
+    gft_extra_matches hx{nullptr, nullptr, nullptr};
+    const bool want_hx = d_extra && d_extra->off && n_docs && (!e->host_only.empty() || !e->inord_exprs.empty());
+    if (want_hx) {
+        xo.resize(n_docs + 1);
+        HIP_TRY(hipMemcpy(xo.data(), d_extra->off, (n_docs + 1) * 8, hipMemcpyDeviceToHost), "extra read-back");
+        xs.resize(xo[n_docs] + 1); xp.resize(xo[n_docs] + 1);
+        if (xo[n_docs]) {
+            HIP_TRY(hipMemcpy(xs.data(), d_extra->slot, xo[n_docs] * 4, hipMemcpyDeviceToHost), "extra read-back");
+            HIP_TRY(hipMemcpy(xp.data(), d_extra->pos, xo[n_docs] * 4, hipMemcpyDeviceToHost), "extra read-back");
+        }
+        hx.off = xo.data(); hx.slot = xs.data(); hx.pos = xp.data();
+    }
+    plan_host(e, want_hx ? &hx : nullptr, n_docs, plan);
     // units -> scan -> solve without a host round trip in between; one read-back at the end, and a second pass only when
     // this batch outgrew the unit table or the match pool the previous ones left behind
     for (int pass = 0; pass < 2; pass++) {
         uint64_t nm = 0;
-        int rc = scan_pipeline(e, d_text_blob, d_doc_off, n_docs, flags, false, &nm, nullptr, pass == 0);
+        int rc = scan_pipeline(e, d_text_blob, d_doc_off, n_docs, flags, plan.all_docs, &nm, nullptr, pass == 0);
         if (rc) return rc;
         const bool was_deferred = e->deferred;
         rc = solve_pipeline(e, n_docs, d_extra, d_hit_bitmap);
@@ -1541,10 +1726,12 @@ int gft_process_device(gft_engine* e, const uint8_t* d_text_blob, const uint64_t
         bool again = false;
         rc = deferred_check(e, &again);
         if (rc) return rc;
-        if (!again) return refine_nonascii(e, d_text_blob, flags);
+        if (!again) break;
     }
     HIP_TRY(hipStreamSynchronize(e->stream), "process pipeline");
-    return refine_nonascii(e, d_text_blob, flags);
+    int rc = refine_nonascii(e, d_text_blob, flags);
+    if (rc) return rc;
+    return host_eval(e, want_hx ? &hx : nullptr, n_docs, plan, nullptr, d_hit_bitmap);
 } GFT_CATCH((e ? &e->err : nullptr))
 
 namespace {
@@ -1583,6 +1770,8 @@ int gft_process_again(gft_engine* e, uint64_t n_docs, const gft_extra_matches* e
     int rc = upload_extra(e, extra, n_docs, dx, pdx);
     if (rc) return rc;
     const uint64_t words = (e->n_exprs + 31) / 32;
+    HostPlan plan;
+    plan_host(e, pdx ? extra : nullptr, n_docs, plan);
     rc = solve_pipeline(e, n_docs, pdx, e->d_bitmap.as<uint32_t>());
     if (rc) return rc;
     if (n_docs * words) {
@@ -1590,7 +1779,7 @@ int gft_process_again(gft_engine* e, uint64_t n_docs, const gft_extra_matches* e
         HIP_TRY(hipMemcpyAsync(hit_bitmap, e->d_bitmap.p, n_docs * words * 4, hipMemcpyDeviceToHost, e->stream), "download");
     }
     HIP_TRY(hipStreamSynchronize(e->stream), "solve pipeline");
-    return GFT_OK;
+    return host_eval(e, pdx ? extra : nullptr, n_docs, plan, hit_bitmap, nullptr);
 } GFT_CATCH((e ? &e->err : nullptr))
 
 int gft_process(gft_engine* e, const uint8_t* text_blob, const uint64_t* doc_off, uint64_t n_docs, uint32_t flags,
@@ -1611,8 +1800,11 @@ int gft_process(gft_engine* e, const uint8_t* text_blob, const uint64_t* doc_off
     if (rc) return rc;
     const uint64_t words = (e->n_exprs + 31) / 32;
     HIP_TRY(e->d_bitmap.ensure(std::max<uint64_t>(n_docs * words, 1) * 4), "bitmap alloc");
+    HostPlan plan;                        // the (expression, document) pairs the host solves (normally none)
+    plan_host(e, pdx ? extra : nullptr, n_docs, plan);
     uint64_t nm = 0;
-    rc = scan_pipeline(e, e->d_text.as<uint8_t>(), e->d_doc_off.as<uint64_t>(), n_docs, flags, false, &nm, doc_off);
+    // (expressions beyond the device solver's limits need every match with its position: the scan then leaves the CSR too)
+    rc = scan_pipeline(e, e->d_text.as<uint8_t>(), e->d_doc_off.as<uint64_t>(), n_docs, flags, plan.all_docs, &nm, doc_off);
     if (rc) return rc;
     e->scan_valid_docs = n_docs;          // gft_process_again may reuse this scan
     rc = solve_pipeline(e, n_docs, pdx, e->d_bitmap.as<uint32_t>());
@@ -1623,7 +1815,7 @@ int gft_process(gft_engine* e, const uint8_t* text_blob, const uint64_t* doc_off
         HIP_TRY(hipMemcpyAsync(hit_bitmap, e->d_bitmap.p, n_docs * words * 4, hipMemcpyDeviceToHost, e->stream), "download");
     }
     HIP_TRY(hipStreamSynchronize(e->stream), "process pipeline");
-    return GFT_OK;
+    return host_eval(e, pdx ? extra : nullptr, n_docs, plan, hit_bitmap, nullptr);
 } GFT_CATCH((e ? &e->err : nullptr))
 
 int gft_debug_emulate_scan(const uint8_t* terms_blob, const uint64_t* term_off, uint32_t n_terms, const uint8_t* text,
@@ -1679,6 +1871,25 @@ int gft_debug_eval_programs(const uint32_t* prog_words, const uint64_t* prog_off
         if (!stack.empty()) return GFT_E_INVALID;
         out_hit[i] = acc ? 1 : 0;
     }
+    return GFT_OK;
+} GFT_CATCH(nullptr)
+
+int gft_debug_host_solve(const uint32_t* words, uint64_t len, const uint32_t* slots, const uint64_t* list_off,
+                         const int64_t* positions, uint32_t n_lists, int* out) try {
+    if (!words || !out || (n_lists && (!slots || !list_off))) return GFT_E_INVALID;
+    gft_engine scratch;                              // (only its error string is used, by check_program)
+    uint32_t n_slots = 0;
+    for (uint64_t i = 0; i < len; i++)
+        if ((words[i] >> 28) == GFT_OP_UNIT) n_slots = std::max(n_slots, (words[i] & GFT_SLOT_MASK) + 1);
+    ProgramTraits tr;
+    const int rc = check_program(&scratch, words, len, n_slots, 0, &tr);
+    if (rc) return rc;
+    SlotLists m;
+    for (uint32_t k = 0; k < n_lists; k++) {
+        std::vector<int64_t>& v = m[slots[k]];       // (a key may carry an empty list: expression_test.go:29-33)
+        for (uint64_t i = list_off[k]; i < list_off[k + 1]; i++) v.push_back(positions[i]);
+    }
+    *out = host_solve(words, len, m) ? 1 : 0;
     return GFT_OK;
 } GFT_CATCH(nullptr)
 

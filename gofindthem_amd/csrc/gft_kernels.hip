@@ -97,6 +97,16 @@ __global__ void __launch_bounds__(256) k_units_single(const uint64_t* __restrict
     unit_base[d] = d;
 }
 
+// words[idx[i]] = (words[idx[i]] & ~clr[i]) | set[i]: the bits of (expression, document) pairs the host solved
+// (host_solve.hpp), into a device-resident bitmap; several patches may name one word
+__global__ void __launch_bounds__(256) k_patch_words(uint32_t* __restrict__ words, const uint64_t* __restrict__ idx,
+                                                     const uint32_t* __restrict__ clr, const uint32_t* __restrict__ set, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (clr[i]) atomicAnd(&words[idx[i]], ~clr[i]);
+    if (set[i]) atomicOr(&words[idx[i]], set[i]);
+}
+
 // unit_base[i] = min(unit_base[i], cap): after a unit table that was too small, every consumer stays inside it
 __global__ void __launch_bounds__(256) k_clamp_u64(uint64_t* __restrict__ v, uint64_t n, uint64_t cap) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -546,6 +556,12 @@ hipError_t launch_unit_count(const uint64_t* d_doc_off, uint64_t n_docs, uint32_
 
 hipError_t launch_pack_ctl(const uint64_t* d_unit_base, const uint64_t* d_doc_off, uint64_t n_docs, uint64_t* d_out, hipStream_t st) {
     k_pack_ctl<<<dim3(1), dim3(1), 0, st>>>(d_unit_base, d_doc_off, n_docs, d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_patch_words(uint32_t* d_words, const uint64_t* d_idx, const uint32_t* d_clr, const uint32_t* d_set, uint64_t n, hipStream_t st) {
+    if (!n) return hipSuccess;
+    k_patch_words<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(d_words, d_idx, d_clr, d_set, n);
     return hipGetLastError();
 }
 

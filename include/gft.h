@@ -126,10 +126,13 @@ int gft_scan_device(gft_engine* e, const uint8_t* d_text_blob, const uint64_t* d
 #define GFT_INORD_FLAG (1u << 27)
 #define GFT_SLOT_MASK ((1u << 27) - 1u)
 
-/* Limits of the device solver that the reference does not have (GFT_E_UNSUPPORTED, the message names the expression):
- * an INORD group with more than 64 leaves-with-thresholds alive at once or nested deeper than 32, an operand stack deeper
- * than 128 (left-deep chains of any length are fine: they need no stack), more than 2^25 slots (terms + extra literals;
- * the solver's program words carry a 25-bit slot), keywords longer than 7 424 bytes (gft_build). */
+/* Limits of the DEVICE solver that the reference does not have: an INORD group with more than 64 leaves-with-thresholds
+ * alive at once or nested deeper than 32, an operand stack deeper than 128 (left-deep chains of any length are fine: they
+ * need no stack).  An expression beyond them is accepted all the same: gft_process* solve it on the host from the scan's
+ * matches (csrc/host_solve.cpp, the reference's recursion restated -- dsl/expression.go:66-142 has no such limits) and put
+ * its bit into the bitmap; every other expression of the set still runs on the device.
+ * Refused with GFT_E_UNSUPPORTED: 2^25 slots or more (terms + extra literals; the solver's program words carry a 25-bit
+ * slot), keywords longer than 7 424 bytes (gft_build). */
 int gft_set_programs(gft_engine* e, const uint32_t* prog_words, const uint64_t* prog_off, uint32_t n_exprs,
                      uint32_t n_extra);
 uint32_t gft_n_exprs(const gft_engine* e);
@@ -313,6 +316,15 @@ int gft_debug_emulate_scan(const uint8_t* terms_blob, const uint64_t* term_off, 
  * compiler against the oracle's tree evaluation. */
 int gft_debug_eval_programs(const uint32_t* prog_words, const uint64_t* prog_off, uint32_t n_exprs, uint32_t n_slots,
                             const uint8_t* present, uint8_t* out_hit, uint32_t* out_depth);
+
+/* The host solver alone (csrc/host_solve.cpp: dsl/expression.go:66-142 restated over the postfix words, lists materialised):
+ * Solve of ONE program over ONE document's map, given as n_lists keys -- slots[k] with the positions
+ * positions[list_off[k] .. list_off[k+1]) in the order addMatchesToSolverMap appended them (a key may have no position at
+ * all: it is present all the same, dsl/expression_test.go:29-33).  *out = 1 / 0.  This is what gft_process* runs for the
+ * (expression, document) pairs the device does not answer itself: expressions beyond the device solver's limits, and INORD
+ * expressions over a slot whose list is not ascending (a keyword and a regex with the same literal).  No device needed. */
+int gft_debug_host_solve(const uint32_t* words, uint64_t len, const uint32_t* slots, const uint64_t* list_off,
+                         const int64_t* positions, uint32_t n_lists, int* out);
 
 #ifdef __cplusplus
 }

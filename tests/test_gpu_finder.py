@@ -394,14 +394,15 @@ def test_process_device_refuses_descending_offsets_on_the_deferred_path():
     run(good, t, 1500, want)
 
 
-def test_keyword_and_regex_with_the_same_literal_known_deviation():
-    """The one documented difference from the reference.  A keyword "aa" and a regex r"aa" feed ONE map key
-    in the reference (finder/finder.go:181-196): its list is the keyword positions followed by the regex positions,
-    [2 3 4 5] ++ [2 4] for the text below -- not sorted, so getLowestIdxGTVal's binary search (dsl/expression.go:175-189)
-    can miss an element that is there: inord("aaay" and "aa") asks for a position > 4 and the reference answers none.
-    The device solver keeps one sorted position set per slot and finds 5.  Only INORD over such a pair can differ; truth
-    values of everything else (here: the plain regex and keyword expressions) are the reference's."""
-    exprs = ['inord("aaay" and "aa")', 'r"aa"', '"aa" and "aaay"', 'inord("aa" and "aaay")']
+def test_keyword_and_regex_with_the_same_literal_share_one_list():
+    """A keyword "aa" and a regex r"aa" feed ONE map key in the reference (finder/finder.go:181-196): its list is the
+    keyword positions followed by the regex positions, [2 3 4 5] ++ [2 4] for the text below -- not sorted, so
+    getLowestIdxGTVal's binary search (dsl/expression.go:175-189) can miss an element that is there: inord("aaay" and
+    "aa") asks for a position > 4 and the reference answers none, although 5 is in the list.  The device solver keeps one
+    sorted position set per slot; documents in which a slot read by an INORD group gets such a list are therefore solved
+    by the host solver (csrc/host_solve.cpp: the reference's algorithm on materialised lists) -- identical results."""
+    exprs = ['inord("aaay" and "aa")', 'r"aa"', '"aa" and "aaay"', 'inord("aa" and "aaay")', 'inord("xx" and "aa")',
+             'not inord("aaay" and "aa")']
     text = "xxaaaaay"
     f = Finder(GpuEngine(), PyRegexpEngine(), True)
     f.AddExpressions(exprs)
@@ -409,12 +410,69 @@ def test_keyword_and_regex_with_the_same_literal_known_deviation():
     blob, off = pack_strings([text])
     want_bm, _ = _oracle_with_regex(f, exprs, blob, off, 1)
     want = [i for i in range(len(exprs)) if want_bm[0, 0] >> i & 1]
-    assert want == [1, 2, 3]            # the reference: expression 0 is false (binary search over [2 3 4 5 2 4] misses 5)
-    assert got == [0, 1, 2, 3]          # the device: 5 > 4 is found
-    # without the regex twin the two agree again
+    assert want == [1, 2, 3, 4, 5]      # the reference: expression 0 is false (binary search over [2 3 4 5 2 4] misses 5)
+    assert got == want
+    # a batch: only the documents where the pair really occurs take the host's road, all rows equal the reference's
+    texts = [text, "xxaay", "nothing here", "aaay aa", "xx aa aa aaay aa", "aaaaaaay xx aa", ""] * 9
+    blob, off = pack_strings(texts)
+    bm = f.ProcessTexts(texts)
+    want_bm, _ = _oracle_with_regex(f, exprs, blob, off, len(texts))
+    assert np.array_equal(bm, want_bm)
+    # without the regex twin nothing is irregular: the device alone answers, and agrees
     f2 = Finder(GpuEngine(), PyRegexpEngine(), True)
     f2.AddExpressions(exprs[:1] + exprs[2:])
     o = Oracle(sorted(f2.GetKeywords()))
     o.set_expressions(exprs[:1] + exprs[2:], True)
-    assert [r.ExpresionIndex for r in f2.ProcessText(text)] == [0, 1, 2]
-    assert o.process(blob, off)[0, 0] == 0b111
+    assert np.array_equal(f2.ProcessTexts(texts), o.process(blob, off))
+
+
+def test_foreign_engines_with_the_same_literal_share_one_list():
+    """the same with a foreign substring engine: every match arrives as a caller-supplied match, the keyword's hits and the
+    regex's for one literal land in one slot in that order -- a list that is not ascending is spotted from the order of the
+    caller's matches alone"""
+    ms_sub = [Match(p, "aa") for p in (2, 3, 4, 5)] + [Match(4, "aaay")]
+    ms_rgx = [Match(2, "aa"), Match(4, "aa")]
+    sub, rgx = Fixed(ms_sub), Fixed(ms_rgx)
+    f = Finder(sub, rgx, True)
+    exprs = ['inord("aaay" and "aa")', 'inord("aaay" and r"aa")', '"aa"', 'inord("aa" and "aaay")']
+    f.AddExpressions(exprs)
+    rgx.regexes = f.GetRegexes()
+    got = [r.ExpresionIndex for r in f.ProcessText("xxaaaaay")]
+    assert got == [2, 3]                # [2 3 4 5 2 4]: nothing > 4 is found (dsl/expression.go:175-189)
+    rgx.matches = []
+    assert [r.ExpresionIndex for r in f.ProcessText("xxaaaaay")] == [0, 1, 2, 3]     # [2 3 4 5]: 5 > 4
+
+
+def test_expressions_beyond_the_device_solver_limits_are_solved_on_the_host():
+    """The device solver holds at most 64 (slot, threshold) pairs per INORD group and 128 operand-stack entries; the
+    reference's recursion has no such limits (dsl/expression.go:66-142).  An expression beyond them no longer makes
+    gft_set_programs fail: it is solved on the host from the scan's matches while the other 1 000 expressions of the set
+    run on the device as before."""
+    import torch
+    from gofindthem_amd.workload import Workload, make_expressions
+    w = Workload(2000)
+    terms = [t.decode() for t in w.terms()]
+    exprs = make_expressions(w.terms(), 1000, inord_fraction=0.3, cover=True)
+    wide = "inord((%s) and (%s))" % (" or ".join('"%s"' % t for t in terms[:200]), " or ".join('"%s"' % t for t in terms[200:400]))
+    deep = "(" * 150 + " or ".join('("%s" and "%s")' % (terms[2 * i], terms[2 * i + 1]) + ")" for i in range(150))
+    deep_right = '"%s"' % terms[500]
+    for i in range(200):                                 # nests to the right: 200 operands wait on the postfix stack
+        deep_right = '("%s" %s %s)' % (terms[501 + i], "and" if i % 3 else "or", deep_right)
+    exprs = exprs[:400] + [wide] + exprs[400:900] + [deep_right, deep] + exprs[900:]
+    f = Finder(GpuEngine(), EmptyRgxEngine(), False)
+    f.AddExpressions(exprs)
+    o = Oracle(sorted(f.GetKeywords()))
+    o.set_expressions(exprs, False)
+    text, off = w.docs_host(0, 300)
+    want = o.process(text, off, fold=True)
+    assert want[:, 400 >> 5].any() and np.array_equal(f.ProcessTexts(blob=text, doc_off=off), want)
+    one = f.ProcessText(bytes(text[int(off[5]):int(off[6])]))
+    assert [r.ExpresionIndex for r in one] == [i for i in range(len(exprs)) if want[5, i >> 5] >> (i & 31) & 1]
+    # device-resident corpus: the host's bits are patched into the device bitmap
+    docs = [bytes(text[int(off[d]):int(off[d + 1])]).decode() for d in range(300)]
+    t, od = _device_batch(docs)
+    words = (len(exprs) + 31) // 32
+    for _ in range(3):                                   # (first call sizes the tables, the next ones would run deferred)
+        bm = torch.zeros((300, words), dtype=torch.int32, device="cuda")
+        f.ProcessDevice(t.data_ptr(), od.data_ptr(), 300, bm.data_ptr())
+        assert np.array_equal(bm.cpu().numpy().astype(np.uint32), want)

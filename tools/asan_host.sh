@@ -15,7 +15,7 @@ for f in gft_kernels.hip gft_solve.hip gft_scan2.hip gft_scan3.hip; do
   [ $o -nt $CS/$f ] || hipcc --offload-arch=gfx950 -O1 -std=c++17 -fPIC -c $CS/$f -o $o
   objs="$objs $o"
 done
-for f in gft_api.cpp ac_tables.cpp scan2_tables.cpp scan3_tables.cpp dsl_compile.cpp finder_host.cpp json_mini.cpp group_host.cpp; do
+for f in gft_api.cpp ac_tables.cpp scan2_tables.cpp scan3_tables.cpp dsl_compile.cpp finder_host.cpp json_mini.cpp group_host.cpp host_solve.cpp; do
   o=$OUT/$f.o
   hipcc -x hip --offload-arch=gfx950 -O1 -std=c++17 -fPIC $SAN -c $CS/$f -o $o
   objs="$objs $o"

@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgft.so")
 ARCH = "gfx950"
 
-HIP_SOURCES = ["gft_kernels.hip", "gft_solve.hip", "gft_scan2.hip", "gft_scan3.hip"]
+HIP_SOURCES = ["gft_kernels.hip", "gft_solve.hip", "gft_scan2.hip", "gft_scan3.hip", "gft_scan4.hip"]
 CXX_SOURCES = ["gft_api.cpp", "ac_tables.cpp", "scan2_tables.cpp", "scan3_tables.cpp", "dsl_compile.cpp", "finder_host.cpp", "json_mini.cpp", "group_host.cpp", "host_solve.cpp"]
 
 

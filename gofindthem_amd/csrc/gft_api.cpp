@@ -85,6 +85,11 @@ struct gft_engine {
     DevBuf d_s2_short3, d_s2_shorts_packed, d_s2_short3_big, d_s2_fpt;
     uint32_t scan2_short3_bytes = 0;
     uint32_t scan2_k2_waves = 0, scan2_cand_cap = 0;    // scan2_plan
+    // the streaming form of the suffix-window kernel (gft_scan4.hip): same tables, its own LDS plan; a unit's region of the
+    // match pool is sized from the match density (matches per text byte) of the batches before
+    bool use_scan4 = false;
+    uint32_t scan4_waves = 0, scan4_fifo[2] = {0, 0};   // fifo entries without / with positions
+    double scan4_density = 0.06;
     uint64_t scan_valid_docs = ~0ull;                   // documents of the last gft_process scan still in the pool (~0: none)
     uint32_t scan2_unit_max = kScan2UnitMax;            // bytes per work unit (adapts to the match density)
     // a scan launched without knowing the unit count / pool need (gft_process*: one read-back per batch, after the solver)
@@ -476,7 +481,7 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
     const uint32_t warm = e->tab.max_term_len ? e->tab.max_term_len - 1 : 0;
     // gft_scan2: a unit's matches should fit the wave's LDS fifo (kScan2FifoCap), so the unit size follows the match
     // density the previous call saw (dense dictionaries -> smaller units); results do not depend on it
-    const uint32_t unit_max = e->use_scan3 ? kScan3UnitMax : e->use_scan2 ? e->scan2_unit_max : kTextBuf - warm;
+    const uint32_t unit_max = e->use_scan3 ? kScan3UnitMax : e->use_scan4 ? kScan4UnitMax : e->use_scan2 ? e->scan2_unit_max : kTextBuf - warm;
 
     // 1. work units
     HIP_TRY(e->d_ctl.ensure(64), "control alloc");
@@ -572,7 +577,10 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
     if (!rc && !e->deferred && (e->use_scan2 || e->use_scan3)) {
         // (every wave of the grid owns a slab from the start: the pool holds those twice over, or a small batch on a fresh
         // engine would overflow it before it had written a match)
-        const uint64_t wpw = e->use_scan3 ? e->scan3_waves : e->scan2_k2_waves, min_slab = e->use_scan3 ? 2 * kScan3MinRoom : 64;
+        // (scan4: a slab holds at least one chunk's regions -- up to eight units of unit_max bytes at 1.6 x the density seen)
+        const uint64_t wpw = e->use_scan3 ? e->scan3_waves : e->use_scan4 ? e->scan4_waves : e->scan2_k2_waves;
+        const uint64_t min_slab = e->use_scan3 ? 2 * kScan3MinRoom
+                                  : e->use_scan4 ? kScan4ChunkUnits * ((uint64_t)(unit_max * e->scan4_density * 1.6) + 49) : 64;
         const uint64_t waves = std::min<uint64_t>(std::max<uint64_t>((n_units + wpw - 1) / wpw, 1), e->n_cus) * wpw;
         rc = ensure_pool(e, 2 * waves * min_slab);
     }
@@ -672,7 +680,22 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
             HIP_TRY(hipMemsetAsync(e->d_dbg.p, 0, 128, st), "memset");
             P.dbg_counters = e->d_dbg.as<uint64_t>();
         }
-        {
+        if (e->use_scan4) {
+            // the streaming form: chunks of up to eight units (fewer when the batch is small: every wave should get several
+            // chunks), a fifo in place of the candidate list, per-unit regions sized from the density seen so far
+            const uint64_t n_waves4 = (uint64_t)e->n_cus * e->scan4_waves;
+            P.chunk_units = (uint32_t)std::min<uint64_t>(kScan4ChunkUnits, std::max<uint64_t>(1, n_docs / (n_waves4 * 4)));
+            P.cand_cap = e->scan4_fifo[P.want_pos ? 1 : 0];
+            P.bound_q16 = (uint32_t)std::min<double>(e->scan4_density * 1.6 * 65536.0 + 1.0, 4.0e9);
+            P.bound_add = 48;
+            // a slab should hold a few chunks' regions (the rest of a slab that the next chunk does not fit is lost)
+            const uint64_t chunk_need = (uint64_t)P.chunk_units * (((uint64_t)unit_max * P.bound_q16 >> 16) + P.bound_add);
+            P.slab = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(kScan2Slab, 4 * chunk_need), std::max<uint64_t>(chunk_need, e->pool_cap / (2 * n_waves4)));
+            const uint64_t n_chunks = (n_units + P.chunk_units - 1) / P.chunk_units;
+            e->last_static_slabs = std::min<uint64_t>(std::max<uint64_t>((n_chunks + e->scan4_waves - 1) / e->scan4_waves, 1), e->n_cus) * e->scan4_waves * P.slab;
+            ProfScope ps(e, "scan");
+            HIP_TRY(launch_scan4(P, e->scan4_waves, e->n_cus, st), "scan kernel launch");
+        } else {
             ProfScope ps(e, "scan");
             // gft_scan2 serves both paths (ordered for CSR results, unordered + balanced for the solver)
             HIP_TRY(launch_scan2(P, e->scan2_k2_waves, e->n_cus, st), "scan kernel launch");
@@ -706,6 +729,7 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
                     (unsigned long long)c4[2], (unsigned long long)total);
         }
         if (cursor <= e->pool_cap) {
+            if (e->use_scan4 && text_hi > text_lo) e->scan4_density = std::max(0.002, (double)total / (double)(text_hi - text_lo));
             if (P.ordered == 0 && text_hi > text_lo) {
                 // a unit of maximal size should fill ~75 % of the fifo
                 const double per_byte = (double)total / (double)(text_hi - text_lo);
@@ -787,6 +811,7 @@ int deferred_check(gft_engine* e, bool* again) {
         *again = true;
         return GFT_OK;
     }
+    if (e->use_scan4 && text_hi > text_lo) e->scan4_density = std::max(0.002, (double)total / (double)(text_hi - text_lo));
     if (e->use_scan2 && !e->use_scan3 && !e->opt_scan_ordered && text_hi > text_lo) {
         // scan2: a unit of maximal size should fill ~75 % of the fifo
         const double per_byte = (double)total / (double)(text_hi - text_lo);
@@ -1235,6 +1260,18 @@ static int install_tables(gft_engine* e, uint32_t flags) {
                                                         e->s2.fpt_lg ? 0u : kScan2FptSize, e->lds_max - 512,
                                                         &e->scan2_k2_waves, &e->scan2_cand_cap);
     e->use_scan2 = k2_fits && !(force && std::string(force) == "dfa");
+    {
+        uint32_t w0 = 0, w1 = 0;
+        const bool k4_fits = e->s2.supported &&
+                             scan4_plan((uint32_t)e->s2.filter.size(), (uint32_t)e->s2.short3.size(), (uint32_t)std::min<size_t>(e->s2.shorts_packed.size(), 255 * 3),
+                                        e->s2.fpt_lg ? 0u : kScan2FptSize, e->lds_max - 512, false, &w0, &e->scan4_fifo[0]) &&
+                             scan4_plan((uint32_t)e->s2.filter.size(), (uint32_t)e->s2.short3.size(), (uint32_t)std::min<size_t>(e->s2.shorts_packed.size(), 255 * 3),
+                                        e->s2.fpt_lg ? 0u : kScan2FptSize, e->lds_max - 512, true, &w1, &e->scan4_fifo[1]);
+        e->scan4_waves = std::min(w0, w1);
+        // (the fifo capacities belong to the smaller of the two wave counts; with fewer waves there is only more room)
+        e->use_scan4 = e->use_scan2 && k4_fits && force && std::string(force) == "scan4";
+        e->scan4_density = 0.06;
+    }
     // Kernel choice: the suffix-window kernel (scan2) where its direct tables apply -- small alphabets, the benchmark's
     // shape --, the stride-2 kernel (scan3: any alphabet, merged filter groups) everywhere else; the DFA kernel only as
     // a cross-check.  GFT_SCAN_KERNEL=scan2 / scan3 / dfa forces one (read here, i.e. by gft_build / gft_import_tables)
@@ -1242,7 +1279,7 @@ static int install_tables(gft_engine* e, uint32_t flags) {
     const bool k3_fits = e->s3.supported && scan3_plan((uint32_t)e->s3.filter.size(), (uint32_t)e->s3.short3.size(), (uint32_t)e->s3.srec.size(),
                                                         bloom_lds_bytes, e->lds_max - 512, &e->scan3_waves, &e->scan3_cand_cap);
     const std::string forced = force ? force : "";
-    e->use_scan3 = k3_fits && forced != "dfa" && forced != "scan2" && (forced == "scan3" || !e->use_scan2);
+    e->use_scan3 = k3_fits && forced != "dfa" && forced != "scan2" && forced != "scan4" && (forced == "scan3" || !e->use_scan2);
     if (e->use_scan3) {
         if ((rc = upload(e, e->d_s3_filter, e->s3.filter, "table upload"))) return rc;
         s3v = e->s3.short3;
@@ -1325,7 +1362,7 @@ uint32_t gft_n_exprs(const gft_engine* e) { return e ? e->n_exprs : 0; }
 int gft_last_nonascii(const gft_engine* e) { return e && e->last_nonascii ? 1 : 0; }
 const char* gft_scan_kernel(const gft_engine* e) {
     if (!e || !e->built) return "";
-    return e->use_scan3 ? "scan3" : e->use_scan2 ? "scan2" : "dfa";
+    return e->use_scan3 ? "scan3" : e->use_scan4 ? "scan4" : e->use_scan2 ? "scan2" : "dfa";
 }
 
 int gft_term(const gft_engine* e, uint32_t term_id, const uint8_t** ptr, uint32_t* len) try {

@@ -265,11 +265,21 @@ struct Scan2Params {
     uint32_t dbg;                // GFT_SCAN_DEBUG bits (timing studies only): 1 = skip verification, 2 = count flags
     uint32_t* nonascii;          // fold only: *nonascii |= 1 when the text holds a byte >= 0x80 (nullptr: not wanted)
     uint64_t* dbg_counters;      // [4] when dbg & 2: flagged positions, table probes, entries compared, -
+    // gft_scan4.hip (the streaming form) only:
+    uint32_t chunk_units;        // units a wave streams through in one go (1 .. kScan4ChunkUnits)
+    uint32_t bound_q16, bound_add;   // a unit's region of the match pool: bytes * bound_q16 / 65536 + bound_add entries
 };
 // waves per workgroup (16, 12, 8 or 4) and candidate-list capacity that fit lds_max; false if nothing fits
 bool scan2_plan(uint32_t filter_words, uint32_t short3_bytes, uint32_t shorts_words, uint32_t fpt_lds_bytes, size_t lds_max,
                 uint32_t* waves, uint32_t* cand_cap);
 hipError_t launch_scan2(const Scan2Params& P, uint32_t waves, unsigned n_cus, hipStream_t st);
+// gft_scan4.hip: the same tables, streamed chunk by chunk.  A chunk's positions are 16-bit: units of at most kScan4UnitMax bytes
+constexpr uint32_t kScan4ChunkUnits = 8;
+constexpr uint32_t kScan4UnitMax = 8176;
+// waves per workgroup and the match fifo's capacity (entries; goes into Scan2Params::cand_cap) that fit lds_max
+bool scan4_plan(uint32_t filter_words, uint32_t short3_bytes, uint32_t shorts_words, uint32_t fpt_lds_bytes, size_t lds_max, bool want_pos,
+                uint32_t* waves, uint32_t* fifo_cap);
+hipError_t launch_scan4(const Scan2Params& P, uint32_t waves, unsigned n_cus, hipStream_t st);
 
 
 // ---- stride-2 suffix-window scan (gft_scan3.hip; tables built by scan3_tables.cpp) ---------------------------------

@@ -402,7 +402,7 @@ def test_keyword_and_regex_with_the_same_literal_share_one_list():
     sorted position set per slot; documents in which a slot read by an INORD group gets such a list are therefore solved
     by the host solver (csrc/host_solve.cpp: the reference's algorithm on materialised lists) -- identical results."""
     exprs = ['inord("aaay" and "aa")', 'r"aa"', '"aa" and "aaay"', 'inord("aa" and "aaay")', 'inord("xx" and "aa")',
-             'not inord("aaay" and "aa")']
+             'not (inord("aaay" and "aa"))']
     text = "xxaaaaay"
     f = Finder(GpuEngine(), PyRegexpEngine(), True)
     f.AddExpressions(exprs)

@@ -10,11 +10,11 @@ from oracle.pyoracle import Oracle, POS_END, POS_START
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["scan3", "scan2", "scan2-ordered", "dfa"], autouse=True)
+@pytest.fixture(params=["scan4", "scan3", "scan2", "scan2-ordered", "dfa"], autouse=True)
 def scan_kernel(request, monkeypatch):
-    """every test runs against the stride-2 suffix-window kernel (the default), the round-1 suffix-window kernel
-    (GFT_SCAN_KERNEL=scan2: balanced path, and its in-kernel ordered path with GFT_SCAN_ORDERED=1) and the general
-    two-tier DFA kernel (GFT_SCAN_KERNEL=dfa); the variable is read by gft_build"""
+    """every test runs against the streaming suffix-window kernel (scan4), the stride-2 suffix-window kernel (scan3), the
+    round-1 suffix-window kernel (GFT_SCAN_KERNEL=scan2: balanced path, and its in-kernel ordered path with
+    GFT_SCAN_ORDERED=1) and the general two-tier DFA kernel (GFT_SCAN_KERNEL=dfa); the variable is read by gft_build"""
     monkeypatch.setenv("GFT_SCAN_KERNEL", request.param.split("-")[0])
     if request.param.endswith("-ordered"):
         monkeypatch.setenv("GFT_SCAN_ORDERED", "1")
@@ -462,7 +462,7 @@ def test_mixed_alphabet_workload(eng, scan_kernel):
     assert len({b for t in kws for b in t}) >= 48 and min(len(t) for t in kws) <= 3
     o = both(eng, kws)
     L = _lib.load()
-    assert L.gft_scan_kernel(eng._h).decode() == {"scan3": "scan3", "scan2": "dfa", "scan2-ordered": "dfa", "dfa": "dfa"}[scan_kernel]
+    assert L.gft_scan_kernel(eng._h).decode() == {"scan4": "dfa", "scan3": "scan3", "scan2": "dfa", "scan2-ordered": "dfa", "dfa": "dfa"}[scan_kernel]
     text, off = w.docs_host(0, 400)
     assert_csr_equal(eng.scan(text, off, fold=True), o.scan(text, off, fold=True))
     assert_csr_equal(eng.scan(text, off, fold=False), o.scan(text, off, fold=False))

@@ -706,6 +706,11 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
             uint64_t t[16];
             HIP_TRY(hipMemcpyAsync(t, e->d_dbg.p, sizeof t, hipMemcpyDeviceToHost, st), "debug read-back");
             HIP_TRY(hipStreamSynchronize(st), "debug read-back");
+            if (e->use_scan4)
+                fprintf(stderr, "[gft scan debug] scan4 wave cycles per unit: chunk set-up %.0f, filter %.0f, queue push %.0f, stage A issue %.0f, stage A %.0f, stage B %.0f, flush %.0f, unit records %.0f\n",
+                        (double)t[4] / n_units, (double)t[5] / n_units, (double)t[6] / n_units, (double)t[7] / n_units, (double)t[8] / n_units,
+                        (double)t[9] / n_units, (double)t[10] / n_units, (double)t[11] / n_units);
+            else
             fprintf(stderr, "[gft scan debug] wave cycles per unit: first bytes %.0f, filter %.0f, list %.0f, stage A %.0f, stage B %.0f, flush %.0f, unit record %.0f\n",
                     (double)t[4] / n_units, (double)t[5] / n_units, (double)t[6] / n_units, (double)t[7] / n_units, (double)t[8] / n_units,
                     (double)t[9] / n_units, (double)t[11] / n_units);

@@ -882,6 +882,7 @@ int solve_pipeline(gft_engine* e, uint64_t n_docs, const gft_extra_matches* d_ex
     S.unit_start = e->d_unit_start.as<uint64_t>(); S.unit_count = e->d_unit_count.as<uint32_t>();
     S.units = e->d_units.as<Unit>();
     S.has_rare = e->n_rare_words > 0 ? 1u : 0u;
+    S.pos_back = (e->build_flags & GFT_POS_END) ? 0u : (e->tab.max_term_len ? e->tab.max_term_len - 1 : 0u);
     S.term = e->d_pool_term.as<uint32_t>(); S.pos = e->d_pool_pos.as<uint32_t>();
     S.x_off = d_extra ? d_extra->off : nullptr;
     S.x_slot = d_extra ? d_extra->slot : nullptr;

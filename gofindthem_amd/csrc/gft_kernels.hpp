@@ -115,6 +115,8 @@ struct SolveParams {
     const uint32_t* order;       // [n_exprs] evaluation order inside every output tile (gft_set_programs)
     const Unit* units;           // the scan's work units (document of every unit)
     uint32_t has_rare;           // some program holds a NOT or INORD word (0: the kernel variant without the position algebra)
+    uint32_t pos_back;           // a match's reported position lies at most this far in front of the unit it ends in: max_term_len - 1
+                                 // (GFT_POS_START), 0 (GFT_POS_END) -- where a successor walk over a long document may stop
     const uint32_t* blk_class;   // per 64 sorted programs: the interpreter they need (0 flat, 1 register stack, 2 deep)
     const uint32_t* wave_blk;    // per tile and round of 16 blocks: the block (inside the tile) of every wave, or ~0
     const uint32_t* fprog_t;     // the same programs per sorted block, transposed by chunk: words 4c..4c+3 of lane l at fblk_off[b] + (c * 64 + l) * 4

@@ -41,6 +41,8 @@ struct DocHits {
     const uint32_t* xslot;
     const uint32_t* xpos;
     uint32_t nx;
+    uint32_t per;               // size of the document's slices (units), for a document of kUnitsPerLaneMode units or more
+    uint32_t back;              // a match's position is at most this far in front of the slice it ends in (0: positions ARE ends)
 };
 
 constexpr uint32_t kNoSlot = 0xFFFFFFFFu;      // pair that never matches: the empty position list
@@ -72,6 +74,9 @@ __device__ int64_t wave_succ_min(const DocHits& M, uint32_t my_slot, int64_t my_
     int64_t best = INT64_MAX;
     const uint32_t sl0 = __builtin_amdgcn_readlane(my_slot, pb);
     const int64_t th0 = readlane_i64(my_theta, pb);
+    // the empty list (the single pair that no match satisfies): nothing to walk -- what is left of a chain behind a term
+    // that does not occur costs nothing (benchmarks/benchmark_test.go:438-462 builds chains of 10 000 terms)
+    if (pc == 1 && sl0 == kNoSlot) return INT64_MAX;
     auto test = [&](uint32_t t, uint32_t p) {
         if (t == sl0 && (int64_t)p > th0 && (int64_t)p < best) best = p;
         for (uint32_t k = 1; k < pc; k++) {
@@ -81,25 +86,56 @@ __device__ int64_t wave_succ_min(const DocHits& M, uint32_t my_slot, int64_t my_
         }
     };
     if (M.u1 - M.u0 >= kUnitsPerLaneMode) {
-        for (uint64_t u = M.u0 + lane; u < M.u1; u += 64) {
-            const uint64_t s = M.unit_start[u];
-            const uint32_t n = M.unit_count[u];
-            uint32_t i = 0;
-            for (; i + 8 <= n; i += 8) {                         // eight matches in flight per lane (the walk is latency-bound)
-                uint32_t t[8], p[8];
-#pragma unroll
-                for (int q = 0; q < 8; q++) { t[q] = M.term[s + i + q]; p[q] = M.pos[s + i + q]; }
-#pragma unroll
-                for (int q = 0; q < 8; q++) test(t[q], p[q]);
-            }
-            for (; i + 4 <= n; i += 4) {
+        // A long document: its units are equal slices in position order, a unit holds the matches that END in its slice.
+        // Nothing at or below the smallest threshold can answer, so the walk starts at the unit that holds that position
+        // -- and it stops as soon as no later unit can hold a smaller answer (a match of a later unit ends behind this
+        // one's slice and starts at most max_term_len - 1 bytes earlier): a chain of k queries over n matches walks
+        // O(n + k x one unit) entries, not k x n.
+        int64_t thmin = th0;
+        for (uint32_t k = 1; k < pc; k++) { const int64_t th = readlane_i64(my_theta, pb + k); thmin = th < thmin ? th : thmin; }
+        const uint64_t per = M.per;                                                   // (all but the last slice have this size)
+        const uint64_t k0 = thmin < 0 ? 0 : (uint64_t)thmin / per;                    // the slice that holds position thmin
+        uint64_t ub = M.u0 + (k0 < M.u1 - M.u0 ? k0 : M.u1 - M.u0 - 1);
+        {   // the first unit, strided over all lanes: one round trip for a unit of a few hundred matches
+            const uint64_t s = M.unit_start[ub];
+            const uint32_t n = M.unit_count[ub];
+            for (uint32_t i0 = 0; i0 < n; i0 += 64 * 4) {
                 uint32_t t[4], p[4];
 #pragma unroll
-                for (int q = 0; q < 4; q++) { t[q] = M.term[s + i + q]; p[q] = M.pos[s + i + q]; }
+                for (int q = 0; q < 4; q++) { const uint32_t i = i0 + 64 * q + lane; t[q] = i < n ? M.term[s + i] : kNoSlot - 1; p[q] = i < n ? M.pos[s + i] : 0u; }
 #pragma unroll
                 for (int q = 0; q < 4; q++) test(t[q], p[q]);
             }
-            for (; i < n; i++) test(M.term[s + i], M.pos[s + i]);
+            ub++;
+        }
+        int64_t sofar = wave_min_i64(best);
+        // ... then the units behind it, one per lane, 64 at a time
+        while (ub < M.u1) {
+            const int64_t next_lo = (int64_t)((ub - M.u0) * per);                      // positions of the next unit's slice begin here
+            if (sofar != INT64_MAX && next_lo - (int64_t)M.back > sofar) break;
+            const uint64_t u = ub + lane;
+            if (u < M.u1) {
+                const uint64_t s = M.unit_start[u];
+                const uint32_t n = M.unit_count[u];
+                uint32_t i = 0;
+                for (; i + 8 <= n; i += 8) {                     // eight matches in flight per lane (the walk is latency-bound)
+                    uint32_t t[8], p[8];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) { t[q] = M.term[s + i + q]; p[q] = M.pos[s + i + q]; }
+#pragma unroll
+                    for (int q = 0; q < 8; q++) test(t[q], p[q]);
+                }
+                for (; i + 4 <= n; i += 4) {
+                    uint32_t t[4], p[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) { t[q] = M.term[s + i + q]; p[q] = M.pos[s + i + q]; }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) test(t[q], p[q]);
+                }
+                for (; i < n; i++) test(M.term[s + i], M.pos[s + i]);
+            }
+            ub += 64;
+            sofar = wave_min_i64(best);
         }
     } else {
         for (uint64_t u = M.u0; u < M.u1; u++) {
@@ -227,6 +263,13 @@ __device__ __forceinline__ uint64_t inord_wave(const SolveParams& S, bool is_ino
             M.term = S.term; M.pos = S.pos;
             M.u0 = S.doc_unit_base[d]; M.u1 = S.doc_unit_base[d + 1];
             M.nx = 0; M.xslot = nullptr; M.xpos = nullptr;
+            M.back = S.pos_back;
+            M.per = 1;
+            if (M.u1 - M.u0 >= kUnitsPerLaneMode) {                                   // (read once per document, not once per query)
+                const Unit first = S.units[M.u0];
+                const uint32_t per32 = __builtin_amdgcn_readfirstlane(first.hi - first.lo);
+                M.per = per32 ? per32 : 1u;
+            }
             if (S.x_off) {
                 const uint64_t x0 = S.x_off[d];
                 M.xslot = S.x_slot + x0; M.xpos = S.x_pos + x0; M.nx = (uint32_t)(S.x_off[d + 1] - x0);

@@ -233,14 +233,17 @@ class Finder:
     def n_expressions(self):
         return self._L.gft_finder_n_expressions(self._h)
 
-    def expression(self, i):
-        """-> (exprString, tag, tree as dict)"""
+    def expression(self, i, tree=True):
+        """-> (exprString, tag, tree as dict); tree=False: source and tag only (the reference's own benchmarks build chains
+        of 10 000 leaves, benchmarks/benchmark_test.go:56 -- a tree that deep is not something json.loads should recurse into)"""
         ptrs = [C.c_void_p() for _ in range(3)]
         lens = [C.c_uint32() for _ in range(3)]
         self._check(self._L.gft_finder_expression(self._h, i, C.byref(ptrs[0]), C.byref(lens[0]), C.byref(ptrs[1]),
-                                                  C.byref(lens[1]), C.byref(ptrs[2]), C.byref(lens[2])))
-        s, t, j = (C.string_at(p, n.value) for p, n in zip(ptrs, lens))
-        return s.decode("utf-8", "surrogateescape"), t.decode("utf-8", "surrogateescape"), json.loads(j.decode("utf-8"))
+                                                  C.byref(lens[1]), C.byref(ptrs[2]) if tree else None,
+                                                  C.byref(lens[2]) if tree else None))
+        s, t = (C.string_at(p, n.value) for p, n in zip(ptrs[:2], lens[:2]))
+        j = json.loads(C.string_at(ptrs[2], lens[2].value).decode("utf-8")) if tree else None
+        return s.decode("utf-8", "surrogateescape"), t.decode("utf-8", "surrogateescape"), j
 
     # -- processing -----------------------------------------------------------------------------------
     def ForceBuild(self):
@@ -255,7 +258,7 @@ class Finder:
         self._check(self._L.gft_finder_process_text(self._h, b, len(b), idx.ctypes.data, cap, C.byref(n)))
         cache = self.__dict__.setdefault("_expr_cache", [])      # (source, tag) per registered expression
         while len(cache) < self.n_expressions:
-            s, t, _ = self.expression(len(cache))
+            s, t, _ = self.expression(len(cache), tree=False)
             cache.append((s, t))
         return [ExpressionResult(i, cache[i][0], cache[i][1]) for i in idx[:n.value].tolist()]
 

@@ -476,3 +476,47 @@ def test_expressions_beyond_the_device_solver_limits_are_solved_on_the_host():
         bm = torch.zeros((300, words), dtype=torch.int32, device="cuda")
         f.ProcessDevice(t.data_ptr(), od.data_ptr(), 300, bm.data_ptr())
         assert np.array_equal(bm.cpu().numpy().astype(np.uint32), want)
+
+
+@pytest.mark.parametrize("k", [100, 10000])
+def test_inord_chains_of_the_reference_benchmarks(k):
+    """benchmarks/benchmark_test.go:55-56, 132-134, 182-184, 438-462: exp100 / exp10000 are ONE `INORD` of 100 / 10 000 AND-ed
+    terms over the ~1 MB document of createText (:66, :473-489).  Once with terms drawn at random like the reference does
+    (a term that does not occur ends the chain: false), once with the terms planted in that order (true) -- every AND is a
+    successor query on the document's matches (dsl/expression.go:87-95), the left-deep chain is as long as the reference's.
+    Both documents in one batch, against the oracle."""
+    from gofindthem_amd.workload import Workload
+    w = Workload(10000)
+    terms = [t.decode() for t in w.terms()]
+    rng = np.random.default_rng(k)
+    blob, off = w.docs_host(0, 250)
+    random_doc = bytes(blob[:int(off[-1])]).decode()
+    words = random_doc.split(" ")
+    assert 900_000 < len(random_doc) < 1_300_000
+    order = rng.permutation(len(terms))[:k].tolist()
+    # the planted document: the same words with term order[i] inserted behind every (len(words) // k)-th word
+    step = max(len(words) // k, 1)
+    out, nxt = [], 0
+    for i, wd in enumerate(words):
+        out.append(wd)
+        if i % step == step - 1 and nxt < k:
+            out.append(terms[order[nxt]])
+            nxt += 1
+    out += [terms[j] for j in order[nxt:]]
+    planted_doc = " ".join(out)
+    chain = "INORD(" + " and ".join('"%s"' % terms[j] for j in order) + ")"
+    drawn = "INORD(" + " and ".join('"%s"' % terms[j] for j in rng.integers(0, len(terms), k).tolist()) + ")"
+    back = "INORD(" + " and ".join('"%s"' % terms[j] for j in order[::-1]) + ")"
+    exprs = [chain, drawn, back, '"%s" and "%s"' % (terms[order[0]], terms[order[-1]])]
+    f = Finder(GpuEngine(), EmptyRgxEngine(), False)
+    f.AddExpressions(exprs)
+    o = Oracle(sorted(f.GetKeywords()))
+    o.set_expressions(exprs, False)
+    docs = [random_doc, planted_doc, "", planted_doc[: len(planted_doc) // 2]]
+    lb, lo = pack_strings(docs)
+    want = o.process(lb, lo, fold=True)
+    got = f.ProcessTexts(docs)
+    assert np.array_equal(got, want)
+    assert int(want[1, 0]) & 1 == 1 and int(want[3, 0]) & 1 == 0          # in order on the planted document, cut short on its half
+    one = f.ProcessText(planted_doc)
+    assert [r.ExpresionIndex for r in one] == [i for i in range(len(exprs)) if int(want[1, 0]) >> i & 1]

@@ -170,11 +170,18 @@ def main():
     gen_ok = bool(np.array_equal(d_off, h_off)) and bool(
         np.array_equal(text[:int(h_off[-1])].cpu().numpy(), h_text))
     parity_ok = all_ranks_ok(gen_ok, dev)
-    if world > 1 and rank == 0:
-        last = (n_steps_done[0] - 1) % len(bitmaps)
-        parity_ok = parity_ok and bool(torch.equal(gather.slot_parts[last][0], bitmaps[last]))
-        bitmap = bitmaps[last]
     parity = "not checked in this run (the CPU oracle runs in the cpu_baseline leg, N = 1 only); tests/ -m gpu hold the parity proofs"
+    if world > 1:
+        # the exchange itself: every rank's checksum of what it computed against rank 0's checksum of what it received
+        # (one tiny all_gather, outside the timed region)
+        from gofindthem_amd.sharding import verify_gather
+        last = (n_steps_done[0] - 1) % len(bitmaps)
+        arrived, n_shards = verify_gather(gather, last, args.docs)
+        arrived = all_ranks_ok(arrived, dev)
+        parity_ok = parity_ok and arrived
+        bitmap = bitmaps[last]
+        parity = ("gathered bitmap verified against the per-rank checksums of all %d shards (the CPU oracle runs in the cpu_baseline "
+                  "leg, N = 1 only)" % n_shards) if arrived else "MISMATCH between a rank's bitmap and what rank 0 received"
 
     # ---- CPU baseline (rank 0, N == 1): the oracle = our restatement of the reference path, on this host ---------------
     cpu = None

@@ -90,6 +90,35 @@ class BitmapGather:
         return torch.cat(parts, 0) if self.rank == 0 else None
 
 
+def bitmap_checksum(t):
+    """64-bit position-weighted checksum of an int32 bitmap (on the tensor's device; wraps like uint64 arithmetic):
+    a word that changed, moved or went missing changes it"""
+    w = t.reshape(-1).to(torch.int64) & 0xFFFFFFFF
+    k = torch.arange(1, w.numel() + 1, dtype=torch.int64, device=t.device) * 0x9E3779B1 + 0x7F4A7C15
+    return int(((w + 1) * k).sum().item()) & 0xFFFFFFFFFFFFFFFF
+
+
+def verify_gather(gather, slot, rows):
+    """Did every shard's bitmap arrive on rank 0 intact?  Every rank folds the first `rows` rows of its LOCAL bitmap of
+    `slot` into a checksum on its device; one tiny all_gather brings the checksums (and row counts) together; rank 0
+    computes the same checksums over what the gather delivered and compares.  -> (ok on rank 0 / True elsewhere, shards
+    checked).  Outside any timed region: it synchronises."""
+    if gather.world == 1:
+        return True, 1
+    local = gather.locals[slot][:rows]
+    dev = local.device
+    c = bitmap_checksum(local)
+    mine = torch.tensor([c - (1 << 64) if c >= (1 << 63) else c, rows], dtype=torch.int64, device=dev)   # (as a signed word)
+    allv = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(gather.world)]
+    dist.all_gather(allv, mine)
+    ok = True
+    if gather.rank == 0:
+        for r, v in enumerate(allv):
+            want, n = int(v[0].item()) & 0xFFFFFFFFFFFFFFFF, int(v[1].item())
+            ok = ok and bitmap_checksum(gather.slot_parts[slot][r][:n]) == want
+    return ok, gather.world
+
+
 def all_ranks_ok(flag, device):
     """logical AND of a per-rank boolean"""
     if not dist.is_initialized() or dist.get_world_size() == 1:

@@ -62,6 +62,15 @@ def _worker(rank, world, port, use_gpu, out_path):
     pipelined_ok = True
     if rank == 0:
         pipelined_ok = bool(torch.equal(gp.full(0), g.full())) and bool(torch.equal(gp.full(1), g.full() ^ 0x55))
+    # bench.py's N > 1 parity: per-rank checksums against what rank 0 received -- and it notices a damaged shard
+    from gofindthem_amd.sharding import verify_gather
+    arrived, n_shards = verify_gather(gp, 1, n)
+    pipelined_ok = pipelined_ok and arrived and n_shards == world
+    if rank == 0:
+        gp.slot_parts[1][world - 1][n // 2, 0] ^= 1 << 7
+    damaged, _ = verify_gather(gp, 1, n)
+    if rank == 0:
+        pipelined_ok = pipelined_ok and not damaged
     ok = all_ranks_ok(pipelined_ok, "cpu")
     t = max_over_ranks(float(rank), "cpu")
     if rank == 0:

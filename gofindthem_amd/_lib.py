@@ -11,6 +11,7 @@ GFT_E_NOMEM, GFT_E_INTERNAL, GFT_W_NO_RCCL = -7, -8, 1
 GFT_POS_START, GFT_POS_END = 0, 1
 GFT_FOLD_ASCII = 1
 GFT_SCAN_UNIQUE = 2
+GFT_POS_RUNES = 4
 OP_UNIT, OP_AND, OP_OR, OP_NOT, OP_INORD = 1, 2, 3, 4, 5
 INORD_FLAG = 1 << 27
 

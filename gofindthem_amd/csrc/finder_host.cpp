@@ -328,8 +328,14 @@ Error Finder::ProcessTexts(const uint8_t* blob, const uint64_t* doc_off, uint64_
     std::vector<uint64_t> loff;
     const uint64_t total = n_docs ? doc_off[n_docs] : 0;
     bool ascii = true;
+    // A large batch that only the device reads is not scanned for high bytes here first (a pass over the whole text on
+    // host cores, a third of the call's time at PCIe rates): it goes up as it is, the scan kernels notice what ASCII
+    // folding does not cover (gft_last_nonascii), and only such a batch comes back for the host's ToLower.
+    const bool optimistic = !caseSensitive_ && !force_host_lower_ && gpu_sub_ && regexes_.empty() && !prefilter_active() &&
+                            total - (n_docs ? doc_off[0] : 0) >= (16u << 20);
     if (!caseSensitive_) {
-        ascii = all_ascii(blob + (n_docs ? doc_off[0] : 0), total - (n_docs ? doc_off[0] : 0));
+        if (force_host_lower_) ascii = false;
+        else if (!optimistic) ascii = all_ascii(blob + (n_docs ? doc_off[0] : 0), total - (n_docs ? doc_off[0] : 0));
         if (ascii) flags = GFT_FOLD_ASCII;
     }
     const bool need_host_text = !caseSensitive_ && !ascii;
@@ -361,6 +367,12 @@ Error Finder::ProcessTexts(const uint8_t* blob, const uint64_t* doc_off, uint64_
     // (a disabled prefilter still leaves its programs out: total_programs() == expressions_.size() then)
     int rc = gft_process(gpu_->handle(), blob, doc_off, n_docs, flags, per_doc_engines && n_docs ? &x : nullptr, bitmap);
     if (rc) return fail_gft(rc);
+    if (optimistic && gft_last_nonascii(gpu_->handle())) {
+        // text that ASCII folding does not lower-case the way strings.ToLower does (finder.go:140-142): once more, through it
+        struct Reset { bool& f; ~Reset() { f = false; } } reset{force_host_lower_};
+        force_host_lower_ = true;
+        return ProcessTexts(blob, doc_off, n_docs, bitmap);
+    }
     return "";
 }
 

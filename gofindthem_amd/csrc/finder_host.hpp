@@ -120,6 +120,7 @@ public:
     const std::vector<ExprWrapper>& expressions() const { return expressions_; }
     int last_code() const { return last_code_; }
     uint64_t last_regex_docs = 0;        // documents the host regex engine saw in the last prefiltered ProcessTexts
+    bool force_host_lower_ = false;      // ProcessTexts is repeating a batch whose text the device cannot fold (finder_host.cpp)
 
     // test hooks (finder_test.go pokes the struct fields directly)
     void debug_add_literal(int which, const std::string& lit);

@@ -156,6 +156,7 @@ struct gft_engine {
     // staging for the host-buffer entry points
     DevBuf d_text, d_doc_off, d_bitmap, d_xoff, d_xslot, d_xpos;
     DevBuf d_uq_first, d_uq_cnt, d_uq_off, d_uq_term;   // GFT_SCAN_UNIQUE: per-workgroup first-occurrence rows, unique CSR
+    DevBuf d_rn_cnt, d_rn_base, d_rn_starts, d_rn_prefix;   // GFT_POS_RUNES: blocks per document, their rune starts, prefix sums
     std::vector<uint64_t> h_match_off;
     std::vector<uint32_t> h_term, h_pos;
 
@@ -875,6 +876,30 @@ int unique_pipeline(gft_engine* e, uint64_t n_docs, uint64_t* n_matches) {
     return GFT_OK;
 }
 
+// GFT_POS_RUNES: the positions of the canonical CSR in d_pos become offsets over []rune(text), what AnknownEngine reports
+// (finder/substringEngine.go:44-53: MultiPatternSearch([]rune(text), ...), Position = m.Pos)
+int rune_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_off, uint64_t n_docs, uint64_t n_matches) {
+    if (!n_docs || !n_matches) return GFT_OK;
+    hipStream_t st = e->stream;
+    HIP_TRY(e->d_rn_cnt.ensure(n_docs * 4), "rune alloc");
+    HIP_TRY(e->d_rn_base.ensure((n_docs + 1) * 8), "rune alloc");
+    HIP_TRY(e->d_partial.ensure(scan_partials_needed(n_docs) * 8), "rune alloc");
+    ProfScope ps(e, "aux");
+    HIP_TRY(launch_rune_doc_blocks(d_doc_off, n_docs, e->d_rn_cnt.as<uint32_t>(), st), "rune blocks");
+    HIP_TRY(launch_exclusive_scan(e->d_rn_cnt.as<uint32_t>(), n_docs, e->d_rn_base.as<uint64_t>(), e->d_partial.as<uint64_t>(), st), "rune scan");
+    uint64_t n_blocks = 0;
+    HIP_TRY(hipMemcpyAsync(&n_blocks, e->d_rn_base.as<uint64_t>() + n_docs, 8, hipMemcpyDeviceToHost, st), "readback");
+    HIP_TRY(hipStreamSynchronize(st), "rune scan");
+    HIP_TRY(e->d_rn_starts.ensure(std::max<uint64_t>(n_blocks, 1) * 4), "rune alloc");
+    HIP_TRY(e->d_rn_prefix.ensure((n_blocks + 1) * 8), "rune alloc");
+    HIP_TRY(e->d_partial.ensure(scan_partials_needed(std::max(n_blocks, n_docs)) * 8), "rune alloc");
+    HIP_TRY(launch_rune_block_starts(d_text, d_doc_off, e->d_rn_base.as<uint64_t>(), n_docs, n_blocks, e->d_rn_starts.as<uint32_t>(), st), "rune starts");
+    HIP_TRY(launch_exclusive_scan(e->d_rn_starts.as<uint32_t>(), n_blocks, e->d_rn_prefix.as<uint64_t>(), e->d_partial.as<uint64_t>(), st), "rune scan");
+    HIP_TRY(launch_pos_to_rune(d_text, d_doc_off, e->d_rn_base.as<uint64_t>(), e->d_rn_prefix.as<uint64_t>(), e->d_match_off.as<uint64_t>(), n_docs,
+                               n_matches, e->d_pos.as<uint32_t>(), st), "rune offsets");
+    return GFT_OK;
+}
+
 int solve_pipeline(gft_engine* e, uint64_t n_docs, const gft_extra_matches* d_extra, uint32_t* d_bitmap) {
     if (!n_docs || !e->n_exprs) return GFT_OK;
     SolveParams S;
@@ -1207,7 +1232,7 @@ void gft_engine_destroy(gft_engine* e) {
 &e->d_unit_cnt, &e->d_unit_base, &e->d_units, &e->d_partial,
                          &e->d_pool_term, &e->d_pool_pos, &e->d_unit_start, &e->d_unit_count, &e->d_unit_out,
                          &e->d_term, &e->d_pos, &e->d_match_off, &e->d_text, &e->d_doc_off, &e->d_bitmap, &e->d_xoff,
-                         &e->d_xslot, &e->d_xpos, &e->d_uq_first, &e->d_uq_cnt, &e->d_uq_off, &e->d_uq_term, &e->d_patch};
+                         &e->d_xslot, &e->d_xpos, &e->d_uq_first, &e->d_uq_cnt, &e->d_uq_off, &e->d_uq_term, &e->d_patch, &e->d_rn_cnt, &e->d_rn_base, &e->d_rn_starts, &e->d_rn_prefix};
         for (DevBuf* b : all) b->release();
         for (int k = 0; k < 2; k++) {
             if (e->pin[k]) (void)hipHostFree(e->pin[k]);
@@ -1484,6 +1509,10 @@ int gft_scan_device(gft_engine* e, const uint8_t* d_text_blob, const uint64_t* d
     int rc = scan_pipeline(e, d_text_blob, d_doc_off, n_docs, flags, true, &nm);
     if (rc) return rc;
     if ((flags & GFT_SCAN_UNIQUE) && (rc = unique_pipeline(e, n_docs, &nm))) return rc;
+    if ((flags & GFT_POS_RUNES) && !(flags & GFT_SCAN_UNIQUE)) {
+        if (e->build_flags & GFT_POS_END) return fail(e, GFT_E_UNSUPPORTED, "GFT_POS_RUNES needs a GFT_POS_START engine (AnknownEngine reports where a match begins)");
+        if ((rc = rune_pipeline(e, d_text_blob, d_doc_off, n_docs, nm))) return rc;
+    }
     if ((rc = refine_nonascii(e, d_text_blob, flags))) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream), "scan pipeline");
     out_dev->n_docs = n_docs; out_dev->n_matches = nm;
@@ -1493,8 +1522,18 @@ int gft_scan_device(gft_engine* e, const uint8_t* d_text_blob, const uint64_t* d
     return GFT_OK;
 } GFT_CATCH((e ? &e->err : nullptr))
 
-constexpr size_t kPinChunk = 32u << 20;      // bytes per bounce buffer
-constexpr unsigned kPinThreads = 4;
+constexpr size_t kPinChunk = 64u << 20;      // bytes per bounce buffer
+// copy threads that fill a bounce buffer: the link (PCIe Gen5 x16, ~55 GB/s in practice) is only kept busy when the host
+// side copies faster than that -- four threads reach ~30 GB/s, so the staging takes what the machine offers, up to 12
+// (GFT_HOST_THREADS overrides)
+static unsigned pin_threads() {
+    static const unsigned n = [] {
+        if (const char* e = getenv("GFT_HOST_THREADS")) { const int v = atoi(e); if (v > 0) return (unsigned)std::min(v, 32); }
+        const unsigned hc = std::thread::hardware_concurrency();
+        return hc ? std::min(std::max(hc, 2u), 12u) : 4u;
+    }();
+    return n;
+}
 
 // pageable host memory -> device through the pinned bounce buffers
 static int h2d_staged(gft_engine* e, void* dst, const void* src, size_t bytes) {
@@ -1512,6 +1551,7 @@ static int h2d_staged(gft_engine* e, void* dst, const void* src, size_t bytes) {
         HIP_TRY(hipEventSynchronize(e->pin_ev[k]), "staging");        // the copy out of this buffer has finished
         const uint8_t* s0 = (const uint8_t*)src + done;
         uint8_t* d0 = (uint8_t*)e->pin[k];
+        const unsigned kPinThreads = pin_threads();
         const size_t part = (n + kPinThreads - 1) / kPinThreads;
         {
             std::vector<std::thread> th;
@@ -1524,6 +1564,48 @@ static int h2d_staged(gft_engine* e, void* dst, const void* src, size_t bytes) {
         HIP_TRY(hipMemcpyAsync((uint8_t*)dst + done, e->pin[k], n, hipMemcpyHostToDevice, e->stream), "upload");
         HIP_TRY(hipEventRecord(e->pin_ev[k], e->stream), "staging");
         done += n;
+    }
+    return GFT_OK;
+}
+
+// device -> pageable host memory through the same bounce buffers (a copy straight into pageable memory is staged by the
+// runtime through one thread); synchronous: returns when dst holds the bytes
+static int d2h_staged(gft_engine* e, void* dst, const void* src, size_t bytes) {
+    if (bytes < (8u << 20)) {
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, e->stream), "download");
+        HIP_TRY(hipStreamSynchronize(e->stream), "download");
+        return GFT_OK;
+    }
+    for (int k = 0; k < 2; k++) {
+        if (!e->pin[k]) HIP_TRY(hipHostMalloc(&e->pin[k], kPinChunk, hipHostMallocDefault), "pinned alloc");
+        if (!e->pin_ev[k]) HIP_TRY(hipEventCreateWithFlags(&e->pin_ev[k], hipEventDisableTiming), "event");
+    }
+    const unsigned nt = pin_threads();
+    size_t issued = 0, done = 0;
+    size_t len[2] = {0, 0};
+    int ki = 0, kd = 0;
+    // chunk i + 1 is on the wire while chunk i is copied out of its buffer
+    while (done < bytes) {
+        while (issued < bytes && len[ki] == 0) {                  // (a buffer is free again once it has been copied out)
+            const size_t n = std::min(kPinChunk, bytes - issued);
+            HIP_TRY(hipMemcpyAsync(e->pin[ki], (const uint8_t*)src + issued, n, hipMemcpyDeviceToHost, e->stream), "download");
+            HIP_TRY(hipEventRecord(e->pin_ev[ki], e->stream), "staging");
+            len[ki] = n; issued += n; ki ^= 1;
+        }
+        HIP_TRY(hipEventSynchronize(e->pin_ev[kd]), "staging");
+        const size_t n = len[kd];
+        const uint8_t* s0 = (const uint8_t*)e->pin[kd];
+        uint8_t* d0 = (uint8_t*)dst + done;
+        const size_t part = (n + nt - 1) / nt;
+        {
+            std::vector<std::thread> th;
+            th.reserve(nt);
+            JoinAll joined(th);
+            for (unsigned t = 1; t < nt; t++)
+                th.emplace_back([=]() noexcept { const size_t a = std::min(n, t * part), b = std::min(n, (t + 1) * part); if (b > a) memcpy(d0 + a, s0 + a, b - a); });
+            memcpy(d0, s0, std::min(n, part));
+        }
+        len[kd] = 0; done += n; kd ^= 1;
     }
     return GFT_OK;
 }
@@ -1552,6 +1634,10 @@ int gft_scan(gft_engine* e, const uint8_t* text_blob, const uint64_t* doc_off, u
     rc = scan_pipeline(e, e->d_text.as<uint8_t>(), e->d_doc_off.as<uint64_t>(), n_docs, flags, true, &nm, doc_off);
     if (rc) return rc;
     if ((flags & GFT_SCAN_UNIQUE) && (rc = unique_pipeline(e, n_docs, &nm))) return rc;
+    if ((flags & GFT_POS_RUNES) && !(flags & GFT_SCAN_UNIQUE)) {
+        if (e->build_flags & GFT_POS_END) return fail(e, GFT_E_UNSUPPORTED, "GFT_POS_RUNES needs a GFT_POS_START engine (AnknownEngine reports where a match begins)");
+        if ((rc = rune_pipeline(e, e->d_text.as<uint8_t>(), e->d_doc_off.as<uint64_t>(), n_docs, nm))) return rc;
+    }
     if ((rc = refine_nonascii(e, e->d_text.as<uint8_t>(), flags))) return rc;
     e->h_match_off.assign(n_docs + 1, 0);
     e->h_term.assign(nm, 0);
@@ -1855,7 +1941,7 @@ int gft_process(gft_engine* e, const uint8_t* text_blob, const uint64_t* doc_off
     if ((rc = refine_nonascii(e, e->d_text.as<uint8_t>(), flags))) return rc;
     if (n_docs * words) {
         if (!hit_bitmap) return fail(e, GFT_E_INVALID, "null bitmap");
-        HIP_TRY(hipMemcpyAsync(hit_bitmap, e->d_bitmap.p, n_docs * words * 4, hipMemcpyDeviceToHost, e->stream), "download");
+        if ((rc = d2h_staged(e, hit_bitmap, e->d_bitmap.p, n_docs * words * 4))) return rc;
     }
     HIP_TRY(hipStreamSynchronize(e->stream), "process pipeline");
     return host_eval(e, pdx ? extra : nullptr, n_docs, plan, hit_bitmap, nullptr);

@@ -536,6 +536,68 @@ __global__ void __launch_bounds__(256) k_fold_safe(const uint8_t* __restrict__ t
     if (__any(bad) && (threadIdx.x & 63u) == 0) atomicOr(flag, 2u);
 }
 
+// ---- rune offsets (GFT_POS_RUNES): AnknownEngine reports Position over []rune(text) (finder/substringEngine.go:44-53) ----
+// A byte starts a rune of Go's decoder (range over a string: utf8.DecodeRuneInString, an invalid byte is one U+FFFD of
+// width 1) unless it is a continuation byte that a VALID multi-byte sequence up to three bytes in front of it covers; a
+// lead byte is never inside another sequence, so the rule is local.  Rune index of byte p = rune starts in [0, p).
+constexpr uint32_t kRuneBlock = 64;         // bytes per counted block (a document's blocks count from its first byte)
+// length of the valid UTF-8 sequence that starts at t[j] (1 for ASCII, and for anything Go decodes as a width-1 error);
+// end = the document's end
+__device__ __forceinline__ uint32_t utf8_valid_len(const uint8_t* __restrict__ t, uint64_t j, uint64_t end) {
+    const uint32_t b0 = t[j];
+    if (b0 < 0xC2u || b0 > 0xF4u) return 1;
+    const uint32_t n = b0 < 0xE0u ? 2u : b0 < 0xF0u ? 3u : 4u;
+    if (j + n > end) return 1;
+    const uint32_t b1 = t[j + 1];
+    const uint32_t lo = b0 == 0xE0u ? 0xA0u : b0 == 0xF0u ? 0x90u : 0x80u, hi = b0 == 0xEDu ? 0x9Fu : b0 == 0xF4u ? 0x8Fu : 0xBFu;   // (utf8.acceptRanges)
+    if (b1 < lo || b1 > hi) return 1;
+    for (uint32_t k = 2; k < n; k++)
+        if ((t[j + k] & 0xC0u) != 0x80u) return 1;
+    return n;
+}
+__device__ __forceinline__ bool rune_start(const uint8_t* __restrict__ t, uint64_t beg, uint64_t end, uint64_t i) {
+    if ((t[i] & 0xC0u) != 0x80u) return true;
+    for (uint32_t k = 1; k <= 3 && i >= beg + k; k++) {
+        const uint64_t j = i - k;
+        if ((t[j] & 0xC0u) != 0x80u) return utf8_valid_len(t, j, end) <= k;      // the only byte that could lead a sequence over i
+    }
+    return true;
+}
+__global__ void __launch_bounds__(256) k_rune_doc_blocks(const uint64_t* __restrict__ doc_off, uint64_t n_docs, uint32_t* __restrict__ cnt) {
+    const uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d < n_docs) cnt[d] = (uint32_t)((doc_off[d + 1] - doc_off[d] + kRuneBlock - 1) / kRuneBlock);
+}
+// one thread per block of kRuneBlock bytes: the rune starts in it.  blk_base[d] = first block of document d
+__global__ void __launch_bounds__(256) k_rune_block_starts(const uint8_t* __restrict__ text, const uint64_t* __restrict__ doc_off,
+                                                           const uint64_t* __restrict__ blk_base, uint64_t n_docs, uint64_t n_blocks,
+                                                           uint32_t* __restrict__ starts) {
+    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_blocks) return;
+    uint64_t lo = 0, hi = n_docs;                       // the document of block b: last d with blk_base[d] <= b
+    while (hi - lo > 1) { const uint64_t mid = (lo + hi) / 2; if (blk_base[mid] <= b) lo = mid; else hi = mid; }
+    const uint64_t beg = doc_off[lo], end = doc_off[lo + 1];
+    const uint64_t a = beg + (b - blk_base[lo]) * kRuneBlock, z = a + kRuneBlock < end ? a + kRuneBlock : end;
+    uint32_t c = 0;
+    for (uint64_t i = a; i < z; i++) c += rune_start(text, beg, end, i) ? 1u : 0u;
+    starts[b] = c;
+}
+// one thread per match: byte offset -> rune offset
+__global__ void __launch_bounds__(256) k_pos_to_rune(const uint8_t* __restrict__ text, const uint64_t* __restrict__ doc_off,
+                                                     const uint64_t* __restrict__ blk_base, const uint64_t* __restrict__ blk_prefix,
+                                                     const uint64_t* __restrict__ match_off, uint64_t n_docs, uint64_t n_matches,
+                                                     uint32_t* __restrict__ pos) {
+    const uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n_matches) return;
+    uint64_t lo = 0, hi = n_docs;                       // the document of match m: last d with match_off[d] <= m
+    while (hi - lo > 1) { const uint64_t mid = (lo + hi) / 2; if (match_off[mid] <= m) lo = mid; else hi = mid; }
+    const uint64_t beg = doc_off[lo], end = doc_off[lo + 1];
+    const uint32_t p = pos[m];
+    const uint64_t g = p / kRuneBlock;
+    uint64_t r = blk_prefix[blk_base[lo] + g] - blk_prefix[blk_base[lo]];
+    for (uint64_t i = beg + g * kRuneBlock; i < beg + p; i++) r += rune_start(text, beg, end, i) ? 1u : 0u;
+    pos[m] = (uint32_t)r;
+}
+
 inline unsigned grid_for(uint64_t n, unsigned per_block, unsigned cap) {
     uint64_t g = (n + per_block - 1) / per_block;
     if (g < 1) g = 1;
@@ -638,6 +700,25 @@ hipError_t launch_fold_safe(const uint8_t* d_text, uint64_t lo, uint64_t hi, uin
     const uint64_t a0 = ((uint64_t)(uintptr_t)d_text + lo) & ~(uint64_t)15, a1 = (uint64_t)(uintptr_t)d_text + hi;
     const uint64_t n = (a1 - a0 + 15) / 16;
     k_fold_safe<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(d_text, lo, hi, d_flag);
+    return hipGetLastError();
+}
+
+hipError_t launch_rune_doc_blocks(const uint64_t* d_doc_off, uint64_t n_docs, uint32_t* d_cnt, hipStream_t st) {
+    if (!n_docs) return hipSuccess;
+    k_rune_doc_blocks<<<dim3((unsigned)((n_docs + 255) / 256)), dim3(256), 0, st>>>(d_doc_off, n_docs, d_cnt);
+    return hipGetLastError();
+}
+hipError_t launch_rune_block_starts(const uint8_t* d_text, const uint64_t* d_doc_off, const uint64_t* d_blk_base, uint64_t n_docs,
+                                    uint64_t n_blocks, uint32_t* d_starts, hipStream_t st) {
+    if (!n_blocks) return hipSuccess;
+    k_rune_block_starts<<<dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, st>>>(d_text, d_doc_off, d_blk_base, n_docs, n_blocks, d_starts);
+    return hipGetLastError();
+}
+hipError_t launch_pos_to_rune(const uint8_t* d_text, const uint64_t* d_doc_off, const uint64_t* d_blk_base, const uint64_t* d_blk_prefix,
+                              const uint64_t* d_match_off, uint64_t n_docs, uint64_t n_matches, uint32_t* d_pos, hipStream_t st) {
+    if (!n_matches) return hipSuccess;
+    k_pos_to_rune<<<dim3((unsigned)((n_matches + 255) / 256)), dim3(256), 0, st>>>(d_text, d_doc_off, d_blk_base, d_blk_prefix, d_match_off, n_docs,
+                                                                                  n_matches, d_pos);
     return hipGetLastError();
 }
 

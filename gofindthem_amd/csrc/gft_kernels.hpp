@@ -378,6 +378,12 @@ hipError_t launch_fold_safe(const uint8_t* d_text, uint64_t lo, uint64_t hi, uin
 hipError_t launch_unique_terms(bool write, const uint64_t* d_match_off, const uint32_t* d_term, uint64_t n_docs, uint32_t n_terms,
                                uint32_t* d_first, unsigned grid, uint32_t* d_cnt, const uint64_t* d_out_off, uint32_t* d_out_term,
                                hipStream_t st);
+// GFT_POS_RUNES: byte offsets of a CSR result -> offsets over []rune(text) (finder/substringEngine.go:44-53)
+hipError_t launch_rune_doc_blocks(const uint64_t* d_doc_off, uint64_t n_docs, uint32_t* d_cnt, hipStream_t st);
+hipError_t launch_rune_block_starts(const uint8_t* d_text, const uint64_t* d_doc_off, const uint64_t* d_blk_base, uint64_t n_docs,
+                                    uint64_t n_blocks, uint32_t* d_starts, hipStream_t st);
+hipError_t launch_pos_to_rune(const uint8_t* d_text, const uint64_t* d_doc_off, const uint64_t* d_blk_base, const uint64_t* d_blk_prefix,
+                              const uint64_t* d_match_off, uint64_t n_docs, uint64_t n_matches, uint32_t* d_pos, hipStream_t st);
 size_t solve_lds_bytes(uint32_t n_slots, uint32_t tile_words, uint32_t group_docs, bool p_in_lds, uint32_t prog_words,
                        uint32_t n_exprs, bool prog_in_lds);
 // group_docs: documents per group (64, 32, 16 or 8 = bits per presence-matrix element)

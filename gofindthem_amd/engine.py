@@ -107,12 +107,12 @@ class Engine:
         return int(self._L.gft_term_id(self._h, b, len(b)))
 
     # -- SubstringEngine.FindSubstrings, batched ------------------------------------------------------
-    def scan(self, blob, doc_off, fold=False, unique=False):
+    def scan(self, blob, doc_off, fold=False, unique=False, runes=False):
         """host numpy in -> CSR numpy out (match_off u64, term_id u32, pos u32).  unique=True: CloudflareEngine's output
         (GFT_SCAN_UNIQUE: every term once per document, first-occurrence order, positions 0)"""
         m = GftMatches()
         n_docs = len(doc_off) - 1
-        self._check(self._L.gft_scan(self._h, _p(blob), _p(doc_off), n_docs, (1 if fold else 0) | (2 if unique else 0), C.byref(m)))
+        self._check(self._L.gft_scan(self._h, _p(blob), _p(doc_off), n_docs, (1 if fold else 0) | (2 if unique else 0) | (4 if runes else 0), C.byref(m)))
         nm = int(m.n_matches)
         mo = np.ctypeslib.as_array(C.cast(m.match_off, C.POINTER(C.c_uint64)), shape=(n_docs + 1,)).copy()
         if nm == 0:

@@ -59,6 +59,11 @@ typedef enum gft_status {
                             * (finder/substringEngine.go:77-86): every term that occurs in a document once, in the order
                             * of its first occurrence, every pos 0 -- enough for expressions without INORD */
 
+#define GFT_POS_RUNES 4u   /* gft_scan / gft_scan_device: AnknownEngine's positions (finder/substringEngine.go:44-53 searches
+                            * []rune(text) and reports m.Pos): every pos is the number of RUNES in front of the match instead of
+                            * the number of bytes, under Go's decoder (an invalid byte is one U+FFFD of width 1).  The match SET
+                            * is the byte-level one; GFT_POS_START engines only; ignored together with GFT_SCAN_UNIQUE (pos 0) */
+
 typedef struct gft_engine gft_engine;
 
 /* ---- lifetime ------------------------------------------------------------------------------------- */

@@ -520,3 +520,32 @@ def test_inord_chains_of_the_reference_benchmarks(k):
     assert int(want[1, 0]) & 1 == 1 and int(want[3, 0]) & 1 == 0          # in order on the planted document, cut short on its half
     one = f.ProcessText(planted_doc)
     assert [r.ExpresionIndex for r in one] == [i for i in range(len(exprs)) if int(want[1, 0]) >> i & 1]
+
+
+def test_large_host_batch_folds_on_the_device_and_comes_back_when_it_cannot():
+    """Finder.ProcessTexts on a batch of 16 MB or more does not scan the text for high bytes on the host first: it is
+    uploaded as it is and folded by the scan kernels; only when they report text that ASCII folding does not lower-case the
+    way strings.ToLower does (finder/finder.go:140-142) the batch is repeated through the host's ToLower.  Both ways must
+    give the reference's rows."""
+    from gofindthem_amd.workload import Workload, make_expressions
+    w = Workload(400)
+    terms = w.terms()
+    exprs = make_expressions(terms, 40, inord_fraction=0.3, cover=True) + ['"\u00e9cole"', '"ecole"']
+    f = Finder(GpuEngine(), EmptyRgxEngine(), False)
+    f.AddExpressions(exprs)
+    o = Oracle(sorted(k.encode("utf-8") for k in f.GetKeywords()))
+    o.set_expressions(exprs, False)
+    text, off = w.docs_host(0, 4300)
+    assert int(off[-1]) >= 16 << 20
+    docs = [bytes(text[int(off[d]):int(off[d + 1])]).decode().upper() if d % 7 == 0 else bytes(text[int(off[d]):int(off[d + 1])]).decode()
+            for d in range(4300)]
+    lb, lo = pack_strings(docs)
+    assert np.array_equal(f.ProcessTexts(docs), o.process(lb, lo, fold=True))          # ASCII: one pass, folded on the device
+    docs[2999] = "\u00c9COLE normale " + docs[2999]                                        # an upper-case E-acute: ToLower's business
+    docs[17] = "une \u00e9cole " + docs[17]                                                # lower-case: safe either way
+    low = [d.lower() for d in docs]
+    lb, lo = pack_strings(low)
+    want = o.process(lb, lo, fold=False)
+    got = f.ProcessTexts(docs)
+    assert np.array_equal(got, want)
+    assert want[2999, 41 >> 5] >> (40 & 31) & 1 and want[17, 40 >> 5] >> (40 & 31) & 1   # "\u00e9cole" is found in both

@@ -451,6 +451,46 @@ def test_unique_terms_mode_is_the_cloudflare_engine_output(eng):
     assert int(m.n_matches) == int(mo[-1])
 
 
+def test_rune_offsets_are_the_anknown_engine_positions(eng):
+    """GFT_POS_RUNES = AnknownEngine.FindSubstrings (finder/substringEngine.go:44-53): MultiPatternSearch([]rune(text)) reports
+    Position over runes.  Expected: the oracle's byte offsets mapped through Go's string -> []rune decoding
+    (oracle/runes_ref.py: multi-byte runes count once, every invalid byte is one U+FFFD)."""
+    from oracle.runes_ref import rune_index_table
+    terms = ["lo", "w\u00f6rld", "\u20acuro", "x", "\U0001d11e", "\u00e9", "rld"]
+    o = both(eng, sorted(t.encode("utf-8") for t in terms))
+    texts = ["h\u00e9llo w\u00f6rld \u20acuro \U0001d11e x lo", "", "x",
+             b"\x80x\xc3 lo \xe2\x82 x \xed\xa0\x80lo \xf5x \xc0\x80 x\xf0\x9f lo".decode("latin-1"),     # invalid sequences of every kind
+             ("\u00e9" * 40 + "x") * 30, "\U0001d11e" * 100 + "lo"]
+    raw = [t.encode("latin-1") if i == 3 else t.encode("utf-8") for i, t in enumerate(texts)]
+    blob = np.frombuffer(b"".join(raw), dtype=np.uint8)
+    off = np.zeros(len(raw) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(r) for r in raw])
+    wo, wt, wp = o.scan(blob, off)
+    want = wp.copy()
+    for d, r in enumerate(raw):
+        tab = rune_index_table(r)
+        for m in range(int(wo[d]), int(wo[d + 1])):
+            want[m] = tab[int(wp[m])]
+    mo, ti, po = eng.scan(blob, off, runes=True)
+    assert np.array_equal(mo, wo) and np.array_equal(ti, wt)
+    assert np.array_equal(po, want), (po[po != want][:8], want[po != want][:8])
+    assert (want != wp).any()                                        # (the mapping did something)
+    # a longer document: more than one counted block per document, blocks that end inside a rune
+    from gofindthem_amd.workload import Workload
+    w = Workload(300, alphabet="mixed")
+    kws = sorted({t.decode("utf-8").lower().encode("utf-8") for t in w.terms()})
+    o = both(eng, kws)
+    text, toff = w.docs_host(0, 40)
+    wo, wt, wp = o.scan(text, toff)
+    want = wp.copy()
+    for d in range(40):
+        tab = rune_index_table(bytes(text[int(toff[d]):int(toff[d + 1])]))
+        for m in range(int(wo[d]), int(wo[d + 1])):
+            want[m] = tab[int(wp[m])]
+    mo, ti, po = eng.scan(text, toff, runes=True)
+    assert np.array_equal(po, want) and np.array_equal(ti, wt)
+
+
 def test_mixed_alphabet_workload(eng, scan_kernel):
     """a real word list's shape (benchmarks/benchmark_test.go:72-83): capitals, digits, punctuation, two-byte UTF-8
     letters -- more than 48 byte classes after folding, 2- and 3-byte terms included.  The round-1 kernel refuses such a

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -1921,8 +1922,18 @@ int gft_process(gft_engine* e, const uint8_t* text_blob, const uint64_t* doc_off
     if (!e->have_programs) return fail(e, GFT_E_NOT_BUILT, "gft_set_programs has not been called");
     DeviceGuard g(e->device);
     SyncOnExit drained(e);      // host buffers are read by asynchronous copies: drained on every way out
+    // GFT_HOST_TIMING=1: where a call from host memory spends its time (stderr; tools/bench_latency.py)
+    static const bool timing = getenv("GFT_HOST_TIMING") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [&](const char* what) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(e->stream);
+        fprintf(stderr, "[gft host timing] %s: %.2f ms since the call began\n", what,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+    };
     int rc = stage_docs(e, text_blob, doc_off, n_docs);
     if (rc) return rc;
+    since("text and offsets uploaded");
     gft_extra_matches dx;
     const gft_extra_matches* pdx = nullptr;
     rc = upload_extra(e, extra, n_docs, dx, pdx);
@@ -1939,11 +1950,13 @@ int gft_process(gft_engine* e, const uint8_t* text_blob, const uint64_t* doc_off
     rc = solve_pipeline(e, n_docs, pdx, e->d_bitmap.as<uint32_t>());
     if (rc) return rc;
     if ((rc = refine_nonascii(e, e->d_text.as<uint8_t>(), flags))) return rc;
+    since("scanned and solved");
     if (n_docs * words) {
         if (!hit_bitmap) return fail(e, GFT_E_INVALID, "null bitmap");
         if ((rc = d2h_staged(e, hit_bitmap, e->d_bitmap.p, n_docs * words * 4))) return rc;
     }
     HIP_TRY(hipStreamSynchronize(e->stream), "process pipeline");
+    since("bitmap downloaded");
     return host_eval(e, pdx ? extra : nullptr, n_docs, plan, hit_bitmap, nullptr);
 } GFT_CATCH((e ? &e->err : nullptr))
 

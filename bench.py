@@ -225,16 +225,18 @@ def main():
         alg_bytes = text_bytes + 8 * args.docs + per_match * n_matches
         scan_avg_ms = scan_ms / max(scan_n, 1)
         achieved = alg_bytes / (scan_avg_ms * 1e-3) / 1e9 if scan_n else 0.0
-        # HBM traffic of the scan kernel from rocprofv3 PMC passes (profiles/r2_pmc_traffic.json; it cannot be
+        # HBM traffic of the scan kernel from rocprofv3 PMC passes (profiles/r3_pmc_traffic.json; it cannot be
         # collected from inside this process) -- only attached when this run uses the profiled configuration
         traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")) as fh:
-                pmc = json.load(fh)
-            if args.alphabet == "lower" and pmc["config"] == {"docs": args.docs, "terms": args.terms, "exprs": args.exprs, "inord": args.inord}:
-                traffic = next(v["traffic_bytes"] for k, v in pmc["kernels"].items() if k.startswith("k_scan2"))
-        except (OSError, KeyError, ValueError):
-            pass
+        for name in ("r3_pmc_traffic.json", "r3_scan4_pmc_traffic.json", "r2_pmc_traffic.json"):   # (the newest set that has this kernel)
+            try:
+                with open(os.path.join(ROOT, "profiles", name)) as fh:
+                    pmc = json.load(fh)
+                if args.alphabet == "lower" and pmc["config"] == {"docs": args.docs, "terms": args.terms, "exprs": args.exprs, "inord": args.inord}:
+                    traffic = next(v["traffic_bytes"] for k, v in pmc["kernels"].items() if k.startswith("k_" + scan_kernel))
+                    break
+            except (OSError, KeyError, ValueError, StopIteration):
+                pass
         out = {
             "metric": "ProcessText throughput: documents/s (and input GB/s), %d-term dictionary + %d expressions, "
                       "%d docs of ~4 KB %s" % (args.terms, args.exprs, total_docs if args.scaling == "strong" else args.docs,

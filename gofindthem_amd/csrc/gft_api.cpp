@@ -104,6 +104,7 @@ struct gft_engine {
     uint32_t opt_scan_dbg = 0;                          // GFT_SCAN_DEBUG (timing studies)
     uint32_t opt_scan_prio = 1;                         // graded wave priorities in the scan kernels (GFT_SCAN_PRIO=0: off)
     uint32_t opt_scan_ordered = 0;                      // GFT_SCAN_ORDERED=1: scan2's per-lane staging path for every unit
+    uint32_t opt_scan4_chunk = 0;                       // GFT_SCAN4_CHUNK: units per chunk of the streaming kernel (0: by batch size)
     uint32_t opt_solve_dbg = 0;                         // GFT_SOLVE_DEBUG (timing studies)
     int opt_solve_group = -1;                           // GFT_SOLVE_GROUP_DOCS: forced group width (-1: the widest that fits)
     // one caller at a time per handle: every entry point that touches the device state takes this
@@ -173,6 +174,7 @@ void refresh_options(gft_engine* e) {
     e->opt_scan_dbg = (uint32_t)num("GFT_SCAN_DEBUG", 0);
     e->opt_scan_prio = num("GFT_SCAN_PRIO", 1) ? 1u : 0u;
     e->opt_scan_ordered = getenv("GFT_SCAN_ORDERED") ? 1u : 0u;
+    e->opt_scan4_chunk = (uint32_t)num("GFT_SCAN4_CHUNK", 0);
     e->opt_solve_dbg = (uint32_t)num("GFT_SOLVE_DEBUG", 0);
     e->opt_solve_group = (int)num("GFT_SOLVE_GROUP_DOCS", -1);
 }
@@ -687,6 +689,7 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
             // chunks), a fifo in place of the candidate list, per-unit regions sized from the density seen so far
             const uint64_t n_waves4 = (uint64_t)e->n_cus * e->scan4_waves;
             P.chunk_units = (uint32_t)std::min<uint64_t>(kScan4ChunkUnits, std::max<uint64_t>(1, n_docs / (n_waves4 * 4)));
+            if (e->opt_scan4_chunk) P.chunk_units = std::min<uint32_t>(e->opt_scan4_chunk, kScan4ChunkUnits);      // (GFT_SCAN4_CHUNK: tests)
             P.cand_cap = e->scan4_fifo[P.want_pos ? 1 : 0];
             P.bound_q16 = (uint32_t)std::min<double>(e->scan4_density * 1.6 * 65536.0 + 1.0, 4.0e9);
             P.bound_add = 48;

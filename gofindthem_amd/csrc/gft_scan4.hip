@@ -48,7 +48,7 @@ __host__ __device__ constexpr uint32_t s4_qb_cap(bool want_pos) { return want_po
 // mod 2^32: only differences are used), the document's length, the unit's end, -, its region's size, its region's offset in
 // the chunk's part of the slab, its matches so far, -}: what a verification stage needs of a unit is one 16-byte read, what the
 // flush needs another -- and the wave's list of units to walk again
-constexpr uint32_t kS4Redo = 8;
+constexpr uint32_t kS4Redo = kScan4ChunkUnits;
 constexpr uint32_t kS4MetaWords = 8 * kScan4ChunkUnits + 2 * kS4Redo;
 typedef __attribute__((address_space(3))) uint32_t lds32;
 typedef __attribute__((address_space(3))) uint16_t lds16;
@@ -162,11 +162,11 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan4(const Scan2Params P) {
     if (ch < n_chunks) { fetch_units(ch, un_n); fetch_docs(ch, un_n, dabs_n, dlen_n); }
     uint32_t n_redo = 0;                         // units waiting to be walked again (their matches outgrew their regions)
 
-    // Work items: the wave's chunks, and -- when its list is full, or the chunks are done -- the units to walk again, alone,
-    // with a region of the size the first walk counted
+    // Work items: the wave's chunks, and behind a chunk the units of it that have to be walked again, alone, with a region of
+    // the size the first walk counted
     for (;;) {
         const bool chunks_left = ch < n_chunks;
-        const bool is_redo = n_redo == kS4Redo || (!chunks_left && n_redo);
+        const bool is_redo = n_redo != 0;        // (a chunk adds up to kScan4ChunkUnits = kS4Redo entries: the list is emptied before the next one)
         if (!chunks_left && !is_redo) break;
         Unit un;
         uint64_t dabs;

@@ -451,6 +451,35 @@ def test_unique_terms_mode_is_the_cloudflare_engine_output(eng):
     assert int(m.n_matches) == int(mo[-1])
 
 
+def test_streaming_kernel_chunks_of_eight_units_and_regions_that_overflow(monkeypatch):
+    """gft_scan4 on small batches takes one unit per chunk; GFT_SCAN4_CHUNK=8 forces the production shape (eight units per
+    chunk: documents that share a stream, slices of long documents, empty documents in between).  A fresh engine sizes a unit's
+    region of the match pool for 0.06 matches per byte: a dictionary that matches at every position overflows ALL eight
+    regions of every chunk -- each unit is then walked again on its own (the list of such units holds one chunk's worth)."""
+    from gofindthem_amd.engine import Engine
+    monkeypatch.setenv("GFT_SCAN_KERNEL", "scan4")
+    monkeypatch.setenv("GFT_SCAN4_CHUNK", "8")
+    rng = np.random.default_rng(5)
+    e = Engine()
+    try:
+        terms = [b"a", b"b", b"ab", b"ba", b"aab", b"abab", b"bbbb", b"abba", b"aaaaa", b"babab"]
+        e.build(terms)
+        o = Oracle(terms)
+        lens = [5000, 0, 3, 4100, 70000, 1, 0, 0, 4096, 4097, 8176, 8177, 20000, 2, 300] * 3
+        texts = [bytes(b"ab"[i] for i in rng.integers(0, 2, n)) for n in lens]
+        blob, off = docs(texts)
+        for _ in range(2):                                   # (second call: the regions follow the density the first one saw)
+            assert_csr_equal(e.scan(blob, off), o.scan(blob, off))
+        from gofindthem_amd.workload import Workload
+        w = Workload(3000)
+        o = Oracle(w.terms())
+        e.build(w.terms())
+        text, toff = w.docs_host(0, 300)
+        assert_csr_equal(e.scan(text, toff, fold=True), o.scan(text, toff, fold=True))
+    finally:
+        e.close()
+
+
 def test_rune_offsets_are_the_anknown_engine_positions(eng):
     """GFT_POS_RUNES = AnknownEngine.FindSubstrings (finder/substringEngine.go:44-53): MultiPatternSearch([]rune(text)) reports
     Position over runes.  Expected: the oracle's byte offsets mapped through Go's string -> []rune decoding

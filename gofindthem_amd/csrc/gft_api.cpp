@@ -104,6 +104,7 @@ struct gft_engine {
     uint32_t opt_scan_dbg = 0;                          // GFT_SCAN_DEBUG (timing studies)
     uint32_t opt_scan_prio = 1;                         // graded wave priorities in the scan kernels (GFT_SCAN_PRIO=0: off)
     uint32_t opt_scan_ordered = 0;                      // GFT_SCAN_ORDERED=1: scan2's per-lane staging path for every unit
+    uint32_t opt_scan4_round = 0;                       // GFT_SCAN4_ROUND: bytes per lane and round of the streaming kernel (0: 64)
     uint32_t opt_scan4_chunk = 0;                       // GFT_SCAN4_CHUNK: units per chunk of the streaming kernel (0: by batch size)
     uint32_t opt_solve_dbg = 0;                         // GFT_SOLVE_DEBUG (timing studies)
     int opt_solve_group = -1;                           // GFT_SOLVE_GROUP_DOCS: forced group width (-1: the widest that fits)
@@ -175,6 +176,7 @@ void refresh_options(gft_engine* e) {
     e->opt_scan_prio = num("GFT_SCAN_PRIO", 1) ? 1u : 0u;
     e->opt_scan_ordered = getenv("GFT_SCAN_ORDERED") ? 1u : 0u;
     e->opt_scan4_chunk = (uint32_t)num("GFT_SCAN4_CHUNK", 0);
+    e->opt_scan4_round = (uint32_t)num("GFT_SCAN4_ROUND", 0);
     e->opt_solve_dbg = (uint32_t)num("GFT_SOLVE_DEBUG", 0);
     e->opt_solve_group = (int)num("GFT_SOLVE_GROUP_DOCS", -1);
 }
@@ -693,6 +695,7 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
             P.cand_cap = e->scan4_fifo[P.want_pos ? 1 : 0];
             P.bound_q16 = (uint32_t)std::min<double>(e->scan4_density * 1.6 * 65536.0 + 1.0, 4.0e9);
             P.bound_add = 48;
+            P.round_c = e->opt_scan4_round ? std::min<uint32_t>(64, std::max<uint32_t>(16, e->opt_scan4_round & ~15u)) : 64;   // (GFT_SCAN4_ROUND: timing studies)
             // a slab should hold a few chunks' regions (the rest of a slab that the next chunk does not fit is lost)
             const uint64_t chunk_need = (uint64_t)P.chunk_units * (((uint64_t)unit_max * P.bound_q16 >> 16) + P.bound_add);
             P.slab = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(kScan2Slab, 4 * chunk_need), std::max<uint64_t>(chunk_need, e->pool_cap / (2 * n_waves4)));

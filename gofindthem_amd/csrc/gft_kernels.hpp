@@ -270,6 +270,7 @@ struct Scan2Params {
     // gft_scan4.hip (the streaming form) only:
     uint32_t chunk_units;        // units a wave streams through in one go (1 .. kScan4ChunkUnits)
     uint32_t bound_q16, bound_add;   // a unit's region of the match pool: bytes * bound_q16 / 65536 + bound_add entries
+    uint32_t round_c;            // bytes per lane and round (16, 32, 48 or 64): a round is 64 x round_c bytes of the stream
 };
 // waves per workgroup (16, 12, 8 or 4) and candidate-list capacity that fit lds_max; false if nothing fits
 bool scan2_plan(uint32_t filter_words, uint32_t short3_bytes, uint32_t shorts_words, uint32_t fpt_lds_bytes, size_t lds_max,

@@ -302,7 +302,8 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan4(const Scan2Params P) {
             // once, and the piece that pays it -- the next round's first -- is requested as the YOUNGEST load of the wave, while
             // the last piece of this round is filtered and its flagged positions are queued, work that needs no memory
             // (vector-memory results return in order: whatever is requested behind a load from HBM waits for it).
-            auto round_c = [&](uint32_t rem) { const uint32_t per = (rem + 63) >> 6; return per >= 64 ? 64u : per <= 16 ? 16u : (per + 15) & ~15u; };
+            const uint32_t c_max = P.round_c;                                        // bytes per lane and round: 16 .. 64
+            auto round_c = [&](uint32_t rem) { const uint32_t per = (rem + 63) >> 6; return per >= c_max ? c_max : per <= 16 ? 16u : (per + 15) & ~15u; };
             uint32_t rb = 0;                                                         // the round being filtered: first byte,
             uint32_t C = round_c(len), q = 0;                                        // bytes per lane, the next piece
             bool have_round = len > 0;

@@ -1,14 +1,20 @@
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/tq; rm -rf $O; mkdir -p $O
-B="python3 bench.py --steps 5 --warmup 2 --cpu-docs 0"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/f -o runc --output-format csv -- $B > $O/f.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/w -o runc --output-format csv -- $B > $O/w.log 2>&1
-python3 tools/pmc_summary.py $O/f $O/w $O/traffic.json --docs 1000000 > $O/s.log 2>&1
-python3 - <<'PY'
-import json
-p=json.load(open("gpurun_out/tq/traffic.json"))
-for k,v in p["kernels"].items():
-    if k.startswith("k_scan2"): print(k, v)
+#!/bin/bash
+# FETCH_SIZE of the scan kernel for the current environment (GFT_SCAN_KERNEL, GFT_SCAN4_ROUND ...), bytes per launch (x2 corrected)
+cd /tmp && export TMPDIR=/tmp
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+O=gpurun_out/tq_$$
+rm -rf $O && mkdir -p $O
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/f -o runc --output-format csv -- python3 bench.py --steps 3 --warmup 1 --cpu-docs 0 > $O/log 2>&1
+python3 - <<PY
+import csv,glob,re
+from collections import defaultdict
+rows=defaultdict(list)
+for p in glob.glob("$O/f/**/*counter_collection.csv",recursive=True):
+    for r in csv.DictReader(open(p)):
+        m=re.search(r"\b(k_scan\d\w*)",r["Kernel_Name"])
+        if m and r["Counter_Name"]=="FETCH_SIZE": rows[m.group(1)].append((int(r["Grid_Size"]),float(r["Counter_Value"])))
+for k,v in rows.items():
+    g=max(x[0] for x in v); vals=[x[1] for x in v if x[0]==g]
+    print(k,"read GB per launch (x2):",round(2*sum(vals)/len(vals)*1024/1e9,2))
 PY
-python3 bench.py --steps 20 --warmup 3 --cpu-docs 0 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['kernels_ms_per_step'])"
-rm -rf $O/f $O/w
+rm -rf $O

@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgft.so")
 ARCH = "gfx950"
 
-HIP_SOURCES = ["gft_kernels.hip", "gft_solve.hip", "gft_scan2.hip", "gft_scan3.hip", "gft_scan4.hip"]
+HIP_SOURCES = ["gft_kernels.hip", "gft_solve.hip", "gft_scan2.hip", "gft_scan3.hip", "gft_scan4.hip", "gft_scan5.hip"]
 CXX_SOURCES = ["gft_api.cpp", "ac_tables.cpp", "scan2_tables.cpp", "scan3_tables.cpp", "dsl_compile.cpp", "finder_host.cpp", "json_mini.cpp", "group_host.cpp", "host_solve.cpp"]
 
 
@@ -31,17 +31,25 @@ def build_lib(force=False, verbose=False):
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "gft.h"))
     if not force and not _newer(LIB, srcs + hdrs):
         return LIB
-    objs = []
+    objs, jobs = [], []
     for s in srcs:
         o = os.path.join(CSRC, os.path.basename(s) + ".o")
         if force or _newer(o, [s] + hdrs):
             cmd = ["hipcc", "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-c", s, "-o", o]
             if s.endswith(".cpp"):
                 cmd[1:1] = ["-x", "hip"]   # host code that includes hip_runtime.h; no kernels inside
-            if verbose:
-                print(" ".join(cmd))
-            subprocess.check_call(cmd)
+            jobs.append(cmd)
         objs.append(o)
+    if jobs:
+        # (a handful of translation units, the kernels take a minute each: compile them side by side)
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
+            list(ex.map(run, jobs))
     cmd = ["hipcc", "-shared", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd))

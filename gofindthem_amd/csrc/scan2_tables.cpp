@@ -261,3 +261,68 @@ void build_scan2_tables(const AcTables& ac, Scan2Tables& t) {
 }
 
 }  // namespace gft
+
+namespace gft {
+
+void scan5_short_sizes(const Scan2Tables& s2, uint32_t* cells, uint32_t* ids) {
+    uint32_t n = 0;
+    for (uint8_t b : s2.short3) n += b != 0;
+    *cells = s2.short3.empty() ? 0u : (uint32_t)((s2.short3.size() + 31) / 32);
+    *ids = n;
+}
+
+void build_scan5_tables(const AcTables& ac, const Scan2Tables& s2, uint32_t G, Scan5Tables& t) {
+    t = Scan5Tables();
+    const uint32_t kp = s2.kp;
+    if (G > kp) G = kp;
+    t.G = G;
+    // class -> group.  Weights: how often a class occurs in the dictionary (the build's only model of the text, as in
+    // pick_off); class 0 is "everything else" -- blanks, punctuation, the bytes of other alphabets -- and frequent in any text.
+    std::vector<uint64_t> cnt(kp, 0);
+    for (const auto& s : ac.terms) for (unsigned char ch : s) cnt[ac.byte_class[ch]]++;
+    std::vector<uint32_t> order(kp);
+    for (uint32_t c = 0; c < kp; c++) order[c] = c;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+        if ((a == 0) != (b == 0)) return a == 0;
+        return cnt[a] > cnt[b];
+    });
+    std::vector<uint32_t> group_of(kp, 0);
+    std::vector<uint64_t> load(G, 0);
+    for (uint32_t i = 0; i < kp; i++) {
+        uint32_t g = i;
+        if (i >= G) {
+            g = 1;                                             // (group 0 is class 0's alone)
+            for (uint32_t k = 1; k < G; k++) if (load[k] < load[g]) g = k;
+        }
+        group_of[order[i]] = g;
+        load[g] += order[i] == 0 ? ~0ull / 4 : cnt[order[i]] + 1;
+    }
+    t.pad_group = group_of[s2.pad_class];
+    for (int b = 0; b < 256; b++) { t.grp[b] = (uint8_t)group_of[s2.cls[b]]; t.grp_fold[b] = (uint8_t)group_of[s2.cls_fold[b]]; }
+    // every window the exact filter flags, in group space
+    const uint64_t bits = (uint64_t)G * G * G * G;
+    t.filter.assign((size_t)((bits + 63) / 64 * 2), 0);
+    const uint64_t kbits = (uint64_t)kp * kp * kp * kp;
+    for (uint64_t key = 0; key < kbits && !s2.hashed; key++) {
+        if (!(s2.filter[key >> 5] >> (key & 31) & 1)) continue;
+        const uint32_t c3 = (uint32_t)(key % kp), c2 = (uint32_t)(key / kp % kp), c1 = (uint32_t)(key / ((uint64_t)kp * kp) % kp),
+                       c0 = (uint32_t)(key / ((uint64_t)kp * kp * kp));
+        const uint64_t gk = (((uint64_t)group_of[c0] * G + group_of[c1]) * G + group_of[c2]) * G + group_of[c3];
+        t.filter[gk >> 5] |= 1u << (gk & 31);
+    }
+    // short terms: bit per exact 3-window, rank -> record id
+    uint32_t cells = 0, n_ids = 0;
+    scan5_short_sizes(s2, &cells, &n_ids);
+    t.cell.assign(cells, 0);
+    t.ids.reserve(n_ids);
+    for (uint32_t cidx = 0; cidx < cells; cidx++) {
+        uint64_t v = (uint64_t)t.ids.size() << 32;
+        for (uint32_t b = 0; b < 32; b++) {
+            const size_t w = (size_t)cidx * 32 + b;
+            if (w < s2.short3.size() && s2.short3[w]) { v |= 1ull << b; t.ids.push_back(s2.short3[w]); }
+        }
+        t.cell[cidx] = v;
+    }
+}
+
+}  // namespace gft

@@ -10,9 +10,9 @@ from oracle.pyoracle import Oracle, POS_END, POS_START
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["scan4", "scan3", "scan2", "scan2-ordered", "dfa"], autouse=True)
+@pytest.fixture(params=["scan5", "scan4", "scan3", "scan2", "scan2-ordered", "dfa"], autouse=True)
 def scan_kernel(request, monkeypatch):
-    """every test runs against the streaming suffix-window kernel (scan4), the stride-2 suffix-window kernel (scan3), the
+    """every test runs against the suffix-window kernel with the unit's text in LDS (scan5), its streaming form (scan4), the stride-2 suffix-window kernel (scan3), the
     round-1 suffix-window kernel (GFT_SCAN_KERNEL=scan2: balanced path, and its in-kernel ordered path with
     GFT_SCAN_ORDERED=1) and the general two-tier DFA kernel (GFT_SCAN_KERNEL=dfa); the variable is read by gft_build"""
     monkeypatch.setenv("GFT_SCAN_KERNEL", request.param.split("-")[0])
@@ -480,6 +480,44 @@ def test_streaming_kernel_chunks_of_eight_units_and_regions_that_overflow(monkey
         e.close()
 
 
+def test_text_in_lds_kernel_rounds_second_walks_and_merged_groups(monkeypatch):
+    """gft_scan5: units of one to five rounds of 1 KiB (documents that end inside a round, on a round, slices of long
+    documents, empty documents, a first document whose positions lie within the buffer's lead of the blob start); a
+    dictionary that matches at every position outgrows the 256-entry fifo in every unit -- each is then walked a second
+    time straight into a pool region of the counted size; GFT_SCAN5_GROUPS=4 merges the byte classes far beyond what LDS
+    asks for (the filter then flags nearly everything: exactness must come from the stages behind it).  Both position
+    conventions, positions packed into the fifo entry next to the term id."""
+    from gofindthem_amd.engine import Engine
+    from gofindthem_amd import _lib
+    monkeypatch.setenv("GFT_SCAN_KERNEL", "scan5")
+    rng = np.random.default_rng(11)
+    e = Engine()
+    try:
+        for groups in (None, "4"):
+            if groups:
+                monkeypatch.setenv("GFT_SCAN5_GROUPS", groups)
+            terms = [b"a", b"b", b"ab", b"ba", b"aab", b"abab", b"bbbb", b"abba", b"aaaaa", b"babab", b"ab" * 20 + b"b"]
+            lens = [5000, 0, 3, 4100, 70000, 1, 0, 0, 1024, 1025, 5120, 5121, 20000, 2, 300, 31, 33, 1023, 2048, 4096] * 2
+            texts = [bytes(b"ab"[i] for i in rng.integers(0, 2, n)) for n in lens]
+            texts[0] = b"abab" + texts[0]
+            blob, off = docs(texts)
+            for pos_mode in (POS_START, POS_END):
+                e.build(terms, pos_end=(pos_mode == POS_END))
+                assert _lib.load().gft_scan_kernel(e._h).decode() == "scan5"
+                o = Oracle(terms, pos_mode)
+                for _ in range(2):                               # (second call: unit sizes follow the density the first one saw)
+                    assert_csr_equal(e.scan(blob, off), o.scan(blob, off))
+            from gofindthem_amd.workload import Workload
+            w = Workload(3000)
+            o = Oracle(w.terms())
+            e.build(w.terms())
+            text, toff = w.docs_host(0, 300)
+            assert_csr_equal(e.scan(text, toff, fold=True), o.scan(text, toff, fold=True))
+            assert_csr_equal(e.scan(text, toff, fold=False), o.scan(text, toff, fold=False))
+    finally:
+        e.close()
+
+
 def test_rune_offsets_are_the_anknown_engine_positions(eng):
     """GFT_POS_RUNES = AnknownEngine.FindSubstrings (finder/substringEngine.go:44-53): MultiPatternSearch([]rune(text)) reports
     Position over runes.  Expected: the oracle's byte offsets mapped through Go's string -> []rune decoding
@@ -531,7 +569,7 @@ def test_mixed_alphabet_workload(eng, scan_kernel):
     assert len({b for t in kws for b in t}) >= 48 and min(len(t) for t in kws) <= 3
     o = both(eng, kws)
     L = _lib.load()
-    assert L.gft_scan_kernel(eng._h).decode() == {"scan4": "dfa", "scan3": "scan3", "scan2": "dfa", "scan2-ordered": "dfa", "dfa": "dfa"}[scan_kernel]
+    assert L.gft_scan_kernel(eng._h).decode() == {"scan5": "dfa", "scan4": "dfa", "scan3": "scan3", "scan2": "dfa", "scan2-ordered": "dfa", "dfa": "dfa"}[scan_kernel]
     text, off = w.docs_host(0, 400)
     assert_csr_equal(eng.scan(text, off, fold=True), o.scan(text, off, fold=True))
     assert_csr_equal(eng.scan(text, off, fold=False), o.scan(text, off, fold=False))

@@ -214,7 +214,7 @@ def main():
 
     if rank == 0:
         scan_kernel = (L.gft_scan_kernel(eh) or b"").decode()
-        kernel_names = {"scan2": "k_scan2 (suffix-window scan)", "scan4": "k_scan4 (streaming suffix-window scan)", "scan3": "k_scan3 (stride-2 suffix-window scan)", "dfa": "k_scan_units (two-tier DFA)"}
+        kernel_names = {"scan5": "k_scan5 (suffix-window scan, one probe per two bytes)", "scan2": "k_scan2 (suffix-window scan)", "scan4": "k_scan4 (streaming suffix-window scan)", "scan3": "k_scan3 (stride-2 suffix-window scan)", "dfa": "k_scan_units (two-tier DFA)"}
         docs_total = total_docs * args.steps
         ms_per_step = elapsed / args.steps * 1e3
         # algorithmic bytes of the dominant (scan) kernel per launch: text once + one offset entry per document +

@@ -93,11 +93,11 @@ struct gft_engine {
     double scan4_density = 0.06;
     // the suffix-window kernel with the unit's text in LDS (gft_scan5.hip): scan2's tables + a filter over merged classes
     bool use_scan5 = false;
-    Scan5Plan s5plan{0, 0, 0, 0, 0};
+    Scan5Plan s5plan{0, 0, 0, 0};
     Scan5Tables s5;
-    DevBuf d_s5_grp, d_s5_grp_fold, d_s5_filter, d_s5_cell, d_s5_ids;
+    DevBuf d_s5_grp, d_s5_grp_fold, d_s5_filter;
     uint32_t s5_term_bits = 0, s5_pos_bias = 0;
-    uint32_t opt_scan5_prefetch = 1;                    // GFT_SCAN5_PREFETCH=0: no next-unit prefetch (timing studies)
+    uint32_t opt_scan5_contig = 0;                      // GFT_SCAN5_CONTIG=1: one contiguous run of units per workgroup
     uint32_t opt_scan5_groups = 0;                      // GFT_SCAN5_GROUPS: forced number of filter groups (tests)
     uint64_t scan_valid_docs = ~0ull;                   // documents of the last gft_process scan still in the pool (~0: none)
     uint32_t scan2_unit_max = kScan2UnitMax;            // bytes per work unit (adapts to the match density)
@@ -185,8 +185,8 @@ void refresh_options(gft_engine* e) {
     e->opt_scan_ordered = getenv("GFT_SCAN_ORDERED") ? 1u : 0u;
     e->opt_scan4_chunk = (uint32_t)num("GFT_SCAN4_CHUNK", 0);
     e->opt_scan4_round = (uint32_t)num("GFT_SCAN4_ROUND", 0);
-    e->opt_scan5_prefetch = num("GFT_SCAN5_PREFETCH", 1) ? 1u : 0u;
     e->opt_scan5_groups = (uint32_t)num("GFT_SCAN5_GROUPS", 0);
+    e->opt_scan5_contig = num("GFT_SCAN5_CONTIG", 0) ? 1u : 0u;
     e->opt_solve_dbg = (uint32_t)num("GFT_SOLVE_DEBUG", 0);
     e->opt_solve_group = (int)num("GFT_SOLVE_GROUP_DOCS", -1);
 }
@@ -497,9 +497,7 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
     const uint32_t warm = e->tab.max_term_len ? e->tab.max_term_len - 1 : 0;
     // gft_scan2: a unit's matches should fit the wave's LDS fifo (kScan2FifoCap), so the unit size follows the match
     // density the previous call saw (dense dictionaries -> smaller units); results do not depend on it
-    const uint32_t unit_max = e->use_scan3 ? kScan3UnitMax : e->use_scan4 ? kScan4UnitMax
-                              : e->use_scan5 ? std::min<uint32_t>(e->scan2_unit_max, e->s5plan.rounds * 1024)
-                              : e->use_scan2 ? e->scan2_unit_max : kTextBuf - warm;
+    const uint32_t unit_max = e->use_scan3 ? kScan3UnitMax : e->use_scan4 ? kScan4UnitMax : e->use_scan2 ? e->scan2_unit_max : kTextBuf - warm;
 
     // 1. work units
     HIP_TRY(e->d_ctl.ensure(64), "control alloc");
@@ -716,15 +714,13 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
             ProfScope ps(e, "scan");
             HIP_TRY(launch_scan4(P, e->scan4_waves, e->n_cus, st), "scan kernel launch");
         } else if (e->use_scan5) {
-            // the text-in-LDS form: scan2's tables behind the group filter, units of at most s5plan.rounds KiB
-            P.filter = e->d_s5_filter.as<uint32_t>(); P.filter_words = (uint32_t)e->s5.filter.size();
+            // one filter probe per two bytes: scan2's tables behind the 3-gram filter over merged classes
+            P.s5_filter = e->d_s5_filter.as<uint64_t>(); P.s5_dual = (uint32_t)e->s5.filter.size();
             P.s5_grp = P.fold ? e->d_s5_grp_fold.as<uint8_t>() : e->d_s5_grp.as<uint8_t>();
             P.s5_G = e->s5.G; P.s5_pad_g = e->s5.pad_group;
-            P.s5_cell = e->d_s5_cell.as<uint64_t>(); P.s5_cells = (uint32_t)e->s5.cell.size();
-            P.s5_id = e->d_s5_ids.as<uint8_t>(); P.s5_ids = (uint32_t)e->s5.ids.size();
-            P.s5_text_cap = e->s5plan.rounds * 1024; P.s5_fifo_cap = e->s5plan.fifo_cap; P.cand_cap = e->s5plan.cand_cap;
+            P.s5_fifo_cap = e->s5plan.fifo_cap; P.cand_cap = e->s5plan.cand_cap;
             P.s5_term_bits = e->s5_term_bits; P.s5_pos_bias = e->s5_pos_bias;
-            P.s5_prefetch = e->opt_scan5_prefetch;
+            P.s5_contig = e->opt_scan5_contig;
             const uint64_t n_waves5 = (uint64_t)e->n_cus * kScan5Waves;
             P.slab = (uint32_t)std::min<uint64_t>(kScan2Slab, std::max<uint64_t>(64, e->pool_cap / (2 * n_waves5)));
             e->last_static_slabs = std::min<uint64_t>(std::max<uint64_t>((n_units + kScan5Waves - 1) / kScan5Waves, 1), e->n_cus) * kScan5Waves * P.slab;
@@ -741,7 +737,7 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
             uint64_t t[16];
             HIP_TRY(hipMemcpyAsync(t, e->d_dbg.p, sizeof t, hipMemcpyDeviceToHost, st), "debug read-back");
             HIP_TRY(hipStreamSynchronize(st), "debug read-back");
-            if (e->use_scan5) fprintf(stderr, "[gft scan debug] scan5 (G=%u, %u rounds, list %u):\n", e->s5.G, e->s5plan.rounds, e->s5plan.cand_cap);
+            if (e->use_scan5) fprintf(stderr, "[gft scan debug] scan5 (G=%u, list %u):\n", e->s5.G, e->s5plan.cand_cap);
             if (e->use_scan4)
                 fprintf(stderr, "[gft scan debug] scan4 wave cycles per unit: chunk set-up %.0f, filter %.0f, queue push %.0f, stage A issue %.0f, stage A %.0f, stage B %.0f, flush %.0f, unit records %.0f\n",
                         (double)t[4] / n_units, (double)t[5] / n_units, (double)t[6] / n_units, (double)t[7] / n_units, (double)t[8] / n_units,
@@ -1264,7 +1260,7 @@ void gft_engine_destroy(gft_engine* e) {
                          &e->d_s2_term_off, &e->d_ctl, &e->d_dbg, &e->d_s2_short3, &e->d_s2_shorts_packed, &e->d_s2_short3_big, &e->d_s2_fpt,
                          &e->d_s3_filter, &e->d_s3_short3, &e->d_s3_srec, &e->d_s3_short3_big, &e->d_s3_srec_big, &e->d_s3_bloom, &e->d_s3_slots,
                          &e->d_s3_more, &e->d_s3_cls, &e->d_s3_cls_fold, &e->d_s3_term_blob, &e->d_s3_term_off,
-                         &e->d_s5_grp, &e->d_s5_grp_fold, &e->d_s5_filter, &e->d_s5_cell, &e->d_s5_ids,
+                         &e->d_s5_grp, &e->d_s5_grp_fold, &e->d_s5_filter,
 &e->d_unit_cnt, &e->d_unit_base, &e->d_units, &e->d_partial,
                          &e->d_pool_term, &e->d_pool_pos, &e->d_unit_start, &e->d_unit_count, &e->d_unit_out,
                          &e->d_term, &e->d_pos, &e->d_match_off, &e->d_text, &e->d_doc_off, &e->d_bitmap, &e->d_xoff,
@@ -1312,8 +1308,7 @@ static int install_tables(gft_engine* e, uint32_t flags) {
     size_t rows = (e->lds_max - fixed) / ((size_t)e->tab.n_classes * 4);
     e->n_lds_states = (uint32_t)std::min<size_t>(rows, e->tab.n_states);
 
-    std::vector<uint8_t> bc(e->tab.byte_class, e->tab.byte_class + 256), c1, c2, g1, g2, s3v, s5g, s5gf, s5ids;
-    std::vector<uint64_t> s5cell;
+    std::vector<uint8_t> bc(e->tab.byte_class, e->tab.byte_class + 256), c1, c2, g1, g2, s3v, s5g, s5gf;
     SyncOnExit drained(e);                              // (declared behind the temporaries the uploads read from: it goes first)
     int rc;
     if ((rc = upload(e, e->d_byte_class, bc, "table upload"))) return rc;
@@ -1340,23 +1335,21 @@ static int install_tables(gft_engine* e, uint32_t flags) {
         e->use_scan4 = e->use_scan2 && k4_fits && force && std::string(force) == "scan4";
         e->scan4_density = 0.06;
     }
-    // the text-in-LDS form of the suffix-window kernel: scan2's tables with a direct filter, a fifo entry of 32 bits holds
-    // term id and relative position (GFT_SCAN_KERNEL=scan5; positions: DESIGN.md 4.1b)
+    // the suffix-window kernel with one filter probe per two bytes -- the default wherever gft_scan2's direct tables apply
+    // (GFT_SCAN_KERNEL=scan2: the one-probe-per-byte kernel): scan2's tables, a fifo entry of 32 bits holds term id and
+    // relative position
     e->use_scan5 = false;
-    if (e->use_scan2 && !e->s2.hashed && force && std::string(force) == "scan5") {
-        uint32_t cells = 0, ids = 0;
-        scan5_short_sizes(e->s2, &cells, &ids);
+    if (e->use_scan2 && !e->s2.hashed && (!force || std::string(force) == "scan5" || std::string(force) == "auto" || !*force)) {
         uint32_t tb = 1;
         while ((1ull << tb) < e->tab.terms.size()) tb++;
         e->s5_term_bits = tb;
         e->s5_pos_bias = e->tab.max_term_len + kScan2MaxOff;
-        const bool packs = (uint64_t)kScan5MaxRounds * 1024 + e->s5_pos_bias + 8 < (1ull << (32 - tb));
-        if (packs && scan5_plan(e->s2.kp, cells, ids, (uint32_t)std::min<size_t>(e->s2.shorts_packed.size(), 255 * 3),
+        const bool packs = (uint64_t)kScan2UnitMax + e->s5_pos_bias + 8 < (1ull << (32 - tb));
+        if (packs && scan5_plan(e->s2.kp, (uint32_t)e->s2.short3.size(), (uint32_t)std::min<size_t>(e->s2.shorts_packed.size(), 255 * 3),
                                 e->s2.fpt_lg ? 0u : kScan2FptSize, e->lds_max - 512, &e->s5plan)) {
             if (e->opt_scan5_groups && e->opt_scan5_groups < e->s5plan.G) {      // (tests: more merging than LDS asks for)
                 e->s5plan.G = std::max<uint32_t>(e->opt_scan5_groups, 2);
-                const uint64_t bits = (uint64_t)e->s5plan.G * e->s5plan.G * e->s5plan.G * e->s5plan.G;
-                e->s5plan.filter_words = (uint32_t)((bits + 63) / 64 * 2);
+                e->s5plan.dual_entries = e->s5plan.G * e->s5plan.G * e->s5plan.G;
             }
             build_scan5_tables(e->tab, e->s2, e->s5plan.G, e->s5);
             e->use_scan5 = true;
@@ -1420,16 +1413,12 @@ static int install_tables(gft_engine* e, uint32_t flags) {
     }
     if (e->use_scan5) {
         s5g.assign(e->s5.grp, e->s5.grp + 256); s5gf.assign(e->s5.grp_fold, e->s5.grp_fold + 256);
-        s5ids = e->s5.ids; if (s5ids.empty()) s5ids.assign(16, 0);
-        s5cell = e->s5.cell; if (s5cell.empty()) s5cell.assign(2, 0);
         if ((rc = upload(e, e->d_s5_grp, s5g, "table upload"))) return rc;
         if ((rc = upload(e, e->d_s5_grp_fold, s5gf, "table upload"))) return rc;
         if ((rc = upload(e, e->d_s5_filter, e->s5.filter, "table upload"))) return rc;
-        if ((rc = upload(e, e->d_s5_cell, s5cell, "table upload"))) return rc;
-        if ((rc = upload(e, e->d_s5_ids, s5ids, "table upload"))) return rc;
         if (getenv("GFT_SCAN_DEBUG"))
-            fprintf(stderr, "[gft build debug] scan5: G=%u of %u classes, %u rounds per unit, filter %zu words, short cells %zu ids %zu, list %u, term bits %u\n",
-                    e->s5.G, e->s2.kp, e->s5plan.rounds, e->s5.filter.size(), e->s5.cell.size(), e->s5.ids.size(), e->s5plan.cand_cap, e->s5_term_bits);
+            fprintf(stderr, "[gft build debug] scan5: G=%u of %u classes, filter %zu entries, list %u, term bits %u\n",
+                    e->s5.G, e->s2.kp, e->s5.filter.size(), e->s5plan.cand_cap, e->s5_term_bits);
     }
     HIP_TRY(hipStreamSynchronize(e->stream), "table upload");
     e->built = true;

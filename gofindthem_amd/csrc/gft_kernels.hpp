@@ -271,16 +271,14 @@ struct Scan2Params {
     uint32_t chunk_units;        // units a wave streams through in one go (1 .. kScan4ChunkUnits)
     uint32_t bound_q16, bound_add;   // a unit's region of the match pool: bytes * bound_q16 / 65536 + bound_add entries
     uint32_t round_c;            // bytes per lane and round (16, 32, 48 or 64): a round is 64 x round_c bytes of the stream
-    // gft_scan5.hip (the unit's text in LDS) only; there `filter` / `filter_words` are the G^4-bit group filter:
+    // gft_scan5.hip (one filter probe per two bytes) only:
     const uint8_t* s5_grp;       // [256] byte -> filter group (the folded table when GFT_FOLD_ASCII), copied to LDS
-    uint32_t s5_G, s5_pad_g;     // groups; the group of class 0 (what stands in front of the blob)
-    const uint64_t* s5_cell;     // [s5_cells] short terms: bits of 32 consecutive 3-windows | rank of the first set one << 32, LDS
-    const uint8_t* s5_id;        // [s5_ids] record id per set bit in rank order (255: short3_big), LDS
-    uint32_t s5_cells, s5_ids;
-    uint32_t s5_text_cap;        // bytes of text a wave's LDS buffer holds = the longest unit (whole rounds of 1 KiB)
+    uint32_t s5_G, s5_pad_g;     // groups; the group of class 0 (what stands in front of a document)
+    const uint64_t* s5_filter;   // [s5_dual = G^3] per 3-gram of groups: low word bit a = some anchor window is (a, 3-gram), high
+    uint32_t s5_dual;            // word bit d = some anchor window is (3-gram, d); copied to LDS
     uint32_t s5_fifo_cap;        // entries (4 B) of a wave's LDS match fifo
+    uint32_t s5_contig;          // 1: a workgroup takes one contiguous run of units (0: the grid moves through the text side by side)
     uint32_t s5_term_bits, s5_pos_bias;   // with positions a fifo entry is term | (pos - (unit.lo - pos_bias)) << term_bits
-    uint32_t s5_prefetch;        // 1: the next unit's first round is requested in front of stage A
 };
 // waves per workgroup (16, 12, 8 or 4) and candidate-list capacity that fit lds_max; false if nothing fits
 bool scan2_plan(uint32_t filter_words, uint32_t short3_bytes, uint32_t shorts_words, uint32_t fpt_lds_bytes, size_t lds_max,
@@ -293,16 +291,13 @@ constexpr uint32_t kScan4UnitMax = 8176;
 bool scan4_plan(uint32_t filter_words, uint32_t short3_bytes, uint32_t shorts_words, uint32_t fpt_lds_bytes, size_t lds_max, bool want_pos,
                 uint32_t* waves, uint32_t* fifo_cap);
 hipError_t launch_scan4(const Scan2Params& P, uint32_t waves, unsigned n_cus, hipStream_t st);
-// gft_scan5.hip: the same tables behind a filter over merged byte classes, the unit's text resident in LDS
+// gft_scan5.hip: the same tables behind a filter over 3-grams of merged byte classes that is probed every other byte
 constexpr uint32_t kScan5Waves = 16;             // waves per workgroup (one LDS copy of the tables per CU)
-constexpr uint32_t kScan5Lead = 32;              // bytes of text in front of the unit that the LDS buffer also holds
-constexpr uint32_t kScan5MaxRounds = 5;          // a unit is at most this many rounds of 1 KiB (positions flags: 3 x 32 bits per lane)
-constexpr uint32_t kScan5MaxGroups = 27;         // filter groups: G^4 bits of LDS
+constexpr uint32_t kScan5MaxGroups = 27;         // filter groups: G^3 x 8 bytes of LDS (G <= 32: a group is a bit of a 32-bit word)
 constexpr uint32_t kScan5CandCapMin = 384;       // flagged positions of one unit listed in LDS at least (more when LDS is left)
-struct Scan5Plan { uint32_t G, rounds, filter_words, cand_cap, fifo_cap; };
-// filter groups, rounds per unit and list capacities that fit lds_max with kScan5Waves waves; false if nothing fits.
-// cells / ids: sizes of the short-term bitmap (build_scan5_tables)
-bool scan5_plan(uint32_t kp, uint32_t cells, uint32_t ids, uint32_t shorts_words, uint32_t fpt_lds_bytes, size_t lds_max, Scan5Plan* out);
+struct Scan5Plan { uint32_t G, dual_entries, cand_cap, fifo_cap; };
+// filter groups and list capacities that fit lds_max with kScan5Waves waves; false if nothing fits
+bool scan5_plan(uint32_t kp, uint32_t short3_bytes, uint32_t shorts_words, uint32_t fpt_lds_bytes, size_t lds_max, Scan5Plan* out);
 hipError_t launch_scan5(const Scan2Params& P, unsigned n_cus, hipStream_t st);
 
 

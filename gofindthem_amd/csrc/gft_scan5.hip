@@ -1,27 +1,25 @@
-// gft_scan5.hip -- the suffix-window Aho-Corasick scan with the unit's text resident in LDS (tables: scan2_tables.hpp,
+// gft_scan5.hip -- the suffix-window Aho-Corasick scan with ONE filter probe per TWO text bytes (tables: scan2_tables.hpp,
 // build_scan5_tables).  Replaces (*Matcher).MatchAll behind CloudflareForkEngine.FindSubstrings
 // (finder/substringEngine.go:110-119), as gft_scan2.hip does; same bucket / fingerprint / short-term tables, same results.
 //
-// What gft_scan2.hip pays for outside its instruction stream (profiles/r3_tcc_counters.json): the
-// verification stages read the text around every flagged position again from global memory, 6-10 gathers per unit whose
-// 32 lines have by then half left the XCD's L2 (16 line re-fetches per 4 KB document, 2 GB per launch), and every such
-// gather is a dependent round trip in front of the LDS decisions.  Here the text is read from HBM exactly once:
-//   FILTER   coalesced rounds of 1 KiB -- lane k owns bytes [1024 r + 16 k, +16) of round r, one 16-byte load per lane and
-//            round, every line requested by exactly one instruction -- and each piece goes to the wave's text buffer in
-//            LDS on its way through the filter.  The room comes from the filter itself: byte classes are merged down to G
-//            filter GROUPS (the rare classes share), G^4 bits instead of K^4 (27 -> 22 classes: 66 -> 29 KB for 2 % more
-//            flagged positions), and from the short-term table as a bitmap with ranks (K^3 bits + a byte per set cell
-//            instead of K^3 bytes).  The keys of the verification stages stay EXACT classes, so everything behind the
-//            filter (fingerprints, bucket slots, short records) is gft_scan2's.
-//   STAGE A / B  as in gft_scan2.hip, but every text access is an (unaligned) LDS read: window + front bytes ds_read_b64,
-//            the 16 bytes in front ds_read_b128, the tail ds_read_b32.  No vector-memory access in stage A at all, stage B
-//            waits for its bucket slots only.
-//   PREFETCH with stage A free of vector memory the next unit's first round can be requested in front of it: by the time
-//            stage B waits for its slots (results return in order) that load has long landed.
+// gft_scan2.hip is bound by the CU's LDS unit and its vector ALU together: 983 LDS cycles per 4 KB document,
+// 547 of them the filter's probes -- one ds_read_b32 at a random address per text byte, 8.5 cycles each with the bank
+// conflicts that 64 random addresses have.  The filter here answers two end positions with one read:
+//   FILTER   the table is indexed by a 3-gram of byte GROUPS (g[j-2], g[j-1], g[j]) and holds 64 bits: bit g[j-3] of the low
+//            word says whether some term's anchor window is (g[j-3], g[j-2], g[j-1], g[j]) -- a window that ENDS at j --, bit
+//            g[j+1] of the high word whether one is (g[j-2], g[j-1], g[j], g[j+1]) -- a window that ends at j+1.  One
+//            ds_read_b64 per two bytes (half the probes, 11 VALU instructions per two bytes instead of 14), the same
+//            per-position flags as gft_scan2's filter.  G^3 x 8 bytes: the byte classes are merged down to G groups (the
+//            classes that are rare in the dictionary share: 27 -> 22 groups = 83 KB for 4 % more flagged positions); the
+//            room comes from 4-byte fifo entries.  The keys of the verification stages stay EXACT classes, so everything
+//            behind the filter (fingerprints, bucket slots, short records) is gft_scan2's.
+//   STAGE A / B  gft_scan2.hip's (gft_scan2_dev.hpp).
 //   OUTPUT   matches go to a 4-byte-per-entry LDS fifo (term id, or term id | relative position << term_bits), flushed
 //            coalesced into the wave's slab.  A unit whose matches outgrow the fifo is verified a second time with the
-//            appends going straight to a pool region of the counted size.
+//            appends going straight to a pool region of the counted size (no per-lane staging path).
 // HBM traffic: text once + 4 B (8 B with positions) per match.  No MFMA (byte automaton, not a contraction).
+// Measured and set aside (git history: 31cb86c): the same kernel with the unit's text resident in LDS -- the unaligned
+// ds_read_b64 / b128 of the verification stages replay at 64 cycles each, and LDS cycles are what the kernel is short of.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -34,39 +32,12 @@ namespace {
 
 #include "gft_scan2_dev.hpp"
 
-typedef __attribute__((address_space(3))) uint8_t lds_wb;
-// (un)aligned LDS accesses by address: gfx950 reads LDS at any alignment (ds_read_b64 / ds_read_b128 / ds_read_b32)
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef u32x2 __attribute__((aligned(1))) u32x2_u;
-typedef u32x4 __attribute__((aligned(1))) u32x4_u;
-typedef uint32_t __attribute__((aligned(1))) u32_u;
-__device__ __forceinline__ void lds_store16(uint32_t addr, uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
-    *(__attribute__((address_space(3))) u32x4*)(uintptr_t)addr = u32x4{x, y, z, w};
-}
-
-// the wave's text buffer: LDS byte address of document position p is tq + p (tq = buffer + kScan5Lead - unit.lo, mod 2^32)
-__device__ __forceinline__ Text8 text8(uint32_t tq, uint32_t p) {
-    const u32x2 v = *(__attribute__((address_space(3))) const u32x2_u*)(uintptr_t)(tq + p - 7);
-    return Text8{v.x, v.y};
-}
-__device__ __forceinline__ Front front5(uint32_t tq, uint32_t p, uint32_t tw) {
-    const u32x4 v = *(__attribute__((address_space(3))) const u32x4_u*)(uintptr_t)(tq + p - 23);
-    Front t;
-    t.f[0] = tw; t.f[4] = v.x; t.f[3] = v.y; t.f[2] = v.z; t.f[1] = v.w;
-    return t;
-}
-__device__ __forceinline__ uint32_t tail5(uint32_t tq, uint32_t p) {
-    return *(__attribute__((address_space(3))) const u32_u*)(uintptr_t)(tq + p + 1);
-}
-
 struct Ctx5 {
-    uint32_t tq;                 // see text8
-    const uint2* s3cell;         // LDS: {bits of 32 consecutive 3-windows, rank of the first} (nullptr: no short terms)
-    const uint8_t* s3ids;        // LDS: record id per set bit, in rank order
     uint32_t* fifo;              // LDS
     uint32_t fifo_cap;
     uint32_t nf;                 // matches of this unit so far (wave-uniform)
+    uint32_t npend;              // short-term jobs parked at the END of the fifo (entry i = fifo[cap - 1 - i]; wave-uniform)
+    bool lost;                   // wave-uniform: a match did not fit the fifo (or a parked job took its place): walk again
     bool direct;                 // wave-uniform: the second walk of a unit that outgrew the fifo -- appends go to the pool
     uint64_t dbase;              // ... at this entry
     uint32_t term_bits, pos_base;
@@ -77,45 +48,69 @@ __device__ __forceinline__ void out_append(const Scan2Params& P, Ctx5& o, bool e
     if (em) {
         const uint32_t idx = o.nf + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
         if (!o.direct) {
-            if (idx < o.fifo_cap) o.fifo[idx] = P.want_pos ? term | (pos - o.pos_base) << o.term_bits : term;
+            if (idx < o.fifo_cap - o.npend) o.fifo[idx] = P.want_pos ? term | (pos - o.pos_base) << o.term_bits : term;
         } else {
             KARG(pool_term)[o.dbase + idx] = term;
             if (P.want_pos) KARG(pool_pos)[o.dbase + idx] = pos;
         }
     }
     o.nf += (uint32_t)__popcll(mask);
+    if (!o.direct && o.nf + o.npend > o.fifo_cap) o.lost = true;
 }
 
-// record id of the short terms that end with 3-window x3 (0: none); wave-uniform call
-__device__ __forceinline__ uint32_t short_id(const Ctx5& o, uint32_t x3) {
-    if (!o.s3cell) return 0;
-    const uint2 cell = o.s3cell[x3 >> 5];
-    const bool hit = (cell.x >> (x3 & 31)) & 1u;
-    uint32_t sid = 0;
-    if (__any(hit)) {
-        const uint32_t rank = cell.y + __popc(cell.x & ((1u << (x3 & 31)) - 1u));
-        sid = o.s3ids[hit ? rank : 0];
-        if (!hit) sid = 0;
-    }
-    return sid;
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <bool WANT_SID>
-__device__ __forceinline__ void cand_keys5(const Ctx& c, const Ctx5& o, uint32_t p, const Text8 t, Cand& k) {
-    cand_keys<false>(c, p, t, k);
-    k.sid = WANT_SID ? short_id(o, k.x3) : 0;
-}
-
-__device__ __forceinline__ void finish_short5(const Ctx& c, Ctx5& o, uint32_t p, uint32_t sid, uint32_t x3) {
-    if (!__any(sid != 0)) return;
+// Short terms are emitted DENSELY: stage A only parks {position, record id} of the candidates whose 3-window ends one
+// (a tenth of them: emitting in place cost three appends per 64 candidates, whoever had a hit), 64 parked jobs make one
+// trip.  The jobs wait at the end of the match fifo, which gives up that room (a unit whose matches then do not fit is
+// walked again with the appends going to the pool: the fifo is all theirs then).
+__device__ __forceinline__ void short_trip(const Ctx& c, Ctx5& o, uint32_t ubase, uint32_t n) {       // the n (<= 64) most recently parked jobs
+    const uint32_t lane = lane_id();
+    const bool on = lane < n;
+    const uint32_t job = o.fifo[o.fifo_cap - 1 - (o.npend - n) - (on ? lane : 0)];
+    o.npend -= n;
+    const uint32_t p = ubase + (job & 0xFFFFu), sid = on ? job >> 16 : 0;
     uint32_t r[3] = {0, 0, 0};
-    if (sid) short_record(c, sid, x3, r);
+    if (sid) {
+        const uint32_t* src = c.lrec + 3 * sid;
+        r[0] = src[0]; r[1] = src[1]; r[2] = src[2];
+    }
 #pragma unroll
     for (uint32_t j = 0; j < 3; j++) {
         if (j && !__any(r[j] != 0)) break;
         const uint32_t L = r[j] >> 28;
         out_append(c.P, o, r[j] != 0 && L <= p + 1, r[j] & 0x0FFFFFFFu, c.P.pos_end ? p : p + 1 - L);
     }
+}
+// sid != 0: this lane's candidate (list entry rel) ends short terms; wave-uniform call
+__device__ __forceinline__ void park_short(const Ctx& c, Ctx5& o, uint32_t ubase, uint32_t rel, uint32_t sid, uint32_t x3) {
+    if (!__any(sid != 0)) return;
+    if (__builtin_expect(__any(sid == 255) && KARG(short3_big) != nullptr, 0)) {
+        // records beyond the LDS ids (a dictionary with hundreds of distinct short-term sets): emitted in place
+        uint32_t r[3] = {0, 0, 0};
+        const uint32_t p = ubase + rel;
+        if (sid) short_record(c, sid, x3, r);
+#pragma unroll
+        for (uint32_t j = 0; j < 3; j++) {
+            const uint32_t L = r[j] >> 28;
+            out_append(c.P, o, r[j] != 0 && L <= p + 1, r[j] & 0x0FFFFFFFu, c.P.pos_end ? p : p + 1 - L);
+        }
+        return;
+    }
+    const uint64_t m = __ballot(sid != 0);
+    const uint32_t n = (uint32_t)__popcll(m);
+    if (o.npend + n > o.fifo_cap / 2) {                            // (never in practice: keep half of the fifo for matches)
+        wave_lds_sync();
+        while (o.npend) short_trip(c, o, ubase, o.npend < 64 ? o.npend : 64);
+        wave_lds_sync();
+    }
+    if (!o.direct && o.nf + o.npend + n > o.fifo_cap) o.lost = true;   // (the jobs go where matches are)
+    if (sid) o.fifo[o.fifo_cap - 1 - o.npend - __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = rel | sid << 16;
+    o.npend += n;
 }
 
 // gft_scan2_dev.hpp finish_long / drain_deferred with the text in LDS and the 4-byte fifo
@@ -161,11 +156,6 @@ __device__ __forceinline__ void finish_long5(const Ctx& c, Ctx5& o, bool on, uin
     }
 }
 
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 __device__ __forceinline__ void drain_deferred5(const Ctx& c, Ctx5& o, uint32_t ubase, Deferred& d) {
     const Scan2Params& P = c.P;
@@ -176,9 +166,9 @@ __device__ __forceinline__ void drain_deferred5(const Ctx& c, Ctx5& o, uint32_t 
         const uint2 it = d.list[on ? i0 + lane : 0];
         const uint32_t p = ubase + it.x;
         const Slot e = slot_load(&P.more[it.y]);
-        const Text8 t8 = text8(o.tq, p);
-        Front t = front5(o.tq, p, t8.tw);
-        const uint32_t tl = tail5(o.tq, p);
+        const Text8 t8 = cand_load(c, p);
+        Front t = front_load(c, p, t8.tw);
+        const uint32_t tl = tail_load(c, p);
         const uint32_t kmax = wave_kmax(on ? e.a.z & kScan2LenMask : 0);
         uint32_t folded = 0;
         if (P.fold) front_fold_upto(t, folded, kmax);
@@ -195,36 +185,35 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
     extern __shared__ __align__(16) uint8_t smem[];
     uint8_t* grp = smem;                                          // byte -> filter group
     uint8_t* cls = smem + 256;                                    // byte -> exact class
-    uint32_t* filt = reinterpret_cast<uint32_t*>(smem + 512);
-    uint2* s3cell = reinterpret_cast<uint2*>(smem + 512 + (size_t)P.filter_words * 4);   // (filter_words is even: 8-byte aligned)
-    uint8_t* s3ids = reinterpret_cast<uint8_t*>(s3cell + P.s5_cells);
-    uint8_t* fpt = s3ids + ((P.s5_ids + 3) & ~3u);
+    uint64_t* dual = reinterpret_cast<uint64_t*>(smem + 512);     // [G^3] the filter
+    uint8_t* short3 = reinterpret_cast<uint8_t*>(dual + P.s5_dual);
+    uint8_t* fpt = short3 + P.short3_bytes;                       // (short3_bytes is a multiple of 16)
     uint32_t* lrec = reinterpret_cast<uint32_t*>(fpt + (FPT_LDS ? kScan2FptSize : 0));
     uint32_t* wg_next = reinterpret_cast<uint32_t*>(smem + (((size_t)(reinterpret_cast<uint8_t*>(lrec) - smem) + P.shorts_words * 4 + 15) & ~(size_t)15));
     uint8_t* wave_lds_all = reinterpret_cast<uint8_t*>(wg_next) + 16;
 
     for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) { grp[i] = P.s5_grp[i]; cls[i] = P.cls[i]; }
-    for (uint32_t i = threadIdx.x; i < P.filter_words; i += blockDim.x) filt[i] = P.filter[i];
-    for (uint32_t i = threadIdx.x; i < P.s5_cells; i += blockDim.x) reinterpret_cast<uint64_t*>(s3cell)[i] = P.s5_cell[i];
-    for (uint32_t i = threadIdx.x; i < P.s5_ids; i += blockDim.x) s3ids[i] = P.s5_id[i];
+    for (uint32_t i = threadIdx.x; i < P.s5_dual; i += blockDim.x) dual[i] = P.s5_filter[i];
+    for (uint32_t i = threadIdx.x; i < P.short3_bytes / 4; i += blockDim.x)
+        reinterpret_cast<uint32_t*>(short3)[i] = reinterpret_cast<const uint32_t*>(P.short3)[i];
     for (uint32_t i = threadIdx.x; FPT_LDS && i < kScan2FptSize / 4; i += blockDim.x)
         reinterpret_cast<uint32_t*>(fpt)[i] = reinterpret_cast<const uint32_t*>(P.fpt)[i];
     for (uint32_t i = threadIdx.x; i < P.shorts_words; i += blockDim.x) lrec[i] = P.shorts_packed[i];
     if (threadIdx.x == 0) { wg_next[0] = blockDim.x >> 6; wg_next[1] = wg_next[2] = wg_next[3] = 0; }
     __syncthreads();
+    if (DBG && (P.dbg & 128)) return;                            // timing study: launch + table staging alone
 
     const uint32_t lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // per-wave LDS region: [text: kScan5Lead + text_cap + 16][fifo: fifo_cap x 4 B][candidate list: cand_cap x 2 B]
-    const uint32_t text_bytes_lds = kScan5Lead + P.s5_text_cap + 16;
-    uint8_t* wave_lds = wave_lds_all + (size_t)wave * (text_bytes_lds + P.s5_fifo_cap * 4 + ((P.cand_cap * 2 + 15) & ~15u));
-    uint8_t* tbuf = wave_lds;
-    uint32_t* fifo = reinterpret_cast<uint32_t*>(wave_lds + text_bytes_lds);
-    uint16_t* cand = reinterpret_cast<uint16_t*>(wave_lds + text_bytes_lds + P.s5_fifo_cap * 4);
-    const uint32_t tb = (uint32_t)(uintptr_t)(lds_wb*)tbuf;       // LDS byte address of the text buffer
-    const uint32_t G = __builtin_amdgcn_readfirstlane(P.s5_G), G2 = __builtin_amdgcn_readfirstlane(G * G);
+    // per-wave LDS region: [fifo: fifo_cap x 4 B][candidate list: cand_cap x 2 B]
+    uint8_t* wave_lds = wave_lds_all + (size_t)wave * (P.s5_fifo_cap * 4 + ((P.cand_cap * 2 + 15) & ~15u));
+    uint32_t* fifo = reinterpret_cast<uint32_t*>(wave_lds);
+    uint16_t* cand = reinterpret_cast<uint16_t*>(wave_lds + P.s5_fifo_cap * 4);
+    const uint32_t G = __builtin_amdgcn_readfirstlane(P.s5_G);
     const uint32_t kp = __builtin_amdgcn_readfirstlane(P.kp), kp2 = __builtin_amdgcn_readfirstlane(kp * kp);
     lds_u8* lgrp = (lds_u8*)0;
-    lds_u32* lfilt = (lds_u32*)512;
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) const u32x2 lds_u64;
+    lds_u64* ldual = (lds_u64*)512;
     if ((uint32_t)(uintptr_t)(lds_u8*)smem != 0) __builtin_trap();   // see lds_u8
 
     unsigned long long tl[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = DBG ? clock64() : 0;
@@ -240,16 +229,16 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
     // every round k, its waves take them one by one from a counter in LDS
     const uint32_t wg_waves = blockDim.x >> 6;
     const uint64_t round_units = (uint64_t)gridDim.x * wg_waves, wg_first = (uint64_t)blockIdx.x * wg_waves;
-    auto unit_of = [&](uint32_t item) { return (uint64_t)(item / wg_waves) * round_units + wg_first + item % wg_waves; };
-    uint64_t u = wg_first + wave, nu = 0;                         // wave-uniform
+    // (s5_contig: the workgroup owns ONE contiguous run of units instead -- a 2 MB page of text then serves it for 32 rounds)
+    const uint64_t per_wg = (P.n_units + gridDim.x - 1) / gridDim.x, run_lo = (uint64_t)blockIdx.x * per_wg;
+    auto unit_of = [&](uint32_t item) -> uint64_t {
+        if (P.s5_contig) return item < per_wg ? run_lo + item : ~(uint64_t)0;
+        return (uint64_t)(item / wg_waves) * round_units + wg_first + item % wg_waves;
+    };
+    uint64_t u = unit_of(wave), nu = 0;                           // wave-uniform
     Unit un_n{0, 0, 0};
     uint64_t abs_n = 0;
     if (u < P.n_units) { un_n = P.units[u]; abs_n = P.doc_off[un_n.doc]; }
-    // the first round of the next unit, requested in front of stage A (see the file comment); `have_pf` = pf_* belong to
-    // the unit that the next iteration works on
-    U128u pf_piece{0, 0, 0, 0}, pf_lead{0, 0, 0, 0};
-    uint32_t pf_hist = 0;
-    bool have_pf = false;
     for (; u < P.n_units; u = nu) {
         const Unit un{(uint32_t)__builtin_amdgcn_readfirstlane(un_n.doc), (uint32_t)__builtin_amdgcn_readfirstlane(un_n.lo),
                       (uint32_t)__builtin_amdgcn_readfirstlane(un_n.hi)};
@@ -263,141 +252,123 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
         mark(7);
         const bool more_units = nu < P.n_units;
         if (more_units) un_n = P.units[nu];
-        const Ctx c{P, cls, filt, nullptr, fpt, lrec, P.text + doc_abs, doc_abs, kp2,
-                    false, false, un.lo, un.hi, false, DBG ? P.dbg : 0u};
+        const Ctx c{P, cls, nullptr, P.short3_bytes ? short3 : nullptr, fpt, lrec, P.text + doc_abs, doc_abs, kp2,
+                    doc_abs < 7, doc_abs < 23, un.lo, un.hi, doc_abs + un.hi + 4 > P.text_bytes, DBG ? P.dbg : 0u};
         const uint32_t nborder = un.lo < kScan2MaxOff ? un.lo : kScan2MaxOff;
-        const uint32_t ubase = un.lo - kScan2MaxOff;               // candidate lists hold p - ubase
-        const uint32_t own = un.hi - un.lo;                        // <= s5_text_cap (the unit table is built with that limit)
-        const uint32_t nr = (own + 1023) >> 10;                    // rounds
-        Ctx5 o{tb + kScan5Lead - un.lo, P.s5_cells ? s3cell : nullptr, s3ids, fifo, P.s5_fifo_cap, 0, false, 0,
-               P.s5_term_bits, un.lo - P.s5_pos_bias};
+        const uint32_t ubase = un.lo - kScan2MaxOff;               // candidate lists hold p - ubase (may wrap; p never does)
+        const uint32_t own = un.hi - un.lo;
+        const uint32_t C = ((own + 63) / 64 + 3) & ~3u;            // bytes per lane (multiple of 4, <= 128)
+        const uint32_t my_lo = un.lo + lane * C;
+        const uint32_t my_hi = my_lo + C < un.hi ? my_lo + C : un.hi;
+        const uint32_t nvalid = my_lo < un.hi ? my_hi - my_lo : 0;
+        Ctx5 o{fifo, P.s5_fifo_cap, 0, 0, false, false, 0, P.s5_term_bits, un.lo - P.s5_pos_bias};
 
         // ---- FILTER -----------------------------------------------------------------------------------------------------
         if (P.prio) __builtin_amdgcn_s_setprio(0);
-        uint32_t m0 = 0, m1 = 0, m2 = 0;
+        uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
         if (own) {
-            const uint8_t* ubeg = c.dbase + un.lo;
-            const uint8_t* src = ubeg + lane * 16;
-            const uint64_t ab = doc_abs + un.lo;                   // blob offset of the unit's first byte
-            U128u nxt{0, 0, 0, 0}, lead{0, 0, 0, 0};
-            uint32_t hist = 0;
-            if (have_pf) { nxt = pf_piece; lead = pf_lead; hist = pf_hist; }
-            else {
-                if (lane * 16 < own) nxt = *reinterpret_cast<const U128u*>(src);
-                // the kScan5Lead bytes in front of the unit (the bytes of the document before it, or of the previous document:
-                // gft_scan2_dev.hpp cand_load; zeros in front of the blob) and, once more, the last four of them for the
-                // window that rolls into the unit
-                if (ab >= kScan5Lead) {
-                    if (lane < kScan5Lead / 16) lead = *reinterpret_cast<const U128u*>(ubeg - kScan5Lead + lane * 16);
-                    hist = load_u32_unaligned(ubeg - 4);
-                } else {
-                    uint32_t lw[4] = {0, 0, 0, 0};
-                    if (lane < kScan5Lead / 16)
-                        for (uint32_t i = 0; i < 16; i++) {
-                            const uint32_t back = kScan5Lead - (lane * 16 + i);      // this byte sits `back` bytes in front of the unit
-                            if (back <= ab) lw[i >> 2] |= (uint32_t)ubeg[-(int)back] << (8 * (i & 3));
-                        }
-                    lead = U128u{lw[0], lw[1], lw[2], lw[3]};
-                    for (uint32_t i = 1; i <= 3 && i <= ab; i++) hist |= (uint32_t)ubeg[-(int)i] << (32 - 8 * i);
-                }
+            // the groups of the three bytes in front of the lane's range (the pad group in front of the document)
+            uint32_t h1 = P.s5_pad_g, h2 = P.s5_pad_g, h3 = P.s5_pad_g, pq = 0;      // g[j-1], g[j-2], g[j-3]; pq = h2 * G + h1
+            (void)h2;
+            const uint8_t* src = c.dbase + my_lo;
+            U128u nxt{0, 0, 0, 0};
+            if (nvalid) {
+                uint32_t hist = 0;
+                if (doc_abs + my_lo >= 4) hist = load_u32_unaligned(src - 4);
+                else for (uint32_t i = 1; i <= 3 && i <= doc_abs + my_lo; i++) hist |= (uint32_t)src[-(int)i] << (32 - 8 * i);
+                nxt = *reinterpret_cast<const U128u*>(src);
+                if (my_lo >= 1) h1 = lgrp[hist >> 24];
+                if (my_lo >= 2) h2 = lgrp[(hist >> 16) & 0xFF];
+                if (my_lo >= 3) h3 = lgrp[(hist >> 8) & 0xFF];
             }
-            have_pf = false;
-            if (lane < kScan5Lead / 16) lds_store16(tb + lane * 16, lead.x, lead.y, lead.z, lead.w);
-            // the window that rolls into lane 0's first piece: groups of the three bytes in front of the unit (the pad group
-            // in front of the blob -- what precedes a document only matters to short terms, whose filter bits have every
-            // group in front of them)
-            const uint32_t pad_g = P.s5_pad_g;
-            const uint32_t k1 = ab >= 1 ? lgrp[hist >> 24] : pad_g, k2 = ab >= 2 ? lgrp[(hist >> 16) & 0xFF] : pad_g,
-                           k3 = ab >= 3 ? lgrp[(hist >> 8) & 0xFF] : pad_g;
-            uint32_t carry_g = __builtin_amdgcn_readfirstlane(k1);
-            uint32_t carry_p1 = __builtin_amdgcn_readfirstlane(mad24s(k2, G, k1));      // pair(lo-1)
-            uint32_t carry_p2 = __builtin_amdgcn_readfirstlane(mad24s(k3, G, k2));      // pair(lo-2)
+            pq = mad24s(h2, G, h1);
             mark(0);
-            uint32_t acc = 0, hib = 0;
-            for (uint32_t r = 0; r < nr; r++) {
+            uint32_t acc = 0, hib = 0;                           // hib: OR of the lane's text (a byte >= 0x80 anywhere?)
+            const uint32_t ndw = C >> 2;                         // dwords per lane (wave-uniform, <= 32)
+            const uint32_t npieces = (ndw + 3) >> 2;
+            for (uint32_t q = 0; q < npieces; q++) {
                 const uint32_t w[4] = {nxt.x, nxt.y, nxt.z, nxt.w};
-                const bool mine = r * 1024 + lane * 16 < own;
-                if (mine) hib |= (w[0] | w[1]) | (w[2] | w[3]);   // (up to 15 bytes behind the unit: conservative)
-                if (r + 1 < nr && (r + 1) * 1024 + lane * 16 < own) nxt = *reinterpret_cast<const U128u*>(src + (r + 1) * 1024);
-                // (the next unit's document offset: its record was requested at the top, the prefetch in front of stage A needs both)
-                if (r == 0 && more_units) abs_n = P.doc_off[un_n.doc];
-                lds_store16(tb + kScan5Lead + r * 1024 + lane * 16, w[0], w[1], w[2], w[3]);
-                uint32_t g[16];
+                if (q * 16 < nvalid) hib |= (w[0] | w[1]) | (w[2] | w[3]);   // (may take in up to 15 bytes behind the lane's range: conservative)
+                if (q + 1 < npieces && (q + 1) * 16 < nvalid) nxt = *reinterpret_cast<const U128u*>(src + (q + 1) * 16);
+                const uint32_t nd = ndw - 4 * q;                 // dwords of this piece that belong to the lane (>= 1)
+                // probe at byte 0 of a dword: 3-gram (h2, h1, c0); the window that ends there has h3 in front, the window that
+                // ends at byte 1 has c1 behind.  Probe at byte 2: 3-gram (c0, c1, c2), h1 in front, c3 behind
+                auto dword = [&](uint32_t wd) {
+                    const uint32_t c0 = lgrp[wd & 0xFF], c1 = lgrp[(wd >> 8) & 0xFF], c2 = lgrp[(wd >> 16) & 0xFF], c3 = lgrp[wd >> 24];
+                    const uint32_t xa = mad24s(pq, G, c0);
+                    const uint32_t xb = mad24s(mad24s(c0, G, c1), G, c2);
+                    const u32x2 fa = ldual[xa], fb = ldual[xb];
+                    acc = __builtin_amdgcn_alignbit(fa.x >> h3, acc, 1);
+                    acc = __builtin_amdgcn_alignbit(fa.y >> c1, acc, 1);
+                    acc = __builtin_amdgcn_alignbit(fb.x >> h1, acc, 1);
+                    acc = __builtin_amdgcn_alignbit(fb.y >> c3, acc, 1);
+                    pq = mad24s(c2, G, c3);
+                    h3 = c1; h2 = c2; h1 = c3;
+                };
+                if (nd >= 4) {                                   // a whole piece: sixteen lookups, then eight probes in flight together
+                    uint32_t cc[19];                             // cc[3 + i] = group of byte i; cc[0..2] = h3, h2, h1
+                    cc[0] = h3; cc[1] = h2; cc[2] = h1;
 #pragma unroll
-                for (int d = 0; d < 4; d++)
+                    for (int i = 0; i < 16; i++) cc[3 + i] = lgrp[(w[i >> 2] >> (8 * (i & 3))) & 0xFF];
+                    uint32_t xk[8];
+                    xk[0] = mad24s(pq, G, cc[3]);
 #pragma unroll
-                    for (int b = 0; b < 4; b++) g[4 * d + b] = lgrp[(w[d] >> (8 * b)) & 0xFF];
-                // the group in front of the lane's piece: the previous lane's last one (lane 0: the previous round's lane 63)
-                const uint32_t gin = (uint32_t)__builtin_amdgcn_update_dpp((int)carry_g, (int)g[15], 0x138, 0xF, 0xF, false);   // wave_shr:1
-                carry_g = __builtin_amdgcn_readlane(g[15], 63);
-                uint32_t pr[16];
-                pr[0] = mad24s(gin, G, g[0]);
+                    for (int t = 1; t < 8; t++) xk[t] = mad24s(mad24s(cc[1 + 2 * t], G, cc[2 + 2 * t]), G, cc[3 + 2 * t]);
+                    u32x2 fk[8];
 #pragma unroll
-                for (int i = 1; i < 16; i++) pr[i] = mad24s(g[i - 1], G, g[i]);
-                const uint32_t p1in = (uint32_t)__builtin_amdgcn_update_dpp((int)carry_p1, (int)pr[15], 0x138, 0xF, 0xF, false);
-                const uint32_t p2in = (uint32_t)__builtin_amdgcn_update_dpp((int)carry_p2, (int)pr[14], 0x138, 0xF, 0xF, false);
-                carry_p1 = __builtin_amdgcn_readlane(pr[15], 63);
-                carry_p2 = __builtin_amdgcn_readlane(pr[14], 63);
+                    for (int t = 0; t < 8; t++) fk[t] = ldual[xk[t]];
 #pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    const uint32_t x = mad24s(i == 0 ? p2in : i == 1 ? p1in : pr[i - 2], G2, pr[i]);
-                    const uint32_t fw = lfilt[x >> 5];
-                    acc = __builtin_amdgcn_alignbit(fw >> (x & 31), acc, 1);
+                    for (int t = 0; t < 8; t++) {
+                        acc = __builtin_amdgcn_alignbit(fk[t].x >> cc[2 * t], acc, 1);         // window ends at byte 2t: cc[2t] stands in front
+                        acc = __builtin_amdgcn_alignbit(fk[t].y >> cc[4 + 2 * t], acc, 1);     // ... at byte 2t + 1: that byte's group behind
+                    }
+                    pq = mad24s(cc[17], G, cc[18]);
+                    h3 = cc[16]; h2 = cc[17]; h1 = cc[18];
+                } else {
+                    dword(w[0]);
+                    if (nd >= 2) dword(w[1]);
+                    if (nd >= 3) dword(w[2]);
                 }
-                if (r == 1) m0 = acc; else if (r == 3) m1 = acc; else if (r == 5) m2 = acc;
+                if ((q & 1) && nd >= 4) {                        // 32 positions complete
+                    if ((q >> 1) == 0) m0 = acc; else if ((q >> 1) == 1) m1 = acc; else if ((q >> 1) == 2) m2 = acc; else m3 = acc;
+                }
             }
-            if (nr & 1) { const uint32_t v = acc >> 16; if (nr == 1) m0 = v; else if (nr == 3) m1 = v; else m2 = v; }
+            if (ndw & 7) {                                       // the last, partial group of 32 positions
+                const uint32_t v = acc >> (32 - 4 * (ndw & 7));
+                const uint32_t k = ndw >> 3;
+                if (k == 0) m0 = v; else if (k == 1) m1 = v; else if (k == 2) m2 = v; else m3 = v;
+            }
+            // ASCII folding is not strings.ToLower once the text leaves ASCII (finder.go:140-142): tell the host
             if (P.fold && P.nonascii && !told_nonascii && __any((hib & 0x80808080u) != 0)) {
                 told_nonascii = true;
                 if (lane == 0 && !(__hip_atomic_fetch_or(wg_next + 1, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 31))
                     atomicOr(P.nonascii, 1u);
             }
-            // positions of the last round at or beyond the unit's end carry garbage flags
-            {
-                const uint32_t lr = nr - 1;
-                const int32_t avail = (int32_t)own - (int32_t)(lr * 1024 + lane * 16);
-                const uint32_t vr = avail <= 0 ? 0u : avail >= 16 ? 16u : (uint32_t)avail;
-                const uint32_t keep = ~((0xFFFFu & ~((1u << vr) - 1u)) << (16 * (lr & 1)));
-                if ((lr >> 1) == 0) m0 &= keep; else if ((lr >> 1) == 1) m1 &= keep; else m2 &= keep;
-            }
+            // positions past the lane's range carry garbage flags
+            m0 = nvalid >= 32 ? m0 : (nvalid ? m0 & ((1u << nvalid) - 1) : 0);
+            m1 = nvalid >= 64 ? m1 : (nvalid > 32 ? m1 & ((1u << (nvalid - 32)) - 1) : 0);
+            m2 = nvalid >= 96 ? m2 : (nvalid > 64 ? m2 & ((1u << (nvalid - 64)) - 1) : 0);
+            m3 = nvalid >= 128 ? m3 : (nvalid > 96 ? m3 & ((1u << (nvalid - 96)) - 1) : 0);
         }
         mark(1);
         if (P.prio) __builtin_amdgcn_s_setprio(1);
-        if (!own && more_units) abs_n = P.doc_off[un_n.doc];
+        if (more_units) abs_n = P.doc_off[un_n.doc];
 
         if (DBG && P.dbg) {
             if (P.dbg & 2) {
-                uint32_t f = __popc(m0) + __popc(m1) + __popc(m2);
+                uint32_t f = __popc(m0) + __popc(m1) + __popc(m2) + __popc(m3);
                 for (int s = 32; s; s >>= 1) f += __shfl_xor(f, s, 64);
                 if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(KARG(dbg_counters)), (unsigned long long)f);
             }
-            if (P.dbg & 1) m0 = m1 = m2 = 0;
+            if (P.dbg & 1) m0 = m1 = m2 = m3 = 0;
         }
 
         // ---- VERIFY: balance the flagged positions over the lanes through an LDS candidate list ---------------------------
-        const uint32_t f = __popc(m0) + __popc(m1) + __popc(m2) + (lane == 0 ? nborder : 0);
+        const uint32_t f = __popc(m0) + __popc(m1) + __popc(m2) + __popc(m3) + (lane == 0 ? nborder : 0);
         const uint32_t fincl = wave_incl_scan(f);
         const uint32_t ftotal = lane_value(fincl, 63);
-        wave_lds_sync();                                           // the text buffer is complete
-        // the next unit's first round goes out now: stage A below touches LDS only
-        if (P.s5_prefetch && more_units) {
-            const Unit nn{(uint32_t)__builtin_amdgcn_readfirstlane(un_n.doc), (uint32_t)__builtin_amdgcn_readfirstlane(un_n.lo),
-                          (uint32_t)__builtin_amdgcn_readfirstlane(un_n.hi)};
-            const uint64_t nabs = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(abs_n >> 32)) << 32 |
-                                  (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)abs_n);
-            const uint64_t nab = nabs + nn.lo;
-            if (nn.hi > nn.lo && nab >= kScan5Lead) {              // (a unit at the very start of the blob loads its own bytes)
-                const uint8_t* nbeg = P.text + nab;
-                pf_piece = U128u{0, 0, 0, 0};
-                if (lane * 16 < nn.hi - nn.lo) pf_piece = *reinterpret_cast<const U128u*>(nbeg + lane * 16);
-                pf_lead = U128u{0, 0, 0, 0};
-                if (lane < kScan5Lead / 16) pf_lead = *reinterpret_cast<const U128u*>(nbeg - kScan5Lead + lane * 16);
-                pf_hist = load_u32_unaligned(nbeg - 4);
-                have_pf = true;
-            }
-        }
         for (uint32_t walk = 0; walk < 2 && ftotal; walk++) {
-            o.nf = 0;
+            o.nf = 0; o.npend = 0; o.lost = false;
             for (uint32_t l0 = 0; l0 < 64;) {
                 const uint32_t before = l0 ? lane_value(fincl, l0 - 1) : 0;
                 const bool fits = lane >= l0 && fincl - before <= P.cand_cap;
@@ -407,18 +378,17 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
                 const uint32_t ptotal = lane_value(fincl, l1 - 1) - before;
                 if (lane >= l0 && lane < l1) {
                     uint32_t wpos = fincl - f - before;
-                    const uint32_t rel = lane * 16 + kScan2MaxOff;
+                    const uint32_t rel = lane * C + kScan2MaxOff;
                     if (lane == 0)
                         for (uint32_t i = 0; i < nborder; i++) cand[wpos++] = (uint16_t)(kScan2MaxOff - nborder + i);
-                    uint32_t mm[3] = {m0, m1, m2};
+                    uint32_t mm[4] = {m0, m1, m2, m3};
 #pragma unroll
-                    for (int k = 0; k < 3; k++) {
+                    for (int k = 0; k < 4; k++) {
                         uint32_t mk = mm[k];
                         while (mk) {
                             const uint32_t i = __builtin_ctz(mk);
                             mk &= mk - 1;
-                            // bit i of mask k: round 2 k + (i >> 4), byte i & 15 of the lane's piece
-                            cand[wpos++] = (uint16_t)(rel + 2048 * k + ((i & 16) << 6) + (i & 15));
+                            cand[wpos++] = (uint16_t)(rel + 32 * k + i);
                         }
                     }
                 }
@@ -439,7 +409,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
                         n_rel[q] = cand[n_on[q] ? i : 0];
                     }
 #pragma unroll
-                    for (int q = 0; q < kStageAWays; q++) n_tx[q] = text8(o.tq, ubase + n_rel[q]);
+                    for (int q = 0; q < kStageAWays; q++) n_tx[q] = cand_load(c, ubase + n_rel[q]);
                 };
                 fetch(0);
                 for (uint32_t i0 = 0; i0 < ptotal; i0 += 64 * kStageAWays) {
@@ -451,13 +421,13 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
                     for (int q = 0; q < kStageAWays; q++) { on[q] = n_on[q]; rel[q] = n_rel[q]; tx[q] = n_tx[q]; }
                     if (i0 + 64 * kStageAWays < ptotal) fetch(i0 + 64 * kStageAWays);
 #pragma unroll
-                    for (int q = 0; q < kStageAWays; q++) cand_keys5<true>(c, o, ubase + rel[q], tx[q], k[q]);
+                    for (int q = 0; q < kStageAWays; q++) cand_keys(c, ubase + rel[q], tx[q], k[q]);
 #pragma unroll
                     for (int q = 0; q < kStageAWays; q++) cand_decide<FPT_LDS>(c, k[q]);
 #pragma unroll
                     for (int q = 0; q < kStageAWays; q++)
                         if (i0 + 64 * q < ptotal)                  // (positions in front of the unit: long terms only)
-                            finish_short5(c, o, k[q].p, on[q] && rel[q] >= kScan2MaxOff ? k[q].sid : 0, k[q].x3);
+                            park_short(c, o, ubase, rel[q], on[q] && rel[q] >= kScan2MaxOff ? k[q].sid : 0, k[q].x3);
                     const uint64_t below = (1ull << lane) - 1;
 #pragma unroll
                     for (int q = 0; q < kStageAWays; q++) {
@@ -468,6 +438,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
                     }
                 }
                 wave_lds_sync();
+                while (o.npend) short_trip(c, o, ubase, o.npend < 64 ? o.npend : 64);
                 if (DBG && (P.dbg & 2)) { if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(KARG(dbg_counters) + 2), (unsigned long long)ns); }
                 mark(3);
                 if (P.prio) __builtin_amdgcn_s_setprio(3);
@@ -480,9 +451,9 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
                     const bool on = i0 + lane < ns;
                     const uint32_t rel = cand[on ? i0 + lane : 0];
                     const uint32_t p = ubase + rel;
-                    const Text8 t8 = text8(o.tq, p);
-                    const Front fr = front5(o.tq, p, t8.tw);
-                    const uint32_t tl5 = tail5(o.tq, p);
+                    const Text8 t8 = cand_load(c, p);
+                    const Front fr = front_load(c, p, t8.tw);
+                    const uint32_t tl5 = tail_load(c, p);
                     Cand k;
                     cand_keys<false>(c, p, t8, k);
                     const Slot s0 = slot_load(&P.slots[scan2_slot_hash(k.x, 0, P.slot_shift, P.slot_seed)]);
@@ -494,7 +465,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
                 l0 = l1;
                 mark(4);
             }
-            if (o.direct || o.nf <= o.fifo_cap) break;
+            if (o.direct || !o.lost) break;
             // the unit's matches outgrew the fifo: their number is known now -- walk it again into a region of that size
             {
                 const uint32_t nh = o.nf;
@@ -529,6 +500,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
                 const uint32_t tmask = (1u << o.term_bits) - 1u;
                 for (uint32_t i = lane; i < nh; i += 64) {
                     const uint32_t e = fifo[i];
+                    // (streaming stores: the pool is read by the NEXT kernel, its lines should not push the units' text out of L2)
                     if (P.want_pos) {
                         __builtin_nontemporal_store(e & tmask, &KARG(pool_term)[base + i]);
                         __builtin_nontemporal_store(o.pos_base + (e >> o.term_bits), &KARG(pool_pos)[base + i]);
@@ -564,39 +536,37 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
 
 }  // namespace
 
-static size_t scan5_fixed_lds(uint32_t filter_words, uint32_t cells, uint32_t ids, uint32_t shorts_words, uint32_t fpt_lds_bytes) {
-    return ((512 + (size_t)filter_words * 4 + (size_t)cells * 8 + ((ids + 3) & ~3u) + fpt_lds_bytes + (size_t)shorts_words * 4 + 15) & ~(size_t)15) + 16;
+static size_t scan5_fixed_lds(uint32_t dual_entries, uint32_t short3_bytes, uint32_t shorts_words, uint32_t fpt_lds_bytes) {
+    return ((512 + (size_t)dual_entries * 8 + short3_bytes + fpt_lds_bytes + (size_t)shorts_words * 4 + 15) & ~(size_t)15) + 16;
 }
-static size_t scan5_wave_lds(uint32_t text_cap, uint32_t fifo_cap, uint32_t cand_cap) {
-    return kScan5Lead + text_cap + 16 + (size_t)fifo_cap * 4 + (((size_t)cand_cap * 2 + 15) & ~(size_t)15);
+static size_t scan5_wave_lds(uint32_t fifo_cap, uint32_t cand_cap) {
+    return (size_t)fifo_cap * 4 + (((size_t)cand_cap * 2 + 15) & ~(size_t)15);
 }
 
-bool scan5_plan(uint32_t kp, uint32_t cells, uint32_t ids, uint32_t shorts_words, uint32_t fpt_lds_bytes, size_t lds_max, Scan5Plan* out) {
-    // whole rounds of text first (a document that does not fit a unit costs a second unit's fixed work), then as many
-    // filter groups as fit (every merged class flags more positions: tools/sim)
+bool scan5_plan(uint32_t kp, uint32_t short3_bytes, uint32_t shorts_words, uint32_t fpt_lds_bytes, size_t lds_max, Scan5Plan* out) {
+    // as many filter groups as fit next to a candidate list of kScan5CandCapMin entries (every merged class flags more
+    // positions: tools/sim); what is left goes to the list
     const uint32_t g_hi = kp < kScan5MaxGroups ? kp : kScan5MaxGroups;
     const uint32_t g_lo = g_hi > 8 + 12 ? g_hi - 8 : (g_hi < 12 ? g_hi : 12);
-    for (uint32_t rounds = kScan5MaxRounds; rounds >= 2; rounds--)
-        for (uint32_t G = g_hi; G >= g_lo; G--) {
-            const uint64_t bits = (uint64_t)G * G * G * G;
-            const uint32_t fw = (uint32_t)((bits + 63) / 64 * 2);
-            const size_t fixed = scan5_fixed_lds(fw, cells, ids, shorts_words, fpt_lds_bytes);
-            const size_t need = fixed + (size_t)kScan5Waves * scan5_wave_lds(rounds * 1024, kScan2FifoCap, kScan5CandCapMin);
-            if (need > lds_max) continue;
-            size_t spare = (lds_max - need) / kScan5Waves / 2 & ~(size_t)7;      // entries the candidate list can grow by
-            out->G = G; out->rounds = rounds; out->filter_words = fw;
-            out->cand_cap = (uint32_t)std::min<size_t>(kScan5CandCapMin + spare, 1024);
-            out->fifo_cap = kScan2FifoCap;
-            return true;
-        }
+    for (uint32_t G = g_hi; G >= g_lo; G--) {
+        const uint32_t ent = G * G * G;
+        const size_t fixed = scan5_fixed_lds(ent, short3_bytes, shorts_words, fpt_lds_bytes);
+        const size_t need = fixed + (size_t)kScan5Waves * scan5_wave_lds(kScan2FifoCap, kScan5CandCapMin);
+        if (need > lds_max) continue;
+        const size_t spare = ((lds_max - need) / kScan5Waves / 2) & ~(size_t)7;      // entries the candidate list can grow by
+        out->G = G; out->dual_entries = ent;
+        out->cand_cap = (uint32_t)std::min<size_t>(kScan5CandCapMin + spare, 2048);
+        out->fifo_cap = kScan2FifoCap;
+        return true;
+    }
     return false;
 }
 
 hipError_t launch_scan5(const Scan2Params& P, unsigned n_cus, hipStream_t st) {
     if (!P.n_units) return hipSuccess;
     const bool fl = P.fpt_lg == 0;
-    const size_t lds = scan5_fixed_lds(P.filter_words, P.s5_cells, P.s5_ids, P.shorts_words, fl ? kScan2FptSize : 0) +
-                       (size_t)kScan5Waves * scan5_wave_lds(P.s5_text_cap, P.s5_fifo_cap, P.cand_cap);
+    const size_t lds = scan5_fixed_lds(P.s5_dual, P.short3_bytes, P.shorts_words, fl ? kScan2FptSize : 0) +
+                       (size_t)kScan5Waves * scan5_wave_lds(P.s5_fifo_cap, P.cand_cap);
     using Kern = void (*)(const Scan2Params);
     const Kern fn = P.dbg ? (fl ? k_scan5<true, true> : k_scan5<false, true>) : (fl ? k_scan5<true, false> : k_scan5<false, false>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

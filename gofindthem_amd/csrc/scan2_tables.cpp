@@ -264,13 +264,6 @@ void build_scan2_tables(const AcTables& ac, Scan2Tables& t) {
 
 namespace gft {
 
-void scan5_short_sizes(const Scan2Tables& s2, uint32_t* cells, uint32_t* ids) {
-    uint32_t n = 0;
-    for (uint8_t b : s2.short3) n += b != 0;
-    *cells = s2.short3.empty() ? 0u : (uint32_t)((s2.short3.size() + 31) / 32);
-    *ids = n;
-}
-
 void build_scan5_tables(const AcTables& ac, const Scan2Tables& s2, uint32_t G, Scan5Tables& t) {
     t = Scan5Tables();
     const uint32_t kp = s2.kp;
@@ -299,29 +292,15 @@ void build_scan5_tables(const AcTables& ac, const Scan2Tables& s2, uint32_t G, S
     }
     t.pad_group = group_of[s2.pad_class];
     for (int b = 0; b < 256; b++) { t.grp[b] = (uint8_t)group_of[s2.cls[b]]; t.grp_fold[b] = (uint8_t)group_of[s2.cls_fold[b]]; }
-    // every window the exact filter flags, in group space
-    const uint64_t bits = (uint64_t)G * G * G * G;
-    t.filter.assign((size_t)((bits + 63) / 64 * 2), 0);
+    // every window (a, b, c, d) the exact filter flags, in group space, under both of its 3-grams
+    t.filter.assign((size_t)G * G * G, 0);
     const uint64_t kbits = (uint64_t)kp * kp * kp * kp;
     for (uint64_t key = 0; key < kbits && !s2.hashed; key++) {
         if (!(s2.filter[key >> 5] >> (key & 31) & 1)) continue;
-        const uint32_t c3 = (uint32_t)(key % kp), c2 = (uint32_t)(key / kp % kp), c1 = (uint32_t)(key / ((uint64_t)kp * kp) % kp),
-                       c0 = (uint32_t)(key / ((uint64_t)kp * kp * kp));
-        const uint64_t gk = (((uint64_t)group_of[c0] * G + group_of[c1]) * G + group_of[c2]) * G + group_of[c3];
-        t.filter[gk >> 5] |= 1u << (gk & 31);
-    }
-    // short terms: bit per exact 3-window, rank -> record id
-    uint32_t cells = 0, n_ids = 0;
-    scan5_short_sizes(s2, &cells, &n_ids);
-    t.cell.assign(cells, 0);
-    t.ids.reserve(n_ids);
-    for (uint32_t cidx = 0; cidx < cells; cidx++) {
-        uint64_t v = (uint64_t)t.ids.size() << 32;
-        for (uint32_t b = 0; b < 32; b++) {
-            const size_t w = (size_t)cidx * 32 + b;
-            if (w < s2.short3.size() && s2.short3[w]) { v |= 1ull << b; t.ids.push_back(s2.short3[w]); }
-        }
-        t.cell[cidx] = v;
+        const uint32_t d = group_of[key % kp], c = group_of[key / kp % kp], b = group_of[key / ((uint64_t)kp * kp) % kp],
+                       a = group_of[key / ((uint64_t)kp * kp * kp)];
+        t.filter[((size_t)b * G + c) * G + d] |= 1ull << a;
+        t.filter[((size_t)a * G + b) * G + c] |= 1ull << (32 + d);
     }
 }
 

@@ -61,18 +61,15 @@ constexpr uint32_t kGold = kGoldDev;
 
 void build_scan2_tables(const AcTables& ac, Scan2Tables& out);
 
-// What gft_scan5.hip needs on top of Scan2Tables (derived, never serialised): the filter over G merged byte classes and
-// the short-term table as a bitmap with ranks.
+// What gft_scan5.hip needs on top of Scan2Tables (derived, never serialised): the filter over 3-grams of G merged byte
+// classes (one probe answers two end positions).
 struct Scan5Tables {
     uint32_t G = 0, pad_group = 0;
     uint8_t grp[256];                // byte -> filter group
     uint8_t grp_fold[256];           // ... of its ASCII lower-case form
-    std::vector<uint32_t> filter;    // G^4 bits (an even number of words)
-    std::vector<uint64_t> cell;      // per 32 consecutive 3-windows (exact classes): bits | rank of the first set one << 32
-    std::vector<uint8_t> ids;        // Scan2Tables::short3 of the set cells, in rank order
+    std::vector<uint64_t> filter;    // [G^3] per 3-gram (b, c, d) of groups: bit a = (a, b, c, d) is flagged by Scan2Tables::filter;
+                                     // bit 32 + e = (b, c, d, e) is
 };
-// cells / ids of a dictionary's short-term bitmap (what scan5_plan needs before G is known)
-void scan5_short_sizes(const Scan2Tables& s2, uint32_t* cells, uint32_t* ids);
 // G <= s2.kp groups: the classes that are rare in the dictionary share groups (longest-processing-time rule), class 0
 // ("other": every byte that no term has, and what stands in front of the blob) keeps one of its own
 void build_scan5_tables(const AcTables& ac, const Scan2Tables& s2, uint32_t G, Scan5Tables& out);

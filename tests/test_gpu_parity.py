@@ -480,13 +480,13 @@ def test_streaming_kernel_chunks_of_eight_units_and_regions_that_overflow(monkey
         e.close()
 
 
-def test_text_in_lds_kernel_rounds_second_walks_and_merged_groups(monkeypatch):
-    """gft_scan5: units of one to five rounds of 1 KiB (documents that end inside a round, on a round, slices of long
-    documents, empty documents, a first document whose positions lie within the buffer's lead of the blob start); a
-    dictionary that matches at every position outgrows the 256-entry fifo in every unit -- each is then walked a second
-    time straight into a pool region of the counted size; GFT_SCAN5_GROUPS=4 merges the byte classes far beyond what LDS
-    asks for (the filter then flags nearly everything: exactness must come from the stages behind it).  Both position
-    conventions, positions packed into the fifo entry next to the term id."""
+def test_two_positions_per_probe_kernel_second_walks_and_merged_groups(monkeypatch):
+    """gft_scan5: one filter probe per two bytes over 3-grams of merged byte classes.  Documents of every length around the
+    lane and piece borders (a lane owns a multiple of four bytes, a probe pair never leaves its dword), slices of long
+    documents, empty documents; a dictionary that matches at every position outgrows the 256-entry fifo in every unit --
+    each is then walked a second time straight into a pool region of the counted size; GFT_SCAN5_GROUPS=4 merges the byte
+    classes far beyond what LDS asks for (the filter then flags nearly everything: exactness must come from the stages
+    behind it).  Both position conventions, positions packed into the fifo entry next to the term id."""
     from gofindthem_amd.engine import Engine
     from gofindthem_amd import _lib
     monkeypatch.setenv("GFT_SCAN_KERNEL", "scan5")

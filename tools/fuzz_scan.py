@@ -69,7 +69,7 @@ def one_process(eng, seed, it):
         terms.add(A[rng.integers(0, len(alpha), int(rng.integers(1, maxlen + 1)))].tobytes())
     tl = sorted(terms)
     pos_mode = POS_END if rng.integers(2) else POS_START
-    os.environ["GFT_SCAN_KERNEL"] = ["auto", "scan2", "scan3", "scan4", "scan4"][int(rng.integers(5))]     # (auto: the library's own choice)
+    os.environ["GFT_SCAN_KERNEL"] = ["auto", "scan2", "scan3", "scan4", "scan5"][int(rng.integers(5))]     # (auto: the library's own choice)
     os.environ.pop("GFT_SCAN_ORDERED", None)
     g = [None, None, "32", "16", "8", "0"][int(rng.integers(6))]
     if g is None:
@@ -147,9 +147,9 @@ def one(eng, seed, it):
         terms.add(A[rng.integers(0, len(alpha), L)].tobytes())
     fold = bool(rng.integers(2)) and not any(65 <= b <= 90 for t in terms for b in t)   # folding needs lower-case terms
     pos_mode = POS_END if rng.integers(2) else POS_START
-    variant = ["", "ordered", "dfa", "scan3", "scan2"][int(rng.choice([0, 0, 1, 2, 3, 3, 3, 4]))]
+    variant = ["", "ordered", "dfa", "scan3", "scan2", "scan5"][int(rng.choice([0, 0, 1, 2, 3, 3, 4, 5, 5]))]
     os.environ.pop("GFT_SCAN_ORDERED", None)
-    os.environ["GFT_SCAN_KERNEL"] = {"dfa": "dfa", "scan3": "scan3", "scan2": "scan2", "ordered": "scan2", "scan4": "scan4"}.get(variant, "auto")
+    os.environ["GFT_SCAN_KERNEL"] = {"dfa": "dfa", "scan3": "scan3", "scan2": "scan2", "ordered": "scan2", "scan4": "scan4", "scan5": "scan5"}.get(variant, "auto")
     if variant == "ordered":
         os.environ["GFT_SCAN_ORDERED"] = "1"
     tl = sorted(terms)

@@ -104,6 +104,7 @@ struct gft_engine {
     // a scan launched without knowing the unit count / pool need (gft_process*: one read-back per batch, after the solver)
     bool deferred = false;
     uint64_t deferred_unit_cap = 0;
+    uint32_t last_nonascii_bits = 0;                    // what the scan kernels said: 1 = bytes >= 0x80 seen, not judged; 2 = judged unsafe
     bool last_nonascii = false;                         // the last GFT_FOLD_ASCII scan ran over text that ASCII folding does not
                                                         // lower-case the way strings.ToLower does (gft_last_nonascii)
     uint64_t last_text_lo = 0, last_text_hi = 0;        // text range of the last scan
@@ -644,7 +645,7 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         HIP_TRY(hipStreamSynchronize(st), "scan kernel");
         const uint64_t cursor = ct[0] + e->last_static_slabs;
         total = ct[1];
-        e->last_nonascii = (uint32_t)ct[2] != 0;
+        e->last_nonascii_bits = (uint32_t)ct[2]; e->last_nonascii = e->last_nonascii_bits != 0;
         if (cursor <= e->pool_cap) break;
         if (attempt == 2) return fail(e, GFT_E_HIP, "match pool overflow persisted");
         rc = ensure_pool(e, cursor + cursor / 16);
@@ -757,7 +758,7 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         HIP_TRY(hipStreamSynchronize(st), "scan kernel");
         const uint64_t cursor = ct[0] + e->last_static_slabs;
         total = ct[1];
-        e->last_nonascii = (uint32_t)ct[2] != 0;
+        e->last_nonascii_bits = (uint32_t)ct[2]; e->last_nonascii = e->last_nonascii_bits != 0;
         if (P.dbg & 2) {
             uint64_t c4[4] = {0, 0, 0, 0};
             HIP_TRY(hipMemcpy(c4, e->d_dbg.p, 32, hipMemcpyDeviceToHost), "debug readback");
@@ -805,7 +806,7 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         HIP_TRY(hipMemcpyAsync(ct, e->d_ctl.as<uint8_t>() + 8, 24, hipMemcpyDeviceToHost, st), "readback");
         HIP_TRY(hipStreamSynchronize(st), "scan kernel");
         total = ct[0];
-        e->last_nonascii = (uint32_t)ct[2] != 0;
+        e->last_nonascii_bits = (uint32_t)ct[2]; e->last_nonascii = e->last_nonascii_bits != 0;
         if (total <= e->pool_cap) break;
         if (attempt == 2) return fail(e, GFT_E_HIP, "match pool overflow persisted");
         rc = ensure_pool(e, total + total / 16);
@@ -831,7 +832,7 @@ int deferred_check(gft_engine* e, bool* again) {
     HIP_TRY(hipMemcpyAsync(rb, e->d_ctl.p, 7 * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream), "readback");
     HIP_TRY(hipStreamSynchronize(e->stream), "process pipeline");
     const uint64_t cursor = rb[1] + e->last_static_slabs, total = rb[2], n_units = rb[4], text_lo = rb[5], text_hi = rb[6];
-    e->last_nonascii = (uint32_t)rb[3] != 0;
+    e->last_nonascii_bits = (uint32_t)rb[3]; e->last_nonascii = e->last_nonascii_bits != 0;
     if (e->deferred_single && (uint32_t)(rb[3] >> 32)) {         // a document of more than one unit: the general path
         e->single_streak = -8;
         *again = true;
@@ -861,13 +862,16 @@ int deferred_check(gft_engine* e, bool* again) {
 
 // A folded scan that met bytes >= 0x80: is ASCII folding still the whole of strings.ToLower for this text (k_fold_safe)?
 // One more pass over the text and one more read-back, for such batches only.
-int refine_nonascii(gft_engine* e, const uint8_t* d_text, uint32_t flags) {
+int refine_nonascii(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_off, uint64_t n_docs, uint32_t flags) {
     if (!(flags & GFT_FOLD_ASCII)) { e->last_nonascii = false; return GFT_OK; }
     if (!e->last_nonascii) return GFT_OK;
+    // (gft_scan3 / gft_scan5 judge the pieces that hold high bytes themselves -- gft_foldsafe_dev.hpp -- and say "unsafe"
+    // or nothing; the other kernels only say that they saw some)
+    if (!(e->last_nonascii_bits & 1u)) { e->last_nonascii = (e->last_nonascii_bits & 2u) != 0; return GFT_OK; }
     uint32_t flag = 0;
     {
         ProfScope ps(e, "aux");
-        HIP_TRY(launch_fold_safe(d_text, e->last_text_lo, e->last_text_hi, e->d_ctl.as<uint32_t>() + 6, e->stream), "fold check");
+        HIP_TRY(launch_fold_safe(d_text, e->last_text_lo, e->last_text_hi, d_doc_off, n_docs, e->d_ctl.as<uint32_t>() + 6, e->stream), "fold check");
     }
     HIP_TRY(hipMemcpyAsync(&flag, e->d_ctl.as<uint32_t>() + 6, 4, hipMemcpyDeviceToHost, e->stream), "readback");
     HIP_TRY(hipStreamSynchronize(e->stream), "fold check");
@@ -1574,7 +1578,7 @@ int gft_scan_device(gft_engine* e, const uint8_t* d_text_blob, const uint64_t* d
         if (e->build_flags & GFT_POS_END) return fail(e, GFT_E_UNSUPPORTED, "GFT_POS_RUNES needs a GFT_POS_START engine (AnknownEngine reports where a match begins)");
         if ((rc = rune_pipeline(e, d_text_blob, d_doc_off, n_docs, nm))) return rc;
     }
-    if ((rc = refine_nonascii(e, d_text_blob, flags))) return rc;
+    if ((rc = refine_nonascii(e, d_text_blob, d_doc_off, n_docs, flags))) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream), "scan pipeline");
     out_dev->n_docs = n_docs; out_dev->n_matches = nm;
     out_dev->match_off = e->d_match_off.as<uint64_t>();
@@ -1699,7 +1703,7 @@ int gft_scan(gft_engine* e, const uint8_t* text_blob, const uint64_t* doc_off, u
         if (e->build_flags & GFT_POS_END) return fail(e, GFT_E_UNSUPPORTED, "GFT_POS_RUNES needs a GFT_POS_START engine (AnknownEngine reports where a match begins)");
         if ((rc = rune_pipeline(e, e->d_text.as<uint8_t>(), e->d_doc_off.as<uint64_t>(), n_docs, nm))) return rc;
     }
-    if ((rc = refine_nonascii(e, e->d_text.as<uint8_t>(), flags))) return rc;
+    if ((rc = refine_nonascii(e, e->d_text.as<uint8_t>(), e->d_doc_off.as<uint64_t>(), n_docs, flags))) return rc;
     e->h_match_off.assign(n_docs + 1, 0);
     e->h_term.assign(nm, 0);
     e->h_pos.assign(nm, 0);
@@ -1919,7 +1923,7 @@ int gft_process_device(gft_engine* e, const uint8_t* d_text_blob, const uint64_t
         if (!again) break;
     }
     HIP_TRY(hipStreamSynchronize(e->stream), "process pipeline");
-    int rc = refine_nonascii(e, d_text_blob, flags);
+    int rc = refine_nonascii(e, d_text_blob, d_doc_off, n_docs, flags);
     if (rc) return rc;
     return host_eval(e, want_hx ? &hx : nullptr, n_docs, plan, nullptr, d_hit_bitmap);
 } GFT_CATCH((e ? &e->err : nullptr))
@@ -2009,7 +2013,7 @@ int gft_process(gft_engine* e, const uint8_t* text_blob, const uint64_t* doc_off
     e->scan_valid_docs = n_docs;          // gft_process_again may reuse this scan
     rc = solve_pipeline(e, n_docs, pdx, e->d_bitmap.as<uint32_t>());
     if (rc) return rc;
-    if ((rc = refine_nonascii(e, e->d_text.as<uint8_t>(), flags))) return rc;
+    if ((rc = refine_nonascii(e, e->d_text.as<uint8_t>(), e->d_doc_off.as<uint64_t>(), n_docs, flags))) return rc;
     since("scanned and solved");
     if (n_docs * words) {
         if (!hit_bitmap) return fail(e, GFT_E_INVALID, "null bitmap");
@@ -2291,6 +2295,9 @@ struct ExtraSlice {
 int multi_process(gft_engine* e, const uint8_t* text_blob, const uint64_t* doc_off, uint64_t n_docs, uint32_t flags,
                   const gft_extra_matches* extra, uint32_t* hit_bitmap) {
     const size_t n = e->peers.size() + 1;
+    // (an empty batch may come without offsets, as on a single device: every shard then is [0, 0) of this one entry)
+    static const uint64_t kNoDocs[1] = {0};
+    if (n_docs == 0) doc_off = kNoDocs;
     split_by_bytes(doc_off, n_docs, n, e->shard_cut);
     const uint64_t words = (e->n_exprs + 31) / 32;
     e->last_nonascii = false;
@@ -2323,6 +2330,8 @@ int multi_process_again(gft_engine* e, uint64_t n_docs, const gft_extra_matches*
 
 int multi_scan(gft_engine* e, const uint8_t* text_blob, const uint64_t* doc_off, uint64_t n_docs, uint32_t flags, gft_matches* out) {
     const size_t n = e->peers.size() + 1;
+    static const uint64_t kNoDocs[1] = {0};
+    if (n_docs == 0) doc_off = kNoDocs;                  // (see multi_process)
     std::vector<uint64_t> cut;
     split_by_bytes(doc_off, n_docs, n, cut);
     std::vector<gft_matches> part(n);

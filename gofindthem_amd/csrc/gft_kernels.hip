@@ -535,6 +535,21 @@ __global__ void __launch_bounds__(256) k_fold_safe(const uint8_t* __restrict__ t
     }
     if (__any(bad) && (threadIdx.x & 63u) == 0) atomicOr(flag, 2u);
 }
+// ... and documents are lower-cased one by one: a pair that k_fold_safe accepts across a document border is a lead byte
+// without continuation in one document and a continuation byte without lead in the next
+__global__ void __launch_bounds__(256) k_fold_doc_edges(const uint8_t* __restrict__ text, const uint64_t* __restrict__ doc_off, uint64_t n_docs,
+                                                        uint32_t* __restrict__ flag) {
+    const uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool bad = false;
+    if (d < n_docs) {
+        const uint64_t a = doc_off[d], b = doc_off[d + 1];
+        if (b > a) {
+            const uint32_t first = text[a], last = text[b - 1];
+            bad = (first & 0xC0u) == 0x80u || last == 0xC2u || last == 0xC3u;
+        }
+    }
+    if (__any(bad) && (threadIdx.x & 63u) == 0) atomicOr(flag, 2u);
+}
 
 // ---- rune offsets (GFT_POS_RUNES): AnknownEngine reports Position over []rune(text) (finder/substringEngine.go:44-53) ----
 // A byte starts a rune of Go's decoder (range over a string: utf8.DecodeRuneInString, an invalid byte is one U+FFFD of
@@ -695,11 +710,12 @@ hipError_t launch_gather(const uint64_t* d_unit_start, const uint32_t* d_unit_co
     return hipGetLastError();
 }
 
-hipError_t launch_fold_safe(const uint8_t* d_text, uint64_t lo, uint64_t hi, uint32_t* d_flag, hipStream_t st) {
+hipError_t launch_fold_safe(const uint8_t* d_text, uint64_t lo, uint64_t hi, const uint64_t* d_doc_off, uint64_t n_docs, uint32_t* d_flag, hipStream_t st) {
     if (hi <= lo) return hipSuccess;
     const uint64_t a0 = ((uint64_t)(uintptr_t)d_text + lo) & ~(uint64_t)15, a1 = (uint64_t)(uintptr_t)d_text + hi;
     const uint64_t n = (a1 - a0 + 15) / 16;
     k_fold_safe<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(d_text, lo, hi, d_flag);
+    if (d_doc_off && n_docs) k_fold_doc_edges<<<dim3((unsigned)((n_docs + 255) / 256)), dim3(256), 0, st>>>(d_text, d_doc_off, n_docs, d_flag);
     return hipGetLastError();
 }
 

@@ -389,8 +389,8 @@ hipError_t launch_gather(const uint64_t* d_unit_start, const uint32_t* d_unit_co
                          uint32_t* d_pos, const uint64_t* d_unit_base, uint64_t n_docs, uint64_t* d_match_off,
                          unsigned n_cus, hipStream_t st, const Unit* d_units_to_sort = nullptr,
                          const uint32_t* d_term_len = nullptr, uint32_t pos_end = 0);
-// *d_flag |= 2 unless ASCII case folding equals strings.ToLower on text[lo, hi) (see k_fold_safe)
-hipError_t launch_fold_safe(const uint8_t* d_text, uint64_t lo, uint64_t hi, uint32_t* d_flag, hipStream_t st);
+// *d_flag |= 2 unless ASCII case folding equals strings.ToLower on every document of text[lo, hi) (see k_fold_safe)
+hipError_t launch_fold_safe(const uint8_t* d_text, uint64_t lo, uint64_t hi, const uint64_t* d_doc_off, uint64_t n_docs, uint32_t* d_flag, hipStream_t st);
 // unique terms per document of a CSR result (first occurrence order); d_first: grid x n_terms words, all ones
 hipError_t launch_unique_terms(bool write, const uint64_t* d_match_off, const uint32_t* d_term, uint64_t n_docs, uint32_t n_terms,
                                uint32_t* d_first, unsigned grid, uint32_t* d_cnt, const uint64_t* d_out_off, uint32_t* d_out_term,

@@ -30,6 +30,8 @@ namespace gft {
 
 namespace {
 
+#include "gft_foldsafe_dev.hpp"
+
 struct __attribute__((packed, aligned(1))) U32u { uint32_t v; };
 struct __attribute__((packed, aligned(1))) U128u { uint32_t x, y, z, w; };
 struct __attribute__((packed, aligned(1))) U64u { uint32_t lo, hi; };
@@ -505,13 +507,15 @@ __global__ void __launch_bounds__(kScan3Threads) k_scan3(const Scan3Params P) {
     auto unit_of = [&](uint32_t item) { return (uint64_t)(item / kWaves) * round_units + wg_first + item % kWaves; };
     uint64_t u = wg_first + wave, nu = 0;                         // wave-uniform
     Unit un_n{0, 0, 0};
-    uint64_t abs_n = 0;
-    if (u < P.n_units) { un_n = P.units[u]; abs_n = P.doc_off[un_n.doc]; }
+    uint64_t abs_n = 0, end_n = 0;                               // the next unit's document: blob offsets of its first byte and of the byte behind it
+    if (u < P.n_units) { un_n = P.units[u]; abs_n = P.doc_off[un_n.doc]; end_n = P.doc_off[un_n.doc + 1]; }
     for (; u < P.n_units; u = nu) {
         const Unit un{(uint32_t)__builtin_amdgcn_readfirstlane(un_n.doc), (uint32_t)__builtin_amdgcn_readfirstlane(un_n.lo),
                       (uint32_t)__builtin_amdgcn_readfirstlane(un_n.hi)};
         const uint64_t doc_abs = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(abs_n >> 32)) << 32 |
                                  (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)abs_n);
+        const uint64_t doc_end = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(end_n >> 32)) << 32 |
+                                 (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)end_n);
         {
             uint32_t item = 0;
             if (lane == 0) item = __hip_atomic_fetch_add(wg_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -526,6 +530,8 @@ __global__ void __launch_bounds__(kScan3Threads) k_scan3(const Scan3Params P) {
         // ---- FILTER --------------------------------------------------------------------------------------------------
         if (P.prio) __builtin_amdgcn_s_setprio(0);
         uint32_t m0 = 0, m1 = 0;
+        FOLD_JOB_VARS(fj_);
+        bool fold_pending = false;
         if (own) {
             const uint8_t* src = c.dbase + un.lo + lane * 16;
             U128u nxt{0, 0, 0, 0};
@@ -537,10 +543,12 @@ __global__ void __launch_bounds__(kScan3Threads) k_scan3(const Scan3Params P) {
                 carry = mad24s(lcls[hp[-2]], G, lcls[hp[-1]]);
             }
             carry = __builtin_amdgcn_readfirstlane(carry);
-            uint32_t acc = 0, hib = 0;                              // hib: OR of the lane's text (a byte >= 0x80 anywhere?)
+            uint32_t acc = 0, njobs = 0;                            // njobs: pieces that hold a byte >= 0x80 (noted in the candidate list, idle until the filter is done)
+            const bool want_fold = P.fold && P.nonascii;
             for (uint32_t r = 0; r < nr; r++) {
                 const uint32_t w[4] = {nxt.x, nxt.y, nxt.z, nxt.w};
-                if (r * 1024 + lane * 16 < own) hib |= (w[0] | w[1]) | (w[2] | w[3]);   // (up to 15 bytes behind the unit: conservative)
+                // ASCII folding is not strings.ToLower once the text leaves ASCII (finder.go:140-142): gft_foldsafe_dev.hpp
+                if (want_fold) fold_job_push(r * 1024 + lane * 16 < own && (((w[0] | w[1]) | (w[2] | w[3])) & 0x80808080u) != 0, r * 1024 + lane * 16, cand, P.cand_cap, njobs);
                 if (r + 1 < nr && (r + 1) * 1024 + lane * 16 < own) nxt = *reinterpret_cast<const U128u*>(src + (r + 1) * 1024);
                 uint32_t q[8];
 #pragma unroll
@@ -563,12 +571,11 @@ __global__ void __launch_bounds__(kScan3Threads) k_scan3(const Scan3Params P) {
                 }
                 if (r == 3) { m0 = acc; acc = 0; }
             }
-            // ASCII folding is not strings.ToLower once the text leaves ASCII (finder.go:140-142): tell the host
-            if (P.fold && P.nonascii && !told_nonascii && __any((hib & 0x80808080u) != 0)) {
-                // (one global atomic per workgroup: bit 31 of its "waves done" word says that somebody has told already)
-                told_nonascii = true;
-                if (lane == 0 && !(__hip_atomic_fetch_or(wg_book + 1, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 31))
-                    atomicOr(P.nonascii, 1u);
+            if (njobs && !told_nonascii) {
+                // bit 1: a piece breaks the rule; bit 0: more pieces than the list holds -- the host then checks the text itself
+                fold_pending = njobs <= P.cand_cap;
+                const uint32_t bits = !fold_pending ? 1u : fold_jobs_begin(P.text, doc_end, doc_abs + un.lo, own, un.lo == 0, cand, njobs, FOLD_JOB_PASS(fj_)) ? 2u : 0u;
+                if (bits) { told_nonascii = true; if (lane == 0) atomicOr(P.nonascii, bits); }
             }
             // probe t of the unit sits in round t / 512, lane (t / 8) % 64, bit 8 * (round % 4) + t % 8 of m0 (rounds 0-3) or
             // m1 (rounds 4-7); probes of the last round that start at or beyond the unit's end carry garbage
@@ -583,7 +590,7 @@ __global__ void __launch_bounds__(kScan3Threads) k_scan3(const Scan3Params P) {
         }
 
         if (P.prio) __builtin_amdgcn_s_setprio(1);
-        if (more_units) abs_n = P.doc_off[un_n.doc];
+        if (more_units) { abs_n = P.doc_off[un_n.doc]; end_n = P.doc_off[un_n.doc + 1]; }
 
         // a unit that continues a document also probes the two positions in front of it that continue its parity (terms
         // whose window ends there but that end inside the unit): entries 0 (lo - 3) and 1 (lo - 1), long anchors only
@@ -638,6 +645,13 @@ __global__ void __launch_bounds__(kScan3Threads) k_scan3(const Scan3Params P) {
                     }
                 }
                 wave_lds_fence();
+                if (fold_pending) {                                // the pieces with high bytes whose loads went out in front of the list build
+                    fold_pending = false;
+                    if (fold_jobs_finish(FOLD_JOB_PASS(fj_)) && !told_nonascii) {
+                        told_nonascii = true;
+                        if (lane == 0) atomicOr(P.nonascii, 2u);
+                    }
+                }
                 // ---- STAGE A: every listed probe -> LDS-only decisions; kStageAWays probes per lane and trip, the list
                 // entries and text of trip t + 1 are fetched while trip t is worked on ------------------------------------
                 if (P.prio) __builtin_amdgcn_s_setprio(2);
@@ -729,6 +743,13 @@ __global__ void __launch_bounds__(kScan3Threads) k_scan3(const Scan3Params P) {
             slab_left = want;
         }
         // (a unit whose cells lie beyond the pool wrote nothing: the host sees the cursor and runs the batch again)
+        if (fold_pending) {                                        // (a unit without a flagged probe never reached stage A)
+            fold_pending = false;
+            if (fold_jobs_finish(FOLD_JOB_PASS(fj_)) && !told_nonascii) {
+                told_nonascii = true;
+                if (lane == 0) atomicOr(P.nonascii, 2u);
+            }
+        }
         if (lane == 0) { KARG(unit_start)[u] = slab_next; KARG(unit_count)[u] = slab_next + nh <= P.pool_cap ? nh : 0u; }
         slab_next += nh;
         slab_left -= nh;

@@ -31,6 +31,7 @@ namespace gft {
 namespace {
 
 #include "gft_scan2_dev.hpp"
+#include "gft_foldsafe_dev.hpp"
 
 struct Ctx5 {
     uint32_t* fifo;              // LDS
@@ -237,13 +238,15 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
     };
     uint64_t u = unit_of(wave), nu = 0;                           // wave-uniform
     Unit un_n{0, 0, 0};
-    uint64_t abs_n = 0;
-    if (u < P.n_units) { un_n = P.units[u]; abs_n = P.doc_off[un_n.doc]; }
+    uint64_t abs_n = 0, end_n = 0;                               // the next unit's document: blob offsets of its first byte and of the byte behind it
+    if (u < P.n_units) { un_n = P.units[u]; abs_n = P.doc_off[un_n.doc]; end_n = P.doc_off[un_n.doc + 1]; }
     for (; u < P.n_units; u = nu) {
         const Unit un{(uint32_t)__builtin_amdgcn_readfirstlane(un_n.doc), (uint32_t)__builtin_amdgcn_readfirstlane(un_n.lo),
                       (uint32_t)__builtin_amdgcn_readfirstlane(un_n.hi)};
         const uint64_t doc_abs = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(abs_n >> 32)) << 32 |
                                  (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)abs_n);
+        const uint64_t doc_end = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(end_n >> 32)) << 32 |
+                                 (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)end_n);
         {
             uint32_t item = 0;
             if (lane == 0) item = __hip_atomic_fetch_add(wg_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -283,12 +286,14 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
             }
             pq = mad24s(h2, G, h1);
             mark(0);
-            uint32_t acc = 0, hib = 0;                           // hib: OR of the lane's text (a byte >= 0x80 anywhere?)
+            uint32_t acc = 0, njobs = 0;                         // njobs: pieces that hold a byte >= 0x80 (noted in the candidate list, idle until the filter is done)
+            const bool want_fold = P.fold && P.nonascii;
             const uint32_t ndw = C >> 2;                         // dwords per lane (wave-uniform, <= 32)
             const uint32_t npieces = (ndw + 3) >> 2;
             for (uint32_t q = 0; q < npieces; q++) {
                 const uint32_t w[4] = {nxt.x, nxt.y, nxt.z, nxt.w};
-                if (q * 16 < nvalid) hib |= (w[0] | w[1]) | (w[2] | w[3]);   // (may take in up to 15 bytes behind the lane's range: conservative)
+                // ASCII folding is not strings.ToLower once the text leaves ASCII (finder.go:140-142): gft_foldsafe_dev.hpp
+                if (want_fold) fold_job_push(q * 16 < nvalid && (((w[0] | w[1]) | (w[2] | w[3])) & 0x80808080u) != 0, lane * C + q * 16, cand, P.cand_cap, njobs);
                 if (q + 1 < npieces && (q + 1) * 16 < nvalid) nxt = *reinterpret_cast<const U128u*>(src + (q + 1) * 16);
                 const uint32_t nd = ndw - 4 * q;                 // dwords of this piece that belong to the lane (>= 1)
                 // probe at byte 0 of a dword: 3-gram (h2, h1, c0); the window that ends there has h3 in front, the window that
@@ -338,11 +343,16 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
                 const uint32_t k = ndw >> 3;
                 if (k == 0) m0 = v; else if (k == 1) m1 = v; else if (k == 2) m2 = v; else m3 = v;
             }
-            // ASCII folding is not strings.ToLower once the text leaves ASCII (finder.go:140-142): tell the host
-            if (P.fold && P.nonascii && !told_nonascii && __any((hib & 0x80808080u) != 0)) {
-                told_nonascii = true;
-                if (lane == 0 && !(__hip_atomic_fetch_or(wg_next + 1, 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 31))
-                    atomicOr(P.nonascii, 1u);
+            if (njobs && !told_nonascii) {
+                // bit 1: a piece breaks the rule; bit 0: more pieces than the list holds -- the host then checks the text itself
+                // (judged here and now: dictionaries over few byte classes rarely meet such text, and carrying the pieces
+                // through the list build as gft_scan3.hip does costs the all-ASCII case registers)
+                uint32_t bits = 1u;
+                if (njobs <= P.cand_cap) {
+                    FOLD_JOB_VARS(fj_);
+                    bits = fold_jobs_begin(P.text, doc_end, doc_abs + un.lo, own, un.lo == 0, cand, njobs, FOLD_JOB_PASS(fj_)) || fold_jobs_finish(FOLD_JOB_PASS(fj_)) ? 2u : 0u;
+                }
+                if (bits) { told_nonascii = true; if (lane == 0) atomicOr(P.nonascii, bits); }
             }
             // positions past the lane's range carry garbage flags
             m0 = nvalid >= 32 ? m0 : (nvalid ? m0 & ((1u << nvalid) - 1) : 0);
@@ -352,7 +362,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
         }
         mark(1);
         if (P.prio) __builtin_amdgcn_s_setprio(1);
-        if (more_units) abs_n = P.doc_off[un_n.doc];
+        if (more_units) { abs_n = P.doc_off[un_n.doc]; end_n = P.doc_off[un_n.doc + 1]; }
 
         if (DBG && P.dbg) {
             if (P.dbg & 2) {

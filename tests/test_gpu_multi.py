@@ -40,6 +40,21 @@ def test_split_is_contiguous_and_byte_balanced():
         e.close()
 
 
+def test_empty_batch_without_offsets_on_a_multi_device_handle():
+    """gft_scan / gft_process accept n_docs == 0 with doc_off == NULL on one device; a multi-device handle used to copy
+    doc_off[0 .. 1) per shard."""
+    e = Engine(devices=_devices())
+    try:
+        e.build([b"ab", b"b"])
+        e.set_programs([[1 << 28]])
+        L = _lib.load()
+        m = _lib.GftMatches()
+        assert L.gft_scan(e._h, None, None, 0, 0, C.byref(m)) == 0 and m.n_matches == 0
+        assert L.gft_process(e._h, None, None, 0, 0, None, None) == 0
+    finally:
+        e.close()
+
+
 def test_engine_over_two_devices_equals_one():
     w = Workload(2000)
     terms = w.terms()

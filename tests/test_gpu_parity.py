@@ -585,6 +585,69 @@ def test_mixed_alphabet_workload(eng, scan_kernel):
     assert L.gft_last_nonascii(eng._h) == 1
 
 
+def _fold_safe_doc(b: bytes) -> bool:
+    """the rule of gft_foldsafe_dev.hpp / k_fold_safe for ONE document: ASCII, C2 80..BF, C3 9F..BF and C3 97 only"""
+    i = 0
+    while i < len(b):
+        c = b[i]
+        if c < 0x80:
+            i += 1
+        elif c in (0xC2, 0xC3) and i + 1 < len(b) and 0x80 <= b[i + 1] <= 0xBF and (c == 0xC2 or b[i + 1] >= 0x9F or b[i + 1] == 0x97):
+            i += 2
+        else:
+            return False
+    return True
+
+
+def test_fold_safety_is_decided_per_document(eng, scan_kernel):
+    """gft_last_nonascii after a folded scan = some document is not "ASCII + lower-case Latin-1" (then ASCII folding is not
+    strings.ToLower, finder.go:140-142).  The suffix-window kernels decide it while they scan (the pieces of text that
+    hold high bytes, 64 per trip), the others in a second pass over the blob: documents built around the rule's edges --
+    a lead byte as a document's last byte, a continuation byte as its first, pairs that straddle lanes, pieces, units and
+    documents, upper-case Latin-1, three-byte sequences, lone high bytes -- against the rule applied document by document;
+    every safe batch must also still be a safe batch when it is not the first one."""
+    from gofindthem_amd import _lib
+    L = _lib.load()
+    both(eng, [b"abc", b"b", b"caf\xc3\xa9", b"stra\xc3\x9fe"])
+    rng = np.random.default_rng(23)
+    safe_units = [b"a", b"b c", b"\xc3\xa9", b"\xc2\xa0", b"\xc3\x9f", b"\xc3\x97", b"\xc3\xbf", b"xyz ", b"\xc2\x80", b"\xc2\xbf"]
+    bad_units = [b"\xc3\x89", b"\xc3\x80", b"\xc3\x9e", b"\xe2\x84\xaa", b"\xc3", b"\xa9", b"\xc4\xb0", b"\xff", b"\xc3a", b"\xc2\xc2\xa0", b"\xc1\x81"]
+
+    def doc(n_units, bad_at=None):
+        parts = [safe_units[int(k)] for k in rng.integers(0, len(safe_units), n_units)]
+        if bad_at is not None:
+            parts.insert(bad_at, bad_units[int(rng.integers(len(bad_units)))])
+        return b"".join(parts)
+
+    cases = []
+    for trial in range(40):
+        n_docs = int(rng.integers(1, 40))
+        lens = rng.choice([0, 1, 3, 17, 300, 1500, 5000], n_docs)
+        batch = [doc(int(n)) for n in lens]
+        kind = trial % 4
+        if kind == 1:                                   # one unsafe unit somewhere inside one document
+            d = int(rng.integers(n_docs))
+            batch[d] = doc(int(lens[d]) + 1, bad_at=int(rng.integers(int(lens[d]) + 1)))
+        elif kind == 2:                                 # a pair cut by a document border: lead at the end, continuation at the start
+            d = int(rng.integers(n_docs))
+            batch[d] = batch[d] + b"\xc3"
+            if d + 1 < n_docs:
+                batch[d + 1] = b"\xa9" + batch[d + 1]
+        elif kind == 3:                                 # safe text that ends and starts with whole two-byte letters
+            batch = [b"\xc3\xa9" + x + b"\xc2\xa0" for x in batch]
+        cases.append(batch)
+    seen = set()
+    for batch in cases:
+        blob, off = docs(batch)
+        want = 0 if all(_fold_safe_doc(x) for x in batch) else 1
+        eng.scan(blob, off, fold=True)
+        assert L.gft_last_nonascii(eng._h) == want, (scan_kernel, [x[-4:] for x in batch][:6])
+        seen.add(want)
+        eng.scan(blob, off, fold=False)                 # (case-sensitive scans never ask)
+        assert L.gft_last_nonascii(eng._h) == 0
+    assert seen == {0, 1}
+
+
 def test_config5_100k_terms_with_regex_leaves(scan_kernel):
     """BASELINE configs[4]: 100 000 terms (the large automaton: second-level filter and tables spill from LDS to L2, ~1 200
     matches per document, the solver's presence matrix at 8 documents per group) + r"..." regex terms through the host

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round 3: collects the rocprofv3 evidence on the GPU box (run through gpurun from the repo root), part $1 = a | b.
-#   a: the headline configuration on the production kernel (k_scan2) and on the streaming kernel (k_scan4, opt-in):
+#   a: the headline configuration on the production kernel (k_scan5) and, for comparison, on k_scan2 (GFT_SCAN_KERNEL=scan2;
+#      the streaming kernel's set, r3_scan4_*, was collected the same way earlier in the round):
 #      bench lines, kernel-trace stats, FETCH_SIZE / WRITE_SIZE (separate passes), TCC hit/miss/RDREQ, SQ counters, phase clocks
 #   b: BASELINE configs[4]'s device half with its traffic counters, the INORD and mixed-alphabet lines, configs[0], the
 #      host-memory path
@@ -26,22 +27,23 @@ python3 tools/sq_summary.py $O/sq1 --docs 1000000 > $O/r3_sq_counters_a.json
 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS SQ_INSTS_SMEM -d $O/sq2 -o run --output-format csv -- $B > $O/sq2.log 2>&1
 python3 tools/sq_summary.py $O/sq2 --docs 1000000 > $O/r3_sq_counters_b.json
 rm -rf $O/stats $O/pmc_fetch $O/pmc_write $O/pmc_tcc $O/sq1 $O/sq2
-# the streaming kernel (GFT_SCAN_KERNEL=scan4), same configuration
-export GFT_SCAN_KERNEL=scan4
-python3 bench.py --steps 20 --warmup 3 > $O/bench_scan4.log 2>&1
-tail -1 $O/bench_scan4.log > $O/r3_scan4_bench.json
-rocprofv3 --kernel-trace --stats -d $O/stats -o run --output-format csv -- $B > $O/stats4.log 2>&1
-find $O/stats -name "*kernel_stats.csv" -exec cp {} $O/r3_scan4_kernel_stats.csv \;
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o runc --output-format csv -- $B > $O/pmc_fetch4.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o runc --output-format csv -- $B > $O/pmc_write4.log 2>&1
-python3 tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/r3_scan4_pmc_traffic.json --docs 1000000 > $O/pmc_summary4.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT -d $O/sq1 -o run --output-format csv -- $B > $O/sq14.log 2>&1
-python3 tools/sq_summary.py $O/sq1 --docs 1000000 > $O/r3_scan4_sq_counters_a.json
-rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS SQ_INSTS_SMEM -d $O/sq2 -o run --output-format csv -- $B > $O/sq24.log 2>&1
-python3 tools/sq_summary.py $O/sq2 --docs 1000000 > $O/r3_scan4_sq_counters_b.json
-python3 tools/probe_scan.py --docs 1000000 --unordered --modes 64,0,1 --reps 3 2>&1 | grep "scan debug\|GFT_SCAN" | tail -6 > $O/r3_scan4_phase_clocks.txt || true
+# the one-probe-per-byte kernel (GFT_SCAN_KERNEL=scan2), same configuration
+export GFT_SCAN_KERNEL=scan2
+python3 bench.py --steps 20 --warmup 3 --cpu-docs 0 > $O/bench_scan2.log 2>&1
+tail -1 $O/bench_scan2.log > $O/r3_scan2_bench.json
+rocprofv3 --kernel-trace --stats -d $O/stats -o run --output-format csv -- $B > $O/stats2.log 2>&1
+find $O/stats -name "*kernel_stats.csv" -exec cp {} $O/r3_scan2_kernel_stats.csv \;
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o runc --output-format csv -- $B > $O/pmc_fetch2.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o runc --output-format csv -- $B > $O/pmc_write2.log 2>&1
+python3 tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/r3_scan2_pmc_traffic.json --docs 1000000 > $O/pmc_summary2.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT -d $O/sq1 -o run --output-format csv -- $B > $O/sq12.log 2>&1
+python3 tools/sq_summary.py $O/sq1 --docs 1000000 > $O/r3_scan2_sq_counters_a.json
+rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS SQ_INSTS_SMEM -d $O/sq2 -o run --output-format csv -- $B > $O/sq22.log 2>&1
+python3 tools/sq_summary.py $O/sq2 --docs 1000000 > $O/r3_scan2_sq_counters_b.json
 unset GFT_SCAN_KERNEL
 rm -rf $O/stats $O/pmc_fetch $O/pmc_write $O/sq1 $O/sq2
+python3 tools/probe_scan.py --docs 1000000 --unordered --modes 64,0,1 --reps 3 2>&1 | grep "scan debug\|GFT_SCAN" | tail -6 > $O/r3_scan_phase_clocks.txt || true
+GFT_SCAN_KERNEL=scan2 python3 tools/probe_scan.py --docs 1000000 --unordered --modes 64,0,1 --reps 3 2>&1 | grep "scan debug\|GFT_SCAN" | tail -6 > $O/r3_scan2_phase_clocks.txt || true
 echo part a collected
 else
 # BASELINE configs[4]'s device half: 100 000 terms, 1 000 expressions with INORD, 200 000 documents

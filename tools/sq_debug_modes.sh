@@ -1,5 +1,6 @@
 #!/bin/bash
-# SQ counters of the scan kernel chosen by $1 (scan2 / scan5 / ...) with GFT_SCAN_DEBUG=$2, per document -> gpurun_out/sqd_$1_$2.json
+# SQ counters of the scan kernel chosen by $1 (scan2 / scan5 / ...) under the timing-study knock-out GFT_SCAN_DEBUG=$2 (0: the
+# production kernel, 1: filter only, 4: no bucket table, 8: no short terms, 12: both), per document -> gpurun_out/sqd_$1_$2.json
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 K=$1

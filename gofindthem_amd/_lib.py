@@ -45,6 +45,7 @@ SYMBOLS = {
     "gft_n_states": (_u32, [_vp]),
     "gft_last_nonascii": (_i, [_vp]),
     "gft_scan_kernel": (C.c_char_p, [_vp]),
+    "gft_debug_scan5_filter": (_i, [_vp, _vp, _u32, _vp, _u32, _u32, _u32, _u32, _vp, _vp, C.POINTER(_u32)]),
     "gft_term": (_i, [_vp, _u32, C.POINTER(_vp), C.POINTER(_u32)]),
     "gft_term_id": (C.c_int64, [_vp, _vp, _u32]),
     "gft_scan": (_i, [_vp, _vp, _vp, _u64, _u32, C.POINTER(GftMatches)]),

@@ -2043,6 +2043,47 @@ int gft_debug_emulate_scan(const uint8_t* terms_blob, const uint64_t* term_off, 
     return GFT_OK;
 } GFT_CATCH(nullptr)
 
+int gft_debug_scan5_filter(const uint8_t* terms_blob, const uint64_t* term_off, uint32_t n_terms, const uint8_t* text, uint32_t len,
+                           uint32_t lane_start, uint32_t scan_flags, uint32_t groups, uint8_t* out_exact, uint8_t* out_dual,
+                           uint32_t* groups_used) try {
+    if ((n_terms && (!terms_blob || !term_off)) || (len && (!text || !out_exact || !out_dual)) || lane_start > len) return GFT_E_INVALID;
+    std::vector<std::string> terms;
+    for (uint32_t i = 0; i < n_terms; i++) terms.emplace_back((const char*)terms_blob + term_off[i], (size_t)(term_off[i + 1] - term_off[i]));
+    AcTables tab;
+    build_ac_tables(std::move(terms), tab);
+    Scan2Tables s2;
+    build_scan2_tables(tab, s2);
+    if (!s2.supported || s2.hashed || s2.kp > 32) return GFT_E_UNSUPPORTED;
+    Scan5Tables s5;
+    build_scan5_tables(tab, s2, groups && groups < s2.kp ? groups : s2.kp, s5);
+    if (groups_used) *groups_used = s5.G;
+    const bool fold = (scan_flags & GFT_FOLD_ASCII) != 0;
+    const uint8_t* cls = fold ? s2.cls_fold : s2.cls;
+    const uint8_t* grp = fold ? s5.grp_fold : s5.grp;
+    const uint32_t kp = s2.kp, G = s5.G;
+    // the exact filter: bit (c[i-3], c[i-2], c[i-1], c[i]) of Scan2Tables::filter, the pad class in front of the document
+    auto cl = [&](int64_t i) { return i < 0 ? s2.pad_class : (uint32_t)cls[text[i]]; };
+    auto gr = [&](int64_t i) { return i < 0 ? s5.pad_group : (uint32_t)grp[text[i]]; };
+    for (uint32_t i = 0; i < len; i++) {
+        const uint64_t key = (((uint64_t)cl((int64_t)i - 3) * kp + cl((int64_t)i - 2)) * kp + cl((int64_t)i - 1)) * kp + cl(i);
+        out_exact[i] = (uint8_t)(s2.filter[key >> 5] >> (key & 31) & 1);
+        out_dual[i] = 0;
+    }
+    // gft_scan5.hip: probes at lane_start, lane_start + 2, ...; the probe at j reads entry (g[j-2], g[j-1], g[j]): bit g[j-3] of
+    // its low word is the flag of j, bit g[j+1] of its high word the flag of j + 1.  (Positions in front of lane_start belong
+    // to the lane before: walked here with the same parity, so that every position is answered once.)
+    for (int64_t j = (int64_t)(lane_start & 1u); j < (int64_t)len; j += 2) {
+        const uint64_t ent = s5.filter[((size_t)gr(j - 2) * G + gr(j - 1)) * G + gr(j)];
+        out_dual[j] = (uint8_t)(ent >> gr(j - 3) & 1);
+        if (j + 1 < (int64_t)len) out_dual[j + 1] = (uint8_t)(ent >> (32 + gr(j + 1)) & 1);
+    }
+    if (lane_start & 1u) {                                   // position 0 is the second half of a probe at -1
+        const uint64_t ent = s5.filter[((size_t)gr(-3) * G + gr(-2)) * G + gr(-1)];
+        if (len) out_dual[0] = (uint8_t)(ent >> (32 + gr(0)) & 1);
+    }
+    return GFT_OK;
+} GFT_CATCH(nullptr)
+
 int gft_debug_eval_programs(const uint32_t* prog_words, const uint64_t* prog_off, uint32_t n_exprs, uint32_t n_slots,
                             const uint8_t* present, uint8_t* out_hit, uint32_t* out_depth) try {
     if (!prog_words || !prog_off || !out_hit || (n_slots && !present) || n_slots > (1u << kDwFieldBits)) return GFT_E_INVALID;

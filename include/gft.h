@@ -313,6 +313,17 @@ int gft_debug_emulate_scan(const uint8_t* terms_blob, const uint64_t* term_off, 
                            uint32_t len, uint32_t lo, uint32_t flags, uint32_t scan_flags, uint32_t* out_term,
                            uint32_t* out_pos, uint64_t cap, uint64_t* needed);
 
+/* The two-positions-per-probe filter of gft_scan5.hip alone, on the host: compiles `terms` (suffix-window tables, then the
+ * 3-gram filter over `groups` merged byte classes; 0 = as many as the dictionary has) and walks ONE document the way the
+ * kernel's lanes do -- a probe at every even offset from `lane_start` answers that position from the low word and the next
+ * one from the high word.  out_exact[i] / out_dual[i] = 1 when the one-probe-per-byte filter of gft_scan2.hip / this filter
+ * flags a window ending at byte i.  The second must flag whatever the first flags (and is equal to it when no classes are
+ * merged); *groups_used = the number of groups.  GFT_E_UNSUPPORTED when the dictionary has no direct suffix-window tables.
+ * No HIP device is needed. */
+int gft_debug_scan5_filter(const uint8_t* terms_blob, const uint64_t* term_off, uint32_t n_terms, const uint8_t* text, uint32_t len,
+                           uint32_t lane_start, uint32_t scan_flags, uint32_t groups, uint8_t* out_exact, uint8_t* out_dual,
+                           uint32_t* groups_used);
+
 /* The solver's program compiler alone, on the host: every program goes through the same steps as in gft_set_programs
  * (check, fusion with Sethi-Ullman operand order, control-bit device words) and its device words are then interpreted for
  * ONE document whose presence set is `present` (one byte per slot, non-zero = the slot's term occurs).  out_hit[i] = the

@@ -33,6 +33,8 @@ namespace {
 #include "gft_scan2_dev.hpp"
 #include "gft_foldsafe_dev.hpp"
 
+constexpr int kWays5 = 2;           // stage A: candidates a lane works on at once
+
 struct Ctx5 {
     uint32_t* fifo;              // LDS
     uint32_t fifo_cap;
@@ -408,39 +410,39 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
                 mark(2);
                 if (P.prio) __builtin_amdgcn_s_setprio(2);
                 uint32_t ns = 0;
-                bool n_on[kStageAWays];
-                uint32_t n_rel[kStageAWays];
-                Text8 n_tx[kStageAWays];
+                bool n_on[kWays5];
+                uint32_t n_rel[kWays5];
+                Text8 n_tx[kWays5];
                 auto fetch = [&](uint32_t i0) {
 #pragma unroll
-                    for (int q = 0; q < kStageAWays; q++) {
+                    for (int q = 0; q < kWays5; q++) {
                         const uint32_t i = i0 + 64 * q + lane;
                         n_on[q] = i < ptotal;
                         n_rel[q] = cand[n_on[q] ? i : 0];
                     }
 #pragma unroll
-                    for (int q = 0; q < kStageAWays; q++) n_tx[q] = cand_load(c, ubase + n_rel[q]);
+                    for (int q = 0; q < kWays5; q++) n_tx[q] = cand_load(c, ubase + n_rel[q]);
                 };
                 fetch(0);
-                for (uint32_t i0 = 0; i0 < ptotal; i0 += 64 * kStageAWays) {
-                    bool on[kStageAWays];
-                    uint32_t rel[kStageAWays];
-                    Text8 tx[kStageAWays];
-                    Cand k[kStageAWays];
+                for (uint32_t i0 = 0; i0 < ptotal; i0 += 64 * kWays5) {
+                    bool on[kWays5];
+                    uint32_t rel[kWays5];
+                    Text8 tx[kWays5];
+                    Cand k[kWays5];
 #pragma unroll
-                    for (int q = 0; q < kStageAWays; q++) { on[q] = n_on[q]; rel[q] = n_rel[q]; tx[q] = n_tx[q]; }
-                    if (i0 + 64 * kStageAWays < ptotal) fetch(i0 + 64 * kStageAWays);
+                    for (int q = 0; q < kWays5; q++) { on[q] = n_on[q]; rel[q] = n_rel[q]; tx[q] = n_tx[q]; }
+                    if (i0 + 64 * kWays5 < ptotal) fetch(i0 + 64 * kWays5);
 #pragma unroll
-                    for (int q = 0; q < kStageAWays; q++) cand_keys(c, ubase + rel[q], tx[q], k[q]);
+                    for (int q = 0; q < kWays5; q++) cand_keys(c, ubase + rel[q], tx[q], k[q]);
 #pragma unroll
-                    for (int q = 0; q < kStageAWays; q++) cand_decide<FPT_LDS>(c, k[q]);
+                    for (int q = 0; q < kWays5; q++) cand_decide<FPT_LDS>(c, k[q]);
 #pragma unroll
-                    for (int q = 0; q < kStageAWays; q++)
+                    for (int q = 0; q < kWays5; q++)
                         if (i0 + 64 * q < ptotal)                  // (positions in front of the unit: long terms only)
                             park_short(c, o, ubase, rel[q], on[q] && rel[q] >= kScan2MaxOff ? k[q].sid : 0, k[q].x3);
                     const uint64_t below = (1ull << lane) - 1;
 #pragma unroll
-                    for (int q = 0; q < kStageAWays; q++) {
+                    for (int q = 0; q < kWays5; q++) {
                         const bool keep = on[q] && k[q].go_long;
                         const uint64_t sb = __ballot(keep);
                         if (keep) cand[ns + __popcll(sb & below)] = (uint16_t)rel[q];

@@ -67,5 +67,9 @@ python3 tools/bench_c1.py > $O/r3_c1_bench.json 2> $O/c1.log
 python3 tools/bench_latency.py --batch-docs 250000 --reps 50 > $O/r3_host_path.json 2> $O/lat.log
 GFT_HOST_TIMING=1 python3 tools/bench_latency.py --batch-docs 250000 --reps 2 2>&1 | grep "host timing" | tail -3 > $O/r3_host_path_phases.txt || true
 python3 tools/probe_pcie.py 2>&1 | grep "GB/s" > $O/r3_pcie_probe.txt || true
+# the vector-memory path and the instruction cache of the production scan kernel (one pass per counter group)
+for grp in "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum" "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES" "SQ_IFETCH SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD"; do
+  bash tools/pmc_one.sh scan5 $grp || true
+done
 echo part b collected
 fi

@@ -97,6 +97,7 @@ struct gft_engine {
     Scan5Tables s5;
     DevBuf d_s5_grp, d_s5_grp_fold, d_s5_filter;
     uint32_t s5_term_bits = 0, s5_pos_bias = 0;
+    uint32_t opt_scan5_fifo = 0;                        // GFT_SCAN5_FIFO: entries of a wave's match fifo (0: 256; timing study)
     uint32_t opt_scan5_contig = 0;                      // GFT_SCAN5_CONTIG=1: one contiguous run of units per workgroup
     uint32_t opt_scan5_groups = 0;                      // GFT_SCAN5_GROUPS: forced number of filter groups (tests)
     uint64_t scan_valid_docs = ~0ull;                   // documents of the last gft_process scan still in the pool (~0: none)
@@ -188,6 +189,7 @@ void refresh_options(gft_engine* e) {
     e->opt_scan4_round = (uint32_t)num("GFT_SCAN4_ROUND", 0);
     e->opt_scan5_groups = (uint32_t)num("GFT_SCAN5_GROUPS", 0);
     e->opt_scan5_contig = num("GFT_SCAN5_CONTIG", 0) ? 1u : 0u;
+    e->opt_scan5_fifo = (uint32_t)std::min<long>(std::max<long>(num("GFT_SCAN5_FIFO", 0), 0), 4096) & ~63u;
     e->opt_solve_dbg = (uint32_t)num("GFT_SOLVE_DEBUG", 0);
     e->opt_solve_group = (int)num("GFT_SOLVE_GROUP_DOCS", -1);
 }
@@ -771,7 +773,7 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
             if (P.ordered == 0 && text_hi > text_lo) {
                 // a unit of maximal size should fill ~75 % of the fifo
                 const double per_byte = (double)total / (double)(text_hi - text_lo);
-                const double want = per_byte > 0 ? 0.75 * kScan2FifoCap / per_byte : (double)kScan2UnitMax;
+                const double want = per_byte > 0 ? 0.75 * (e->use_scan5 ? e->s5plan.fifo_cap : kScan2FifoCap) / per_byte : (double)kScan2UnitMax;
                 uint32_t um = want >= kScan2UnitMax ? kScan2UnitMax : (uint32_t)want & ~255u;
                 e->scan2_unit_max = std::max<uint32_t>(512, um);
             }
@@ -853,7 +855,7 @@ int deferred_check(gft_engine* e, bool* again) {
     if (e->use_scan2 && !e->use_scan3 && !e->opt_scan_ordered && text_hi > text_lo) {
         // scan2: a unit of maximal size should fill ~75 % of the fifo
         const double per_byte = (double)total / (double)(text_hi - text_lo);
-        const double want = per_byte > 0 ? 0.75 * kScan2FifoCap / per_byte : (double)kScan2UnitMax;
+        const double want = per_byte > 0 ? 0.75 * (e->use_scan5 ? e->s5plan.fifo_cap : kScan2FifoCap) / per_byte : (double)kScan2UnitMax;
         const uint32_t um = want >= kScan2UnitMax ? kScan2UnitMax : (uint32_t)want & ~255u;
         e->scan2_unit_max = std::max<uint32_t>(512, um);
     }
@@ -1350,7 +1352,7 @@ static int install_tables(gft_engine* e, uint32_t flags) {
         e->s5_pos_bias = e->tab.max_term_len + kScan2MaxOff;
         const bool packs = (uint64_t)kScan2UnitMax + e->s5_pos_bias + 8 < (1ull << (32 - tb));
         if (packs && scan5_plan(e->s2.kp, (uint32_t)e->s2.short3.size(), (uint32_t)std::min<size_t>(e->s2.shorts_packed.size(), 255 * 3),
-                                e->s2.fpt_lg ? 0u : kScan2FptSize, e->lds_max - 512, &e->s5plan)) {
+                                e->s2.fpt_lg ? 0u : kScan2FptSize, e->lds_max - 512, e->opt_scan5_fifo ? e->opt_scan5_fifo : kScan2FifoCap, &e->s5plan)) {
             if (e->opt_scan5_groups && e->opt_scan5_groups < e->s5plan.G) {      // (tests: more merging than LDS asks for)
                 e->s5plan.G = std::max<uint32_t>(e->opt_scan5_groups, 2);
                 e->s5plan.dual_entries = e->s5plan.G * e->s5plan.G * e->s5plan.G;

@@ -297,7 +297,8 @@ constexpr uint32_t kScan5MaxGroups = 27;         // filter groups: G^3 x 8 bytes
 constexpr uint32_t kScan5CandCapMin = 384;       // flagged positions of one unit listed in LDS at least (more when LDS is left)
 struct Scan5Plan { uint32_t G, dual_entries, cand_cap, fifo_cap; };
 // filter groups and list capacities that fit lds_max with kScan5Waves waves; false if nothing fits
-bool scan5_plan(uint32_t kp, uint32_t short3_bytes, uint32_t shorts_words, uint32_t fpt_lds_bytes, size_t lds_max, Scan5Plan* out);
+// fifo_cap: entries of a wave's match fifo (the unit size follows it: a unit's matches should fit)
+bool scan5_plan(uint32_t kp, uint32_t short3_bytes, uint32_t shorts_words, uint32_t fpt_lds_bytes, size_t lds_max, uint32_t fifo_cap, Scan5Plan* out);
 hipError_t launch_scan5(const Scan2Params& P, unsigned n_cus, hipStream_t st);
 
 

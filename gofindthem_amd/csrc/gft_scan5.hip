@@ -555,7 +555,7 @@ static size_t scan5_wave_lds(uint32_t fifo_cap, uint32_t cand_cap) {
     return (size_t)fifo_cap * 4 + (((size_t)cand_cap * 2 + 15) & ~(size_t)15);
 }
 
-bool scan5_plan(uint32_t kp, uint32_t short3_bytes, uint32_t shorts_words, uint32_t fpt_lds_bytes, size_t lds_max, Scan5Plan* out) {
+bool scan5_plan(uint32_t kp, uint32_t short3_bytes, uint32_t shorts_words, uint32_t fpt_lds_bytes, size_t lds_max, uint32_t fifo_cap, Scan5Plan* out) {
     // as many filter groups as fit next to a candidate list of kScan5CandCapMin entries (every merged class flags more
     // positions: tools/sim); what is left goes to the list
     const uint32_t g_hi = kp < kScan5MaxGroups ? kp : kScan5MaxGroups;
@@ -563,12 +563,12 @@ bool scan5_plan(uint32_t kp, uint32_t short3_bytes, uint32_t shorts_words, uint3
     for (uint32_t G = g_hi; G >= g_lo; G--) {
         const uint32_t ent = G * G * G;
         const size_t fixed = scan5_fixed_lds(ent, short3_bytes, shorts_words, fpt_lds_bytes);
-        const size_t need = fixed + (size_t)kScan5Waves * scan5_wave_lds(kScan2FifoCap, kScan5CandCapMin);
+        const size_t need = fixed + (size_t)kScan5Waves * scan5_wave_lds(fifo_cap, kScan5CandCapMin);
         if (need > lds_max) continue;
         const size_t spare = ((lds_max - need) / kScan5Waves / 2) & ~(size_t)7;      // entries the candidate list can grow by
         out->G = G; out->dual_entries = ent;
         out->cand_cap = (uint32_t)std::min<size_t>(kScan5CandCapMin + spare, 2048);
-        out->fifo_cap = kScan2FifoCap;
+        out->fifo_cap = fifo_cap;
         return true;
     }
     return false;

@@ -504,7 +504,13 @@ __global__ void __launch_bounds__(kScan3Threads) k_scan3(const Scan3Params P) {
     uint32_t* wg_book = reinterpret_cast<uint32_t*>(__builtin_assume_aligned(smem + off_next, 16));   // work counter, waves done, matches
     uint32_t* wg_next = wg_book;
     const uint64_t round_units = (uint64_t)gridDim.x * kWaves, wg_first = (uint64_t)blockIdx.x * kWaves;
-    auto unit_of = [&](uint32_t item) { return (uint64_t)(item / kWaves) * round_units + wg_first + item % kWaves; };
+    // (16, 8 or 4 waves: a shift instead of a 32-bit division per unit)
+    const bool waves_p2 = (kWaves & (kWaves - 1)) == 0;
+    const uint32_t waves_lg = (uint32_t)__builtin_ctz(kWaves);
+    auto unit_of = [&](uint32_t item) {
+        const uint32_t q = waves_p2 ? item >> waves_lg : item / kWaves;
+        return (uint64_t)q * round_units + wg_first + (item - q * kWaves);
+    };
     uint64_t u = wg_first + wave, nu = 0;                         // wave-uniform
     Unit un_n{0, 0, 0};
     uint64_t abs_n = 0, end_n = 0;                               // the next unit's document: blob offsets of its first byte and of the byte behind it

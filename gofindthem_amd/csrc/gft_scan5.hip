@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
     for (uint32_t i = threadIdx.x; FPT_LDS && i < kScan2FptSize / 4; i += blockDim.x)
         reinterpret_cast<uint32_t*>(fpt)[i] = reinterpret_cast<const uint32_t*>(P.fpt)[i];
     for (uint32_t i = threadIdx.x; i < P.shorts_words; i += blockDim.x) lrec[i] = P.shorts_packed[i];
-    if (threadIdx.x == 0) { wg_next[0] = blockDim.x >> 6; wg_next[1] = wg_next[2] = wg_next[3] = 0; }
+    if (threadIdx.x == 0) { wg_next[0] = kScan5Waves; wg_next[1] = wg_next[2] = wg_next[3] = 0; }
     __syncthreads();
     if (DBG && (P.dbg & 128)) return;                            // timing study: launch + table staging alone
 
@@ -223,14 +223,14 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
     auto mark = [&](int ph) {
         if (DBG && (P.dbg & 64)) { const unsigned long long now = clock64(); tl[ph] += now - tprev; tprev = now; }
     };
-    const uint64_t static_slabs = (uint64_t)gridDim.x * (blockDim.x >> 6) * KARG(slab);
-    uint64_t slab_next = ((uint64_t)blockIdx.x * (blockDim.x >> 6) + wave) * KARG(slab), wave_matches = 0;   // wave-uniform
+    const uint64_t static_slabs = (uint64_t)gridDim.x * kScan5Waves * KARG(slab);
+    uint64_t slab_next = ((uint64_t)blockIdx.x * kScan5Waves + wave) * KARG(slab), wave_matches = 0;   // wave-uniform
     bool told_nonascii = false;
     uint32_t slab_left = KARG(slab);
 
     // work distribution as in gft_scan2.hip: the workgroup owns the units b * waves + k * (grid * waves) + [0, waves) of
     // every round k, its waves take them one by one from a counter in LDS
-    const uint32_t wg_waves = blockDim.x >> 6;
+    constexpr uint32_t wg_waves = kScan5Waves;                    // (a constant: item / wg_waves is a shift, not a division per unit)
     const uint64_t round_units = (uint64_t)gridDim.x * wg_waves, wg_first = (uint64_t)blockIdx.x * wg_waves;
     // (s5_contig: the workgroup owns ONE contiguous run of units instead -- a 2 MB page of text then serves it for 32 rounds)
     const uint64_t per_wg = (P.n_units + gridDim.x - 1) / gridDim.x, run_lo = (uint64_t)blockIdx.x * per_wg;
@@ -532,7 +532,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
             __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(wg_next + 2), (unsigned long long)wave_matches, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_WORKGROUP);
         const uint32_t done = __hip_atomic_fetch_add(wg_next + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) & 0x7FFFFFFFu;
-        if (done + 1 == (blockDim.x >> 6)) {
+        if (done + 1 == kScan5Waves) {
             const unsigned long long all = __hip_atomic_load(reinterpret_cast<unsigned long long*>(wg_next + 2), __ATOMIC_RELAXED,
                                                              __HIP_MEMORY_SCOPE_WORKGROUP);
             if (all) atomicAdd(reinterpret_cast<unsigned long long*>(KARG(n_matches)), all);

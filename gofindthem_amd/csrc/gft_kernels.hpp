@@ -294,6 +294,7 @@ hipError_t launch_scan4(const Scan2Params& P, uint32_t waves, unsigned n_cus, hi
 // gft_scan5.hip: the same tables behind a filter over 3-grams of merged byte classes that is probed every other byte
 constexpr uint32_t kScan5Waves = 16;             // waves per workgroup (one LDS copy of the tables per CU)
 constexpr uint32_t kScan5MaxGroups = 27;         // filter groups: G^3 x 8 bytes of LDS (G <= 32: a group is a bit of a 32-bit word)
+constexpr uint32_t kScan5SurvX = 64;              // stage A hands the window keys of a unit's first survivors to stage B through LDS
 constexpr uint32_t kScan5CandCapMin = 384;       // flagged positions of one unit listed in LDS at least (more when LDS is left)
 struct Scan5Plan { uint32_t G, dual_entries, cand_cap, fifo_cap; };
 // filter groups and list capacities that fit lds_max with kScan5Waves waves; false if nothing fits

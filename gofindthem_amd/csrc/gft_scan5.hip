@@ -207,10 +207,11 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
     if (DBG && (P.dbg & 128)) return;                            // timing study: launch + table staging alone
 
     const uint32_t lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // per-wave LDS region: [fifo: fifo_cap x 4 B][candidate list: cand_cap x 2 B]
-    uint8_t* wave_lds = wave_lds_all + (size_t)wave * (P.s5_fifo_cap * 4 + ((P.cand_cap * 2 + 15) & ~15u));
+    // per-wave LDS region: [fifo: fifo_cap x 4 B][window keys of the first survivors: kScan5SurvX x 4 B][candidate list: cand_cap x 2 B]
+    uint8_t* wave_lds = wave_lds_all + (size_t)wave * (P.s5_fifo_cap * 4 + kScan5SurvX * 4 + ((P.cand_cap * 2 + 15) & ~15u));
     uint32_t* fifo = reinterpret_cast<uint32_t*>(wave_lds);
-    uint16_t* cand = reinterpret_cast<uint16_t*>(wave_lds + P.s5_fifo_cap * 4);
+    uint32_t* survx = fifo + P.s5_fifo_cap;
+    uint16_t* cand = reinterpret_cast<uint16_t*>(survx + kScan5SurvX);
     const uint32_t G = __builtin_amdgcn_readfirstlane(P.s5_G);
     const uint32_t kp = __builtin_amdgcn_readfirstlane(P.kp), kp2 = __builtin_amdgcn_readfirstlane(kp * kp);
     lds_u8* lgrp = (lds_u8*)0;
@@ -445,7 +446,11 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
                     for (int q = 0; q < kWays5; q++) {
                         const bool keep = on[q] && k[q].go_long;
                         const uint64_t sb = __ballot(keep);
-                        if (keep) cand[ns + __popcll(sb & below)] = (uint16_t)rel[q];
+                        if (keep) {
+                            const uint32_t at = ns + (uint32_t)__popcll(sb & below);
+                            cand[at] = (uint16_t)rel[q];
+                            if (at < kScan5SurvX) survx[at] = k[q].x;   // (stage B's first trip then needs no text to name its slots)
+                        }
                         ns += (uint32_t)__popcll(sb);
                     }
                 }
@@ -463,14 +468,27 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
                     const bool on = i0 + lane < ns;
                     const uint32_t rel = cand[on ? i0 + lane : 0];
                     const uint32_t p = ubase + rel;
-                    const Text8 t8 = cand_load(c, p);
-                    const Front fr = front_load(c, p, t8.tw);
-                    const uint32_t tl5 = tail_load(c, p);
                     Cand k;
-                    cand_keys<false>(c, p, t8, k);
-                    const Slot s0 = slot_load(&P.slots[scan2_slot_hash(k.x, 0, P.slot_shift, P.slot_seed)]);
-                    const Slot s1 = slot_load(&P.slots[scan2_slot_hash(k.x, 1, P.slot_shift, P.slot_seed)]);
-                    finish_long5(c, o, on, rel, k, s0, s1, fr, tl5, dfr);
+                    k.p = p; k.x3 = 0; k.sid = 0; k.go_long = true;
+                    if (i0 + 64 <= kScan5SurvX) {
+                        // the survivors' window keys came along from stage A: slots and text leave together, one round trip
+                        k.x = survx[on ? i0 + lane : 0];
+                        const Slot s0 = slot_load(&P.slots[scan2_slot_hash(k.x, 0, P.slot_shift, P.slot_seed)]);
+                        const Slot s1 = slot_load(&P.slots[scan2_slot_hash(k.x, 1, P.slot_shift, P.slot_seed)]);
+                        const Text8 t8 = cand_load(c, p);
+                        const Front fr = front_load(c, p, t8.tw);
+                        const uint32_t tl5 = tail_load(c, p);
+                        k.tw = t8.tw;
+                        finish_long5(c, o, on, rel, k, s0, s1, fr, tl5, dfr);
+                    } else {
+                        const Text8 t8 = cand_load(c, p);
+                        const Front fr = front_load(c, p, t8.tw);
+                        const uint32_t tl5 = tail_load(c, p);
+                        cand_keys<false>(c, p, t8, k);
+                        const Slot s0 = slot_load(&P.slots[scan2_slot_hash(k.x, 0, P.slot_shift, P.slot_seed)]);
+                        const Slot s1 = slot_load(&P.slots[scan2_slot_hash(k.x, 1, P.slot_shift, P.slot_seed)]);
+                        finish_long5(c, o, on, rel, k, s0, s1, fr, tl5, dfr);
+                    }
                 }
                 if (dfr.n) drain_deferred5(c, o, ubase, dfr);
                 wave_lds_sync();
@@ -552,7 +570,7 @@ static size_t scan5_fixed_lds(uint32_t dual_entries, uint32_t short3_bytes, uint
     return ((512 + (size_t)dual_entries * 8 + short3_bytes + fpt_lds_bytes + (size_t)shorts_words * 4 + 15) & ~(size_t)15) + 16;
 }
 static size_t scan5_wave_lds(uint32_t fifo_cap, uint32_t cand_cap) {
-    return (size_t)fifo_cap * 4 + (((size_t)cand_cap * 2 + 15) & ~(size_t)15);
+    return (size_t)fifo_cap * 4 + kScan5SurvX * 4 + (((size_t)cand_cap * 2 + 15) & ~(size_t)15);
 }
 
 bool scan5_plan(uint32_t kp, uint32_t short3_bytes, uint32_t shorts_words, uint32_t fpt_lds_bytes, size_t lds_max, uint32_t fifo_cap, Scan5Plan* out) {

@@ -19,6 +19,7 @@
 #include <cstdlib>
 
 #include "ac_tables.hpp"
+#include "copy_pool.hpp"
 #include "gft_guard.hpp"
 #include "gft_kernels.hpp"
 #include "host_solve.hpp"
@@ -58,6 +59,7 @@ struct gft_engine {
     void* pin[2] = {nullptr, nullptr};
     uint64_t* pin_rb = nullptr;            // pinned landing place of the per-batch read-back of the control block
     hipEvent_t pin_ev[2] = {nullptr, nullptr};
+    std::unique_ptr<gft::CopyPool> copy_pool;   // the threads that fill / empty the bounce buffers (created with the first large copy)
     bool own_stream = false;
     unsigned n_cus = 256;
     size_t lds_max = 65536;
@@ -1589,15 +1591,25 @@ int gft_scan_device(gft_engine* e, const uint8_t* d_text_blob, const uint64_t* d
     return GFT_OK;
 } GFT_CATCH((e ? &e->err : nullptr))
 
-constexpr size_t kPinChunk = 64u << 20;      // bytes per bounce buffer
-// copy threads that fill a bounce buffer: the link (PCIe Gen5 x16, ~55 GB/s in practice) is only kept busy when the host
-// side copies faster than that -- four threads reach ~30 GB/s, so the staging takes what the machine offers, up to 12
-// (GFT_HOST_THREADS overrides)
+constexpr size_t kPinBuf = 128u << 20;       // bytes per bounce buffer
+// what goes through a buffer at once (GFT_HOST_CHUNK_MB, 4 .. 128; timing study)
+static size_t pin_chunk() {
+    static const size_t n = [] {
+        size_t mb = 128;
+        if (const char* e = getenv("GFT_HOST_CHUNK_MB")) { const long v = atol(e); if (v >= 4 && v <= 128) mb = (size_t)v; }
+        return mb << 20;
+    }();
+    return n;
+}
+#define kPinChunk pin_chunk()
+// copy threads that fill a bounce buffer: the link (PCIe Gen5 x16, 57 GB/s from pinned memory) is only kept busy when the
+// host side copies faster than that -- four threads reach ~58 GB/s, eight 120 (tools/probe_pcie.py); more than eight only add
+// wake-ups (12: 11.4-12.0 M documents/s on the 250 000-document batch, 8: 12.2-12.3).  GFT_HOST_THREADS overrides
 static unsigned pin_threads() {
     static const unsigned n = [] {
         if (const char* e = getenv("GFT_HOST_THREADS")) { const int v = atoi(e); if (v > 0) return (unsigned)std::min(v, 32); }
         const unsigned hc = std::thread::hardware_concurrency();
-        return hc ? std::min(std::max(hc, 2u), 12u) : 4u;
+        return hc ? std::min(std::max(hc, 2u), 8u) : 4u;
     }();
     return n;
 }
@@ -1609,25 +1621,17 @@ static int h2d_staged(gft_engine* e, void* dst, const void* src, size_t bytes) {
         return GFT_OK;
     }
     for (int k = 0; k < 2; k++) {
-        if (!e->pin[k]) HIP_TRY(hipHostMalloc(&e->pin[k], kPinChunk, hipHostMallocDefault), "pinned alloc");
+        if (!e->pin[k]) HIP_TRY(hipHostMalloc(&e->pin[k], kPinBuf, hipHostMallocDefault), "pinned alloc");
         if (!e->pin_ev[k]) HIP_TRY(hipEventCreateWithFlags(&e->pin_ev[k], hipEventDisableTiming), "event");
     }
+    if (!e->copy_pool) e->copy_pool.reset(new gft::CopyPool(pin_threads() - 1));
     size_t done = 0;
-    for (int k = 0; done < bytes; k ^= 1) {
-        const size_t n = std::min(kPinChunk, bytes - done);
+    // (the first chunks are small and double: the link idles while the very first one is filled)
+    size_t chunk = std::min<size_t>(kPinChunk, 4u << 20);
+    for (int k = 0; done < bytes; k ^= 1, chunk = std::min(kPinChunk, chunk * 2)) {
+        const size_t n = std::min(chunk, bytes - done);
         HIP_TRY(hipEventSynchronize(e->pin_ev[k]), "staging");        // the copy out of this buffer has finished
-        const uint8_t* s0 = (const uint8_t*)src + done;
-        uint8_t* d0 = (uint8_t*)e->pin[k];
-        const unsigned kPinThreads = pin_threads();
-        const size_t part = (n + kPinThreads - 1) / kPinThreads;
-        {
-            std::vector<std::thread> th;
-            th.reserve(kPinThreads);
-            JoinAll joined(th);              // (a copy thread that could not be started: the others are joined, the error returned)
-            for (unsigned t = 1; t < kPinThreads; t++)
-                th.emplace_back([=]() noexcept { const size_t a = std::min(n, t * part), b = std::min(n, (t + 1) * part); if (b > a) memcpy(d0 + a, s0 + a, b - a); });
-            memcpy(d0, s0, std::min(n, part));
-        }
+        e->copy_pool->copy(e->pin[k], (const uint8_t*)src + done, n);
         HIP_TRY(hipMemcpyAsync((uint8_t*)dst + done, e->pin[k], n, hipMemcpyHostToDevice, e->stream), "upload");
         HIP_TRY(hipEventRecord(e->pin_ev[k], e->stream), "staging");
         done += n;
@@ -1644,34 +1648,26 @@ static int d2h_staged(gft_engine* e, void* dst, const void* src, size_t bytes) {
         return GFT_OK;
     }
     for (int k = 0; k < 2; k++) {
-        if (!e->pin[k]) HIP_TRY(hipHostMalloc(&e->pin[k], kPinChunk, hipHostMallocDefault), "pinned alloc");
+        if (!e->pin[k]) HIP_TRY(hipHostMalloc(&e->pin[k], kPinBuf, hipHostMallocDefault), "pinned alloc");
         if (!e->pin_ev[k]) HIP_TRY(hipEventCreateWithFlags(&e->pin_ev[k], hipEventDisableTiming), "event");
     }
-    const unsigned nt = pin_threads();
+    if (!e->copy_pool) e->copy_pool.reset(new gft::CopyPool(pin_threads() - 1));
     size_t issued = 0, done = 0;
     size_t len[2] = {0, 0};
     int ki = 0, kd = 0;
-    // chunk i + 1 is on the wire while chunk i is copied out of its buffer
+    // chunk i + 1 is on the wire while chunk i is copied out of its buffer (a result smaller than two buffers goes in
+    // quarters, so that there is a chunk i + 1)
+    const size_t chunk = std::min(kPinChunk, std::max<size_t>(4u << 20, (bytes / 4 + 4095) & ~(size_t)4095));
     while (done < bytes) {
         while (issued < bytes && len[ki] == 0) {                  // (a buffer is free again once it has been copied out)
-            const size_t n = std::min(kPinChunk, bytes - issued);
+            const size_t n = std::min(chunk, bytes - issued);
             HIP_TRY(hipMemcpyAsync(e->pin[ki], (const uint8_t*)src + issued, n, hipMemcpyDeviceToHost, e->stream), "download");
             HIP_TRY(hipEventRecord(e->pin_ev[ki], e->stream), "staging");
             len[ki] = n; issued += n; ki ^= 1;
         }
         HIP_TRY(hipEventSynchronize(e->pin_ev[kd]), "staging");
         const size_t n = len[kd];
-        const uint8_t* s0 = (const uint8_t*)e->pin[kd];
-        uint8_t* d0 = (uint8_t*)dst + done;
-        const size_t part = (n + nt - 1) / nt;
-        {
-            std::vector<std::thread> th;
-            th.reserve(nt);
-            JoinAll joined(th);
-            for (unsigned t = 1; t < nt; t++)
-                th.emplace_back([=]() noexcept { const size_t a = std::min(n, t * part), b = std::min(n, (t + 1) * part); if (b > a) memcpy(d0 + a, s0 + a, b - a); });
-            memcpy(d0, s0, std::min(n, part));
-        }
+        e->copy_pool->copy((uint8_t*)dst + done, e->pin[kd], n);
         len[kd] = 0; done += n; kd ^= 1;
     }
     return GFT_OK;

@@ -262,13 +262,19 @@ class Finder:
             cache.append((s, t))
         return [ExpressionResult(i, cache[i][0], cache[i][1]) for i in idx[:n.value].tolist()]
 
-    def ProcessTexts(self, texts=None, blob=None, doc_off=None):
-        """batch extension -> uint32 bitmap [n_docs, ceil(E/32)]"""
+    def ProcessTexts(self, texts=None, blob=None, doc_off=None, out=None):
+        """batch extension -> uint32 bitmap [n_docs, ceil(E/32)]; `out`: a caller's array of that shape to fill instead of a
+        fresh one (a Go caller keeps its []uint32 from batch to batch: no page of the result is touched for the first time)"""
         if texts is not None:
             blob, doc_off = pack(texts)
         n_docs = len(doc_off) - 1
         words = (self.n_expressions + 31) // 32
-        bm = np.zeros((n_docs, words), dtype=np.uint32)
+        if out is not None:
+            if out.dtype != np.uint32 or out.shape != (n_docs, words) or not out.flags["C_CONTIGUOUS"]:
+                raise ValueError("out must be a C-contiguous uint32 array of shape (n_docs, ceil(n_expressions / 32))")
+            bm = out
+        else:
+            bm = np.zeros((n_docs, words), dtype=np.uint32)
         self._check(self._L.gft_finder_process_texts(self._h, blob.ctypes.data, doc_off.ctypes.data, n_docs,
                                                      bm.ctypes.data if bm.size else None))
         return bm

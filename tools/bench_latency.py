@@ -55,4 +55,11 @@ if args.batch_docs:
         f.ProcessTexts(blob=bb, doc_off=bo)
     dt = (time.perf_counter() - t0) / 5
     out["ProcessTexts_host_memory"] = {"docs": args.batch_docs, "docs_per_s": args.batch_docs / dt, "text_GB_per_s": int(bo[-1]) / dt / 1e9}
+    # the same with the result rows going into the caller's own array, batch after batch (what a Go caller's []uint32 is)
+    rows = f.ProcessTexts(blob=bb, doc_off=bo)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        f.ProcessTexts(blob=bb, doc_off=bo, out=rows)
+    dt = (time.perf_counter() - t0) / 5
+    out["ProcessTexts_host_memory_reused_rows"] = {"docs": args.batch_docs, "docs_per_s": args.batch_docs / dt, "text_GB_per_s": int(bo[-1]) / dt / 1e9}
 print(json.dumps(out))

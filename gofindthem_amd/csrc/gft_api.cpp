@@ -99,9 +99,6 @@ struct gft_engine {
     Scan5Tables s5;
     DevBuf d_s5_grp, d_s5_grp_fold, d_s5_filter;
     uint32_t s5_term_bits = 0, s5_pos_bias = 0;
-    bool scan5_direct = false;                          // scan5_output_mode
-    double scan5_density = 0.3;                         // matches per text byte of the last batch
-    int opt_scan5_direct = -1;                          // GFT_SCAN5_DIRECT=1: timing study (scan5_output_mode)
     uint32_t opt_scan5_fifo = 0;                        // GFT_SCAN5_FIFO: entries of a wave's match fifo (0: 256; timing study)
     uint32_t opt_scan5_contig = 0;                      // GFT_SCAN5_CONTIG=1: one contiguous run of units per workgroup
     uint32_t opt_scan5_groups = 0;                      // GFT_SCAN5_GROUPS: forced number of filter groups (tests)
@@ -194,7 +191,6 @@ void refresh_options(gft_engine* e) {
     e->opt_scan4_round = (uint32_t)num("GFT_SCAN4_ROUND", 0);
     e->opt_scan5_groups = (uint32_t)num("GFT_SCAN5_GROUPS", 0);
     e->opt_scan5_contig = num("GFT_SCAN5_CONTIG", 0) ? 1u : 0u;
-    e->opt_scan5_direct = (int)num("GFT_SCAN5_DIRECT", -1);
     e->opt_scan5_fifo = (uint32_t)std::min<long>(std::max<long>(num("GFT_SCAN5_FIFO", 0), 0), 4096) & ~63u;
     e->opt_solve_dbg = (uint32_t)num("GFT_SOLVE_DEBUG", 0);
     e->opt_solve_group = (int)num("GFT_SOLVE_GROUP_DOCS", -1);
@@ -486,18 +482,6 @@ int csr_from_pool(gft_engine* e, uint64_t n_docs) {
 // d_term / d_pos and *n_matches is set.
 constexpr uint64_t kHostUnitDocs = 1024;   // batches up to this many documents get their unit table from the host
 
-// gft_scan5 can write a unit's matches to the pool as it finds them instead of through the LDS fifo, which then no longer
-// bounds the unit (GFT_SCAN5_DIRECT=1; a dictionary that matches every few bytes -- 100 000 terms: 0.3 matches per byte -- has
-// fifo-sized units of 480 bytes, 8.5 per 4 KB document).  Measured at 100 000 terms and NOT the default: presence-only scan
-// 5.84 -> 7.13 ms, with positions 7.53 -> 7.25 ms but the solver 3.04 -> 3.53 ms (one unit of 2 400 matches per document):
-// a whole document's 4 400 flagged positions go through the 400-entry candidate list in eleven passes of a few lanes each.
-void scan5_output_mode(gft_engine* e, double fifo_unit_bytes) {
-    if (!e->use_scan5) return;
-    e->scan5_direct = e->opt_scan5_direct > 0;
-    e->scan5_density = fifo_unit_bytes > 0 ? 0.75 * e->s5plan.fifo_cap / fifo_unit_bytes : 0.3;
-    if (e->scan5_direct) e->scan2_unit_max = kScan2UnitMax;
-}
-
 // defer_ok: the caller reads the control block back itself after its last kernel (deferred_check) -- the unit table and
 // the match pool are then sized from the previous batch, and a batch that outgrew them is run again.
 int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_off, uint64_t n_docs, uint32_t flags,
@@ -617,8 +601,7 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         // (scan4: a slab holds at least one chunk's regions -- up to eight units of unit_max bytes at 1.6 x the density seen)
         const uint64_t wpw = e->use_scan3 ? e->scan3_waves : e->use_scan4 ? e->scan4_waves : e->use_scan5 ? kScan5Waves : e->scan2_k2_waves;
         const uint64_t min_slab = e->use_scan3 ? 2 * kScan3MinRoom
-                                  : e->use_scan4 ? kScan4ChunkUnits * ((uint64_t)(unit_max * e->scan4_density * 1.6) + 49)
-                                  : e->use_scan5 && e->scan5_direct ? 2 * (uint64_t)std::min<double>(std::max(256.0, e->scan5_density * unit_max * 1.3), 16384.0) : 64;
+                                  : e->use_scan4 ? kScan4ChunkUnits * ((uint64_t)(unit_max * e->scan4_density * 1.6) + 49) : 64;
         const uint64_t waves = std::min<uint64_t>(std::max<uint64_t>((n_units + wpw - 1) / wpw, 1), e->n_cus) * wpw;
         rc = ensure_pool(e, 2 * waves * min_slab);
     }
@@ -743,15 +726,8 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
             P.s5_fifo_cap = e->s5plan.fifo_cap; P.cand_cap = e->s5plan.cand_cap;
             P.s5_term_bits = e->s5_term_bits; P.s5_pos_bias = e->s5_pos_bias;
             P.s5_contig = e->opt_scan5_contig;
-            P.s5_direct = e->scan5_direct ? 1u : 0u;
-            P.s5_need = 0;
             const uint64_t n_waves5 = (uint64_t)e->n_cus * kScan5Waves;
             P.slab = (uint32_t)std::min<uint64_t>(kScan2Slab, std::max<uint64_t>(64, e->pool_cap / (2 * n_waves5)));
-            if (e->scan5_direct) {
-                // a unit's expected matches at the density the batches before showed, + 30 %; a slab holds two such units
-                P.s5_need = (uint32_t)std::min<double>(std::max(256.0, e->scan5_density * unit_max * 1.3), 16384.0);
-                P.slab = std::max<uint32_t>(P.slab, 2 * P.s5_need);
-            }
             e->last_static_slabs = std::min<uint64_t>(std::max<uint64_t>((n_units + kScan5Waves - 1) / kScan5Waves, 1), e->n_cus) * kScan5Waves * P.slab;
             ProfScope ps(e, "scan");
             HIP_TRY(launch_scan5(P, e->n_cus, st), "scan kernel launch");
@@ -802,7 +778,6 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
                 const double want = per_byte > 0 ? 0.75 * (e->use_scan5 ? e->s5plan.fifo_cap : kScan2FifoCap) / per_byte : (double)kScan2UnitMax;
                 uint32_t um = want >= kScan2UnitMax ? kScan2UnitMax : (uint32_t)want & ~255u;
                 e->scan2_unit_max = std::max<uint32_t>(512, um);
-                scan5_output_mode(e, want);
             }
             break;
         }
@@ -885,7 +860,6 @@ int deferred_check(gft_engine* e, bool* again) {
         const double want = per_byte > 0 ? 0.75 * (e->use_scan5 ? e->s5plan.fifo_cap : kScan2FifoCap) / per_byte : (double)kScan2UnitMax;
         const uint32_t um = want >= kScan2UnitMax ? kScan2UnitMax : (uint32_t)want & ~255u;
         e->scan2_unit_max = std::max<uint32_t>(512, um);
-        scan5_output_mode(e, want);
     }
     return GFT_OK;
 }
@@ -1458,7 +1432,6 @@ static int install_tables(gft_engine* e, uint32_t flags) {
     e->built = true;
     e->scan_valid_docs = ~0ull;
     e->scan2_unit_max = kScan2UnitMax;
-    e->scan5_direct = e->use_scan5 && e->opt_scan5_direct > 0;
     e->have_programs = false;   // slots refer to the dictionary: programs must be set again
     e->n_exprs = 0;
     return GFT_OK;

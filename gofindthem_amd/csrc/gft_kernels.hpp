@@ -277,8 +277,6 @@ struct Scan2Params {
     const uint64_t* s5_filter;   // [s5_dual = G^3] per 3-gram of groups: low word bit a = some anchor window is (a, 3-gram), high
     uint32_t s5_dual;            // word bit d = some anchor window is (3-gram, d); copied to LDS
     uint32_t s5_fifo_cap;        // entries (4 B) of a wave's LDS match fifo
-    uint32_t s5_direct;          // 1: matches go to the pool as they are found (dense dictionaries: units are not sized by the fifo)
-    uint32_t s5_need;            // ... a unit starts with at least this much of the wave's slab (<= slab)
     uint32_t s5_contig;          // 1: a workgroup takes one contiguous run of units (0: the grid moves through the text side by side)
     uint32_t s5_term_bits, s5_pos_bias;   // with positions a fifo entry is term | (pos - (unit.lo - pos_bias)) << term_bits
 };

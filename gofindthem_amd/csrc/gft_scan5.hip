@@ -43,8 +43,6 @@ struct Ctx5 {
     bool lost;                   // wave-uniform: a match did not fit the fifo (or a parked job took its place): walk again
     bool direct;                 // wave-uniform: the second walk of a unit that outgrew the fifo -- appends go to the pool
     uint64_t dbase;              // ... at this entry
-    uint32_t room;               // ... of which this many are the unit's (all it needs on a second walk; what the slab has left
-                                 // when a dense dictionary's units write to the pool from the start: P.s5_direct)
     uint32_t term_bits, pos_base;
 };
 
@@ -54,13 +52,13 @@ __device__ __forceinline__ void out_append(const Scan2Params& P, Ctx5& o, bool e
         const uint32_t idx = o.nf + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
         if (!o.direct) {
             if (idx < o.fifo_cap - o.npend) o.fifo[idx] = P.want_pos ? term | (pos - o.pos_base) << o.term_bits : term;
-        } else if (idx < o.room) {
+        } else {
             KARG(pool_term)[o.dbase + idx] = term;
             if (P.want_pos) KARG(pool_pos)[o.dbase + idx] = pos;
         }
     }
     o.nf += (uint32_t)__popcll(mask);
-    if (o.direct ? o.nf > o.room : o.nf + o.npend > o.fifo_cap) o.lost = true;
+    if (!o.direct && o.nf + o.npend > o.fifo_cap) o.lost = true;
 }
 
 __device__ __forceinline__ void wave_lds_sync() {
@@ -269,7 +267,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
         const uint32_t my_lo = un.lo + lane * C;
         const uint32_t my_hi = my_lo + C < un.hi ? my_lo + C : un.hi;
         const uint32_t nvalid = my_lo < un.hi ? my_hi - my_lo : 0;
-        Ctx5 o{fifo, P.s5_fifo_cap, 0, 0, false, false, 0, 0, P.s5_term_bits, un.lo - P.s5_pos_bias};
+        Ctx5 o{fifo, P.s5_fifo_cap, 0, 0, false, false, 0, P.s5_term_bits, un.lo - P.s5_pos_bias};
 
         // ---- FILTER -----------------------------------------------------------------------------------------------------
         if (P.prio) __builtin_amdgcn_s_setprio(0);
@@ -382,20 +380,6 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
         const uint32_t f = __popc(m0) + __popc(m1) + __popc(m2) + __popc(m3) + (lane == 0 ? nborder : 0);
         const uint32_t fincl = wave_incl_scan(f);
         const uint32_t ftotal = lane_value(fincl, 63);
-        if (P.s5_direct && ftotal) {
-            // a dictionary that matches every few bytes: a unit's matches never fit the fifo (its units would be a few hundred
-            // bytes), so they go to the pool as they are found -- into what is left of the wave's slab, a fresh one when that
-            // is little -- and only a unit that outgrows even that is walked again
-            if (slab_left < KARG(s5_need)) {                       // (what a unit of this batch is expected to need, with a margin)
-                uint64_t nb = 0;
-                if (lane == 0) nb = atomicAdd(reinterpret_cast<unsigned long long*>(KARG(cursor)), (unsigned long long)KARG(slab));
-                slab_next = static_slabs + __shfl(nb, 0, 64);
-                slab_left = KARG(slab);
-            }
-            const uint64_t cap = KARG(pool_cap);
-            const uint64_t pool_room = cap > slab_next ? cap - slab_next : 0;
-            o.direct = true; o.dbase = slab_next; o.room = pool_room < slab_left ? (uint32_t)pool_room : slab_left;
-        }
         for (uint32_t walk = 0; walk < 2 && ftotal; walk++) {
             o.nf = 0; o.npend = 0; o.lost = false;
             for (uint32_t l0 = 0; l0 < 64;) {
@@ -511,9 +495,8 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
                 l0 = l1;
                 mark(4);
             }
-            if (!o.lost || walk) break;
-            // the unit's matches outgrew the fifo (or what the slab had left): their number is known now -- walk it again into a
-            // region of that size
+            if (o.direct || !o.lost) break;
+            // the unit's matches outgrew the fifo: their number is known now -- walk it again into a region of that size
             {
                 const uint32_t nh = o.nf;
                 if (nh > slab_left) {
@@ -525,8 +508,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
                 }
                 o.dbase = slab_next;
                 o.direct = true;
-                o.room = nh;
-                if (slab_next + nh > KARG(pool_cap)) { o.room = 0; break; }   // (beyond the pool: nothing is written, the host runs the batch again)
+                if (slab_next + nh > KARG(pool_cap)) break;        // (beyond the pool: nothing is written, the host runs the batch again)
             }
         }
         if (ftotal) {
@@ -542,7 +524,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
             slab_next += nh;
             slab_left -= nh;
             wave_matches += nh;
-            const bool room = base + nh <= KARG(pool_cap) && !(o.direct && nh > o.room);
+            const bool room = base + nh <= KARG(pool_cap);
             if (lane == 0) { KARG(unit_start)[u] = base; KARG(unit_count)[u] = room ? nh : 0u; }
             if (room && !o.direct) {
                 const uint32_t tmask = (1u << o.term_bits) - 1u;

@@ -486,19 +486,15 @@ def test_two_positions_per_probe_kernel_second_walks_and_merged_groups(monkeypat
     documents, empty documents; a dictionary that matches at every position outgrows the 256-entry fifo in every unit --
     each is then walked a second time straight into a pool region of the counted size; GFT_SCAN5_GROUPS=4 merges the byte
     classes far beyond what LDS asks for (the filter then flags nearly everything: exactness must come from the stages
-    behind it); GFT_SCAN5_DIRECT=1 sends every unit's matches straight to the pool (what the slab has left, a second walk
-    when that is not enough).  Both position conventions, positions packed into the fifo entry next to the term id."""
+    behind it).  Both position conventions, positions packed into the fifo entry next to the term id."""
     from gofindthem_amd.engine import Engine
     from gofindthem_amd import _lib
     monkeypatch.setenv("GFT_SCAN_KERNEL", "scan5")
     rng = np.random.default_rng(11)
     e = Engine()
     try:
-        for groups in (None, "4", "direct"):
-            if groups == "direct":                      # matches written to the pool as they are found (GFT_SCAN5_DIRECT=1)
-                monkeypatch.delenv("GFT_SCAN5_GROUPS", raising=False)
-                monkeypatch.setenv("GFT_SCAN5_DIRECT", "1")
-            elif groups:
+        for groups in (None, "4"):
+            if groups:
                 monkeypatch.setenv("GFT_SCAN5_GROUPS", groups)
             terms = [b"a", b"b", b"ab", b"ba", b"aab", b"abab", b"bbbb", b"abba", b"aaaaa", b"babab", b"ab" * 20 + b"b"]
             lens = [5000, 0, 3, 4100, 70000, 1, 0, 0, 1024, 1025, 5120, 5121, 20000, 2, 300, 31, 33, 1023, 2048, 4096] * 2

@@ -100,7 +100,6 @@ struct gft_engine {
     DevBuf d_s5_grp, d_s5_grp_fold, d_s5_filter;
     uint32_t s5_term_bits = 0, s5_pos_bias = 0;
     uint32_t opt_scan5_fifo = 0;                        // GFT_SCAN5_FIFO: entries of a wave's match fifo (0: 256; timing study)
-    uint32_t opt_scan5_contig = 0;                      // GFT_SCAN5_CONTIG=1: one contiguous run of units per workgroup
     uint32_t opt_scan5_groups = 0;                      // GFT_SCAN5_GROUPS: forced number of filter groups (tests)
     uint64_t scan_valid_docs = ~0ull;                   // documents of the last gft_process scan still in the pool (~0: none)
     uint32_t scan2_unit_max = kScan2UnitMax;            // bytes per work unit (adapts to the match density)
@@ -190,7 +189,6 @@ void refresh_options(gft_engine* e) {
     e->opt_scan4_chunk = (uint32_t)num("GFT_SCAN4_CHUNK", 0);
     e->opt_scan4_round = (uint32_t)num("GFT_SCAN4_ROUND", 0);
     e->opt_scan5_groups = (uint32_t)num("GFT_SCAN5_GROUPS", 0);
-    e->opt_scan5_contig = num("GFT_SCAN5_CONTIG", 0) ? 1u : 0u;
     e->opt_scan5_fifo = (uint32_t)std::min<long>(std::max<long>(num("GFT_SCAN5_FIFO", 0), 0), 4096) & ~63u;
     e->opt_solve_dbg = (uint32_t)num("GFT_SOLVE_DEBUG", 0);
     e->opt_solve_group = (int)num("GFT_SOLVE_GROUP_DOCS", -1);
@@ -725,7 +723,6 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
             P.s5_G = e->s5.G; P.s5_pad_g = e->s5.pad_group;
             P.s5_fifo_cap = e->s5plan.fifo_cap; P.cand_cap = e->s5plan.cand_cap;
             P.s5_term_bits = e->s5_term_bits; P.s5_pos_bias = e->s5_pos_bias;
-            P.s5_contig = e->opt_scan5_contig;
             const uint64_t n_waves5 = (uint64_t)e->n_cus * kScan5Waves;
             P.slab = (uint32_t)std::min<uint64_t>(kScan2Slab, std::max<uint64_t>(64, e->pool_cap / (2 * n_waves5)));
             e->last_static_slabs = std::min<uint64_t>(std::max<uint64_t>((n_units + kScan5Waves - 1) / kScan5Waves, 1), e->n_cus) * kScan5Waves * P.slab;

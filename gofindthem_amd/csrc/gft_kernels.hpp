@@ -277,7 +277,6 @@ struct Scan2Params {
     const uint64_t* s5_filter;   // [s5_dual = G^3] per 3-gram of groups: low word bit a = some anchor window is (a, 3-gram), high
     uint32_t s5_dual;            // word bit d = some anchor window is (3-gram, d); copied to LDS
     uint32_t s5_fifo_cap;        // entries (4 B) of a wave's LDS match fifo
-    uint32_t s5_contig;          // 1: a workgroup takes one contiguous run of units (0: the grid moves through the text side by side)
     uint32_t s5_term_bits, s5_pos_bias;   // with positions a fifo entry is term | (pos - (unit.lo - pos_bias)) << term_bits
 };
 // waves per workgroup (16, 12, 8 or 4) and candidate-list capacity that fit lds_max; false if nothing fits

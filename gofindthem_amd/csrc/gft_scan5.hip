@@ -233,12 +233,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
     // every round k, its waves take them one by one from a counter in LDS
     constexpr uint32_t wg_waves = kScan5Waves;                    // (a constant: item / wg_waves is a shift, not a division per unit)
     const uint64_t round_units = (uint64_t)gridDim.x * wg_waves, wg_first = (uint64_t)blockIdx.x * wg_waves;
-    // (s5_contig: the workgroup owns ONE contiguous run of units instead -- a 2 MB page of text then serves it for 32 rounds)
-    const uint64_t per_wg = (P.n_units + gridDim.x - 1) / gridDim.x, run_lo = (uint64_t)blockIdx.x * per_wg;
-    auto unit_of = [&](uint32_t item) -> uint64_t {
-        if (P.s5_contig) return item < per_wg ? run_lo + item : ~(uint64_t)0;
-        return (uint64_t)(item / wg_waves) * round_units + wg_first + item % wg_waves;
-    };
+    auto unit_of = [&](uint32_t item) -> uint64_t { return (uint64_t)(item / wg_waves) * round_units + wg_first + item % wg_waves; };
     uint64_t u = unit_of(wave), nu = 0;                           // wave-uniform
     Unit un_n{0, 0, 0};
     uint64_t abs_n = 0, end_n = 0;                               // the next unit's document: blob offsets of its first byte and of the byte behind it
@@ -289,14 +284,13 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
             }
             pq = mad24s(h2, G, h1);
             mark(0);
-            uint32_t acc = 0, njobs = 0;                         // njobs: pieces that hold a byte >= 0x80 (noted in the candidate list, idle until the filter is done)
+            uint32_t acc = 0, njobs = 0, hib = 0;                // hib: OR of the lane's text (a byte >= 0x80 anywhere?)
             const bool want_fold = P.fold && P.nonascii;
             const uint32_t ndw = C >> 2;                         // dwords per lane (wave-uniform, <= 32)
             const uint32_t npieces = (ndw + 3) >> 2;
             for (uint32_t q = 0; q < npieces; q++) {
                 const uint32_t w[4] = {nxt.x, nxt.y, nxt.z, nxt.w};
-                // ASCII folding is not strings.ToLower once the text leaves ASCII (finder.go:140-142): gft_foldsafe_dev.hpp
-                if (want_fold) fold_job_push(q * 16 < nvalid && (((w[0] | w[1]) | (w[2] | w[3])) & 0x80808080u) != 0, lane * C + q * 16, cand, P.cand_cap, njobs);
+                if (q * 16 < nvalid) hib |= (w[0] | w[1]) | (w[2] | w[3]);   // (may take in up to 15 bytes behind the lane's range: conservative)
                 if (q + 1 < npieces && (q + 1) * 16 < nvalid) nxt = *reinterpret_cast<const U128u*>(src + (q + 1) * 16);
                 const uint32_t nd = ndw - 4 * q;                 // dwords of this piece that belong to the lane (>= 1)
                 // probe at byte 0 of a dword: 3-gram (h2, h1, c0); the window that ends there has h3 in front, the window that
@@ -345,6 +339,13 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
                 const uint32_t v = acc >> (32 - 4 * (ndw & 7));
                 const uint32_t k = ndw >> 3;
                 if (k == 0) m0 = v; else if (k == 1) m1 = v; else if (k == 2) m2 = v; else m3 = v;
+            }
+            // ASCII folding is not strings.ToLower once the text leaves ASCII (finder.go:140-142): the pieces of the lanes that
+            // met a byte >= 0x80 are judged now (gft_foldsafe_dev.hpp; which of a lane's pieces it was is not kept -- text that
+            // leaves ASCII is the exception for the dictionaries this kernel serves, the filter loop pays two ORs for it)
+            if (want_fold && !told_nonascii && __any((hib & 0x80808080u) != 0)) {
+                for (uint32_t q = 0; q < npieces; q++)
+                    fold_job_push((hib & 0x80808080u) != 0 && q * 16 < nvalid, lane * C + q * 16, cand, P.cand_cap, njobs);
             }
             if (njobs && !told_nonascii) {
                 // bit 1: a piece breaks the rule; bit 0: more pieces than the list holds -- the host then checks the text itself

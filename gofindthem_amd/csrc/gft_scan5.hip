@@ -224,8 +224,10 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
     auto mark = [&](int ph) {
         if (DBG && (P.dbg & 64)) { const unsigned long long now = clock64(); tl[ph] += now - tprev; tprev = now; }
     };
-    const uint64_t static_slabs = (uint64_t)gridDim.x * kScan5Waves * KARG(slab);
-    uint64_t slab_next = ((uint64_t)blockIdx.x * kScan5Waves + wave) * KARG(slab), wave_matches = 0;   // wave-uniform
+    // (the slabs that every wave of the grid owns from the start: the cursor counts what is taken behind them)
+    auto static_slabs = [&]() { return (uint64_t)gridDim.x * kScan5Waves * KARG(slab); };
+    uint64_t slab_next = ((uint64_t)blockIdx.x * kScan5Waves + wave) * KARG(slab);   // wave-uniform
+    uint32_t wave_matches = 0;                                    // (a wave's share of a launch stays far below 2^32)
     bool told_nonascii = false;
     uint32_t slab_left = KARG(slab);
 
@@ -243,8 +245,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
                       (uint32_t)__builtin_amdgcn_readfirstlane(un_n.hi)};
         const uint64_t doc_abs = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(abs_n >> 32)) << 32 |
                                  (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)abs_n);
-        const uint64_t doc_end = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(end_n >> 32)) << 32 |
-                                 (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)end_n);
+        const uint64_t end_v = end_n;                             // (the document's end is read by the fold-safety check only: kept in its vector register)
         {
             uint32_t item = 0;
             if (lane == 0) item = __hip_atomic_fetch_add(wg_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -354,7 +355,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
                 uint32_t bits = 1u;
                 if (njobs <= P.cand_cap) {
                     FOLD_JOB_VARS(fj_);
-                    bits = fold_jobs_begin(P.text, doc_end, doc_abs + un.lo, own, un.lo == 0, cand, njobs, FOLD_JOB_PASS(fj_)) || fold_jobs_finish(FOLD_JOB_PASS(fj_)) ? 2u : 0u;
+                    bits = fold_jobs_begin(P.text, end_v, doc_abs + un.lo, own, un.lo == 0, cand, njobs, FOLD_JOB_PASS(fj_)) || fold_jobs_finish(FOLD_JOB_PASS(fj_)) ? 2u : 0u;
                 }
                 if (bits) { told_nonascii = true; if (lane == 0) atomicOr(P.nonascii, bits); }
             }
@@ -504,7 +505,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
                     const uint32_t want = nh > KARG(slab) ? nh : KARG(slab);
                     uint64_t nb = 0;
                     if (lane == 0) nb = atomicAdd(reinterpret_cast<unsigned long long*>(KARG(cursor)), (unsigned long long)want);
-                    slab_next = static_slabs + __shfl(nb, 0, 64);
+                    slab_next = static_slabs() + __shfl(nb, 0, 64);
                     slab_left = want;
                 }
                 o.dbase = slab_next;
@@ -518,7 +519,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
                 const uint32_t want = nh > KARG(slab) ? nh : KARG(slab);
                 uint64_t nb = 0;
                 if (lane == 0) nb = atomicAdd(reinterpret_cast<unsigned long long*>(KARG(cursor)), (unsigned long long)want);
-                slab_next = static_slabs + __shfl(nb, 0, 64);
+                slab_next = static_slabs() + __shfl(nb, 0, 64);
                 slab_left = want;
             }
             const uint64_t base = slab_next;

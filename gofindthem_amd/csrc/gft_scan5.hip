@@ -266,7 +266,6 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
         Ctx5 o{fifo, P.s5_fifo_cap, 0, 0, false, false, 0, P.s5_term_bits, un.lo - P.s5_pos_bias};
 
         // ---- FILTER -----------------------------------------------------------------------------------------------------
-        if (P.prio) __builtin_amdgcn_s_setprio(0);
         uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
         if (own) {
             // the groups of the three bytes in front of the lane's range (the pad group in front of the document)
@@ -366,7 +365,6 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
             m3 = nvalid >= 128 ? m3 : (nvalid > 96 ? m3 & ((1u << (nvalid - 96)) - 1) : 0);
         }
         mark(1);
-        if (P.prio) __builtin_amdgcn_s_setprio(1);
         if (more_units) { abs_n = P.doc_off[un_n.doc]; end_n = P.doc_off[un_n.doc + 1]; }
 
         if (DBG && P.dbg) {
@@ -411,7 +409,6 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
                 // stage A: every flagged position -> LDS-only decisions; short terms are emitted here, positions that may end a
                 // term of length >= 4 are compacted in place to the front of the list (write index <= read index)
                 mark(2);
-                if (P.prio) __builtin_amdgcn_s_setprio(2);
                 uint32_t ns = 0;
                 bool n_on[kWays5];
                 uint32_t n_rel[kWays5];
@@ -460,7 +457,6 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
                 while (o.npend) short_trip(c, o, ubase, o.npend < 64 ? o.npend : 64);
                 if (DBG && (P.dbg & 2)) { if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(KARG(dbg_counters) + 2), (unsigned long long)ns); }
                 mark(3);
-                if (P.prio) __builtin_amdgcn_s_setprio(3);
                 // stage B: the survivors, densely packed over the lanes, go to the L2 bucket table
                 Deferred dfr;
                 dfr.list = reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(cand) + ((ns * 2 + 7) & ~7u));

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Timing study of the scan kernel alone (not part of the test-suite or the bench contract).
     python tools/probe_scan.py [--docs N] [--terms T]
-Prints the scan kernel's HIP-event time for the production kernel and for the GFT_SCAN_DEBUG timing variants."""
+Prints the scan kernel's HIP-event time for the production kernel and for the GFT_SCAN_DEBUG timing variants.
+(The figure is a mean over the launches of a few calls: with a dictionary whose units are resized after the first batch --
+100 000 terms -- it includes that batch's short second launch; bench.py's per-step kernel time is the one to quote there.)"""
 import argparse
 import os
 import sys
@@ -19,6 +21,7 @@ ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--alphabet", default="lower")
 ap.add_argument("--modes", default="0,1,2")
 ap.add_argument("--unordered", action="store_true", help="time the scan as the process path runs it (any order)")
+ap.add_argument("--positions", action="store_true", help="with --unordered: an INORD program, so that the scan also writes positions")
 args = ap.parse_args()
 
 wl = Workload(args.terms, alphabet=args.alphabet)
@@ -36,7 +39,8 @@ def make_engine():
     eng = Engine(0)
     eng.build(sorted({t.decode('utf-8').lower().encode('utf-8') for t in wl.terms()}))
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
-    eng.set_programs([[1 << 28]])
+    # (one UNIT program: presence only; inord(t0 and t1): the scan writes positions too)
+    eng.set_programs([[1 << 28 | 1 << 27 | 0, 1 << 28 | 1 << 27 | 1, 2 << 28 | 1 << 27, 5 << 28]] if args.positions else [[1 << 28]])
 
 
 class _M:

@@ -99,6 +99,8 @@ struct gft_engine {
     Scan5Tables s5;
     DevBuf d_s5_grp, d_s5_grp_fold, d_s5_filter;
     uint32_t s5_term_bits = 0, s5_pos_bias = 0;
+    bool s5_short_groups = false;                       // scan5 takes its short terms from the stride-2 kernel's tables (> 32 byte classes)
+    uint32_t opt_scan5_large = 1;                       // GFT_SCAN5_LARGE=0: dictionaries over more than 32 byte classes stay on the stride-2 kernel
     uint32_t opt_scan5_fifo = 0;                        // GFT_SCAN5_FIFO: entries of a wave's match fifo (0: 256; timing study)
     uint32_t opt_scan5_groups = 0;                      // GFT_SCAN5_GROUPS: forced number of filter groups (tests)
     uint64_t scan_valid_docs = ~0ull;                   // documents of the last gft_process scan still in the pool (~0: none)
@@ -189,6 +191,7 @@ void refresh_options(gft_engine* e) {
     e->opt_scan4_chunk = (uint32_t)num("GFT_SCAN4_CHUNK", 0);
     e->opt_scan4_round = (uint32_t)num("GFT_SCAN4_ROUND", 0);
     e->opt_scan5_groups = (uint32_t)num("GFT_SCAN5_GROUPS", 0);
+    e->opt_scan5_large = num("GFT_SCAN5_LARGE", 1) ? 1u : 0u;
     e->opt_scan5_fifo = (uint32_t)std::min<long>(std::max<long>(num("GFT_SCAN5_FIFO", 0), 0), 4096) & ~63u;
     e->opt_solve_dbg = (uint32_t)num("GFT_SOLVE_DEBUG", 0);
     e->opt_solve_group = (int)num("GFT_SOLVE_GROUP_DOCS", -1);
@@ -722,6 +725,16 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
             P.s5_grp = P.fold ? e->d_s5_grp_fold.as<uint8_t>() : e->d_s5_grp.as<uint8_t>();
             P.s5_G = e->s5.G; P.s5_pad_g = e->s5.pad_group;
             P.s5_fifo_cap = e->s5plan.fifo_cap; P.cand_cap = e->s5plan.cand_cap;
+            P.s5_sG = 0; P.s5_sgrp = nullptr; P.s5_srec_big = nullptr;
+            if (e->s5_short_groups) {
+                // more than 32 byte classes: the short terms through the group-indexed tables of the stride-2 kernel's set
+                P.short3 = e->d_s3_short3.as<uint8_t>(); P.short3_bytes = (uint32_t)e->s3.short3.size();
+                P.shorts_packed = e->d_s3_srec.as<uint32_t>(); P.shorts_words = (uint32_t)e->s3.srec.size();
+                P.short3_big = e->s3.short3_big.empty() ? nullptr : e->d_s3_short3_big.as<uint32_t>();
+                P.s5_srec_big = e->d_s3_srec_big.as<uint32_t>();
+                P.s5_sgrp = P.fold ? e->d_s3_cls_fold.as<uint8_t>() : e->d_s3_cls.as<uint8_t>();
+                P.s5_sG = e->s3.G;
+            }
             P.s5_term_bits = e->s5_term_bits; P.s5_pos_bias = e->s5_pos_bias;
             const uint64_t n_waves5 = (uint64_t)e->n_cus * kScan5Waves;
             P.slab = (uint32_t)std::min<uint64_t>(kScan2Slab, std::max<uint64_t>(64, e->pool_cap / (2 * n_waves5)));
@@ -1340,24 +1353,34 @@ static int install_tables(gft_engine* e, uint32_t flags) {
         e->use_scan4 = e->use_scan2 && k4_fits && force && std::string(force) == "scan4";
         e->scan4_density = 0.06;
     }
-    // the suffix-window kernel with one filter probe per two bytes -- the default wherever gft_scan2's direct tables apply
-    // (GFT_SCAN_KERNEL=scan2: the one-probe-per-byte kernel): scan2's tables, a fifo entry of 32 bits holds term id and
-    // relative position
+    // The suffix-window kernel with one filter probe per two bytes: the default for every dictionary whose long-term tables
+    // exist (GFT_SCAN_KERNEL=scan2: the one-probe-per-byte kernel, scan3: the stride-2 kernel).  It runs on scan2's tables; a
+    // fifo entry of 32 bits holds term id and relative position.  With more than 32 byte classes there is no
+    // direct short-term table (Scan2Tables::short_direct): the group-indexed one of the stride-2 kernel's tables serves then
+    // (GFT_SCAN5_LARGE=0 leaves such dictionaries to the stride-2 kernel).
     e->use_scan5 = false;
-    if (e->use_scan2 && !e->s2.hashed && (!force || std::string(force) == "scan5" || std::string(force) == "auto" || !*force)) {
+    e->s5_short_groups = false;
+    const bool want5 = !force || std::string(force) == "scan5" || std::string(force) == "auto" || !*force;
+    const bool large5 = e->s2.long_ok && !e->s2.short_direct && e->s3.supported && e->opt_scan5_large;
+    if ((e->use_scan2 || large5) && e->s2.long_ok && want5) {
         uint32_t tb = 1;
         while ((1ull << tb) < e->tab.terms.size()) tb++;
         e->s5_term_bits = tb;
         e->s5_pos_bias = e->tab.max_term_len + kScan2MaxOff;
         const bool packs = (uint64_t)kScan2UnitMax + e->s5_pos_bias + 8 < (1ull << (32 - tb));
-        if (packs && scan5_plan(e->s2.kp, (uint32_t)e->s2.short3.size(), (uint32_t)std::min<size_t>(e->s2.shorts_packed.size(), 255 * 3),
-                                e->s2.fpt_lg ? 0u : kScan2FptSize, e->lds_max - 512, e->opt_scan5_fifo ? e->opt_scan5_fifo : kScan2FifoCap, &e->s5plan)) {
+        const uint32_t short_bytes = large5 ? (uint32_t)e->s3.short3.size() : (uint32_t)e->s2.short3.size();
+        const uint32_t rec_words = large5 ? (uint32_t)e->s3.srec.size() : (uint32_t)std::min<size_t>(e->s2.shorts_packed.size(), 255 * 3);
+        if (packs && scan5_plan(e->s2.kp, short_bytes, rec_words, e->s2.fpt_lg ? 0u : kScan2FptSize, e->lds_max - 512,
+                                e->opt_scan5_fifo ? e->opt_scan5_fifo : kScan2FifoCap, &e->s5plan)) {
             if (e->opt_scan5_groups && e->opt_scan5_groups < e->s5plan.G) {      // (tests: more merging than LDS asks for)
                 e->s5plan.G = std::max<uint32_t>(e->opt_scan5_groups, 2);
                 e->s5plan.dual_entries = e->s5plan.G * e->s5plan.G * e->s5plan.G;
             }
             build_scan5_tables(e->tab, e->s2, e->s5plan.G, e->s5);
             e->use_scan5 = true;
+            e->s5_short_groups = large5;
+            e->use_scan2 = true;           // (the scan2 family's path through scan_pipeline; gft_scan2.hip itself runs only when s2.supported)
+            if (!k2_fits) { e->scan2_k2_waves = kScan5Waves; e->scan2_cand_cap = e->s5plan.cand_cap; }   // (what that path sizes slabs by)
         }
     }
     // Kernel choice: the suffix-window kernel (scan2) where its direct tables apply -- small alphabets, the benchmark's
@@ -1399,6 +1422,19 @@ static int install_tables(gft_engine* e, uint32_t flags) {
                 e->s2.kp, n_slots, n_simple, e->s2.slots.size(), n_used, n_ff, (unsigned)e->s2.fpt.size(), e->s2.shorts.size() - 1,
                 e->s2.hashed ? "hashed" : "direct", e->s2.filter_bits, e->scan2_k2_waves);
         fprintf(stderr, "[gft build debug] candidate list capacity %u per wave\n", e->scan2_cand_cap);
+    }
+    if (e->use_scan5 && e->s5_short_groups && !e->use_scan3) {
+        // the short-term tables of the stride-2 kernel's set, which is not uploaded as a whole then
+        s3v = e->s3.short3;
+        if (s3v.empty()) s3v.assign(16, 0);
+        if ((rc = upload(e, e->d_s3_short3, s3v, "table upload"))) return rc;
+        if ((rc = upload(e, e->d_s3_srec, e->s3.srec, "table upload"))) return rc;
+        if (!e->s3.short3_big.empty() && (rc = upload(e, e->d_s3_short3_big, e->s3.short3_big, "table upload"))) return rc;
+        if ((rc = upload(e, e->d_s3_srec_big, e->s3.srec_big, "table upload"))) return rc;
+        g1.assign(e->s3.cls, e->s3.cls + 256); g2.assign(e->s3.cls_fold, e->s3.cls_fold + 256);
+        if ((rc = upload(e, e->d_s3_cls, g1, "table upload"))) return rc;
+        if ((rc = upload(e, e->d_s3_cls_fold, g2, "table upload"))) return rc;
+        HIP_TRY(hipStreamSynchronize(e->stream), "table upload");      // g1 / g2 / s3v are locals
     }
     if (e->use_scan2) {
         e->scan2_short3_bytes = (uint32_t)e->s2.short3.size();
@@ -1561,6 +1597,10 @@ int gft_import_tables(gft_engine* e, const uint8_t* blob, uint64_t len) try {
     e->tab = std::move(a);
     e->s2 = std::move(t);
     e->s3 = std::move(u);
+    // (a dictionary whose suffix-window set is not serialised as complete -- more than 32 byte classes -- gets its long-term
+    // tables from the compiler again: a blob only ever holds what validate_tables checks)
+    if (!e->s2.supported) build_scan2_tables(e->tab, e->s2);
+    else e->s2.long_ok = true;
     return install_tables(e, flags);
 } GFT_CATCH((e ? &e->err : nullptr))
 

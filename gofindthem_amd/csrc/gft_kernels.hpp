@@ -277,6 +277,11 @@ struct Scan2Params {
     const uint64_t* s5_filter;   // [s5_dual = G^3] per 3-gram of groups: low word bit a = some anchor window is (a, 3-gram), high
     uint32_t s5_dual;            // word bit d = some anchor window is (3-gram, d); copied to LDS
     uint32_t s5_fifo_cap;        // entries (4 B) of a wave's LDS match fifo
+    // ... over an alphabet too large for the direct short-term table (s5_sG != 0): short3 / shorts_packed / short3_big are the
+    // group-indexed tables of scan3_tables.hpp (short3, srec, short3_big), plus:
+    const uint8_t* s5_sgrp;      // [256] byte -> group of those tables (the folded table when GFT_FOLD_ASCII), copied to LDS
+    uint32_t s5_sG;              // their number of groups (0: the direct table of exact classes)
+    const uint32_t* s5_srec_big; // records of the cells with id 255 ({n, n x 2 words})
     uint32_t s5_term_bits, s5_pos_bias;   // with positions a fifo entry is term | (pos - (unit.lo - pos_bias)) << term_bits
 };
 // waves per workgroup (16, 12, 8 or 4) and candidate-list capacity that fit lds_max; false if nothing fits

@@ -116,6 +116,61 @@ __device__ __forceinline__ void park_short(const Ctx& c, Ctx5& o, uint32_t ubase
     o.npend += n;
 }
 
+// ---- short terms over an alphabet too large for the direct K^3 table (SG = true): the tables of the stride-2 kernel
+// (scan3_tables.hpp) -- a record id per 3-window of byte GROUPS, records of up to three {term | len << 28, the term's bytes
+// as text[e-3 .. e]} -- so a record's terms are verified against the text (gft_scan3.hip stage_s).  Stage A parks {position,
+// record id}; ids of 255 name cells whose records live in global memory (short3_big / srec_big) ------------------------------
+__device__ __forceinline__ void short_trip_g(const Ctx& c, Ctx5& o, lds_u8* lsg, uint32_t ubase, uint32_t n) {
+    const Scan2Params& P = c.P;
+    const uint32_t lane = lane_id();
+    const bool on = lane < n;
+    const uint32_t job = o.fifo[o.fifo_cap - 1 - (o.npend - n) - (on ? lane : 0)];
+    o.npend -= n;
+    const uint32_t p = ubase + (job & 0xFFFFu);
+    uint32_t sid = on ? job >> 16 : 0;
+    const Text8 t8 = cand_load(c, p);
+    const uint32_t W = P.fold ? fold4(t8.w) : t8.w;               // text[p-3 .. p]
+    if (__builtin_expect(__any(sid == 255), 0)) {
+        const uint32_t G = P.s5_sG;
+        const uint32_t x3 = (lsg[(t8.w >> 8) & 0xFF] * G + lsg[(t8.w >> 16) & 0xFF]) * G + lsg[t8.w >> 24];
+        const bool b = sid == 255;
+        uint32_t cnt = 0;
+        const uint32_t* g = nullptr;
+        if (b) { g = KARG(s5_srec_big) + KARG(short3_big)[x3]; cnt = g[0]; }
+        for (uint32_t j = 0; __any(j < cnt); j++) {
+            uint32_t w0 = 0, w1 = 0;
+            if (j < cnt) { w0 = g[1 + 2 * j]; w1 = g[2 + 2 * j]; }
+            const uint32_t L = w0 >> 28;
+            const bool ok = w0 != 0 && L <= p + 1 && ((W ^ w1) >> ((32 - 8 * L) & 31)) == 0;
+            out_append(P, o, ok, w0 & 0x0FFFFFFFu, P.pos_end ? p : p + 1 - L);
+        }
+        if (b) sid = 0;
+    }
+    if (!__any(sid != 0)) return;
+    const uint32_t* r = c.lrec + sid * kScan3RecWords;
+#pragma unroll
+    for (uint32_t j = 0; j < 3; j++) {
+        const uint32_t w0 = sid ? r[2 * j] : 0;
+        if (j && !__any(w0 != 0)) break;
+        const uint32_t L = w0 >> 28;
+        const bool ok = w0 != 0 && L <= p + 1 && ((W ^ r[2 * j + 1]) >> ((32 - 8 * L) & 31)) == 0;
+        out_append(P, o, ok, w0 & 0x0FFFFFFFu, P.pos_end ? p : p + 1 - L);
+    }
+}
+__device__ __forceinline__ void park_short_g(const Ctx& c, Ctx5& o, lds_u8* lsg, uint32_t ubase, uint32_t rel, uint32_t sid) {
+    if (!__any(sid != 0)) return;
+    const uint64_t m = __ballot(sid != 0);
+    const uint32_t n = (uint32_t)__popcll(m);
+    if (o.npend + n > o.fifo_cap / 2) {
+        wave_lds_sync();
+        while (o.npend) short_trip_g(c, o, lsg, ubase, o.npend < 64 ? o.npend : 64);
+        wave_lds_sync();
+    }
+    if (!o.direct && o.nf + o.npend + n > o.fifo_cap) o.lost = true;   // (the jobs go where matches are)
+    if (sid) o.fifo[o.fifo_cap - 1 - o.npend - __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0))] = rel | sid << 16;
+    o.npend += n;
+}
+
 // gft_scan2_dev.hpp finish_long / drain_deferred with the text in LDS and the 4-byte fifo
 __device__ __forceinline__ void finish_long5(const Ctx& c, Ctx5& o, bool on, uint32_t rel, const Cand& k, const Slot& s0, const Slot& s1,
                                              Front t, uint32_t tl, Deferred& d) {
@@ -182,20 +237,22 @@ __device__ __forceinline__ void drain_deferred5(const Ctx& c, Ctx5& o, uint32_t 
     __builtin_amdgcn_wave_barrier();
 }
 
-// FPT_LDS: the fingerprint table is staged in LDS; DBG: the timing-study instantiation (GFT_SCAN_DEBUG)
-template <bool FPT_LDS, bool DBG>
+// FPT_LDS: the fingerprint table is staged in LDS; DBG: the timing-study instantiation (GFT_SCAN_DEBUG); SG: the short terms
+// come from the group-indexed tables of the stride-2 kernel (an alphabet of more than 32 byte classes: short_trip_g)
+template <bool FPT_LDS, bool DBG, bool SG>
 __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
     extern __shared__ __align__(16) uint8_t smem[];
     uint8_t* grp = smem;                                          // byte -> filter group
     uint8_t* cls = smem + 256;                                    // byte -> exact class
-    uint64_t* dual = reinterpret_cast<uint64_t*>(smem + 512);     // [G^3] the filter
+    uint8_t* sgrp = smem + 512;                                   // SG: byte -> group of the short-term tables
+    uint64_t* dual = reinterpret_cast<uint64_t*>(smem + 768);     // [G^3] the filter
     uint8_t* short3 = reinterpret_cast<uint8_t*>(dual + P.s5_dual);
     uint8_t* fpt = short3 + P.short3_bytes;                       // (short3_bytes is a multiple of 16)
     uint32_t* lrec = reinterpret_cast<uint32_t*>(fpt + (FPT_LDS ? kScan2FptSize : 0));
     uint32_t* wg_next = reinterpret_cast<uint32_t*>(smem + (((size_t)(reinterpret_cast<uint8_t*>(lrec) - smem) + P.shorts_words * 4 + 15) & ~(size_t)15));
     uint8_t* wave_lds_all = reinterpret_cast<uint8_t*>(wg_next) + 16;
 
-    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) { grp[i] = P.s5_grp[i]; cls[i] = P.cls[i]; }
+    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) { grp[i] = P.s5_grp[i]; cls[i] = P.cls[i]; sgrp[i] = SG ? P.s5_sgrp[i] : 0; }
     for (uint32_t i = threadIdx.x; i < P.s5_dual; i += blockDim.x) dual[i] = P.s5_filter[i];
     for (uint32_t i = threadIdx.x; i < P.short3_bytes / 4; i += blockDim.x)
         reinterpret_cast<uint32_t*>(short3)[i] = reinterpret_cast<const uint32_t*>(P.short3)[i];
@@ -217,7 +274,8 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
     lds_u8* lgrp = (lds_u8*)0;
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     typedef __attribute__((address_space(3))) const u32x2 lds_u64;
-    lds_u64* ldual = (lds_u64*)512;
+    lds_u64* ldual = (lds_u64*)768;
+    lds_u8* lsg = (lds_u8*)512;
     if ((uint32_t)(uintptr_t)(lds_u8*)smem != 0) __builtin_trap();   // see lds_u8
 
     unsigned long long tl[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = DBG ? clock64() : 0;
@@ -433,13 +491,22 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
                     for (int q = 0; q < kWays5; q++) { on[q] = n_on[q]; rel[q] = n_rel[q]; tx[q] = n_tx[q]; }
                     if (i0 + 64 * kWays5 < ptotal) fetch(i0 + 64 * kWays5);
 #pragma unroll
-                    for (int q = 0; q < kWays5; q++) cand_keys(c, ubase + rel[q], tx[q], k[q]);
+                    for (int q = 0; q < kWays5; q++) {
+                        cand_keys<!SG>(c, ubase + rel[q], tx[q], k[q]);
+                        if (SG && P.short3_bytes) {
+                            const uint32_t wq = tx[q].w, sG = P.s5_sG;
+                            k[q].sid = short3[mad24s(mad24s(lsg[(wq >> 8) & 0xFF], sG, lsg[(wq >> 16) & 0xFF]), sG, lsg[wq >> 24])];
+                        }
+                    }
 #pragma unroll
                     for (int q = 0; q < kWays5; q++) cand_decide<FPT_LDS>(c, k[q]);
 #pragma unroll
                     for (int q = 0; q < kWays5; q++)
                         if (i0 + 64 * q < ptotal)                  // (positions in front of the unit: long terms only)
-                            park_short(c, o, ubase, rel[q], on[q] && rel[q] >= kScan2MaxOff ? k[q].sid : 0, k[q].x3);
+                        {
+                            const uint32_t sidq = on[q] && rel[q] >= kScan2MaxOff ? k[q].sid : 0;
+                            if (SG) park_short_g(c, o, lsg, ubase, rel[q], sidq); else park_short(c, o, ubase, rel[q], sidq, k[q].x3);
+                        }
                     const uint64_t below = (1ull << lane) - 1;
 #pragma unroll
                     for (int q = 0; q < kWays5; q++) {
@@ -454,7 +521,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
                     }
                 }
                 wave_lds_sync();
-                while (o.npend) short_trip(c, o, ubase, o.npend < 64 ? o.npend : 64);
+                while (o.npend) { if (SG) short_trip_g(c, o, lsg, ubase, o.npend < 64 ? o.npend : 64); else short_trip(c, o, ubase, o.npend < 64 ? o.npend : 64); }
                 if (DBG && (P.dbg & 2)) { if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(KARG(dbg_counters) + 2), (unsigned long long)ns); }
                 mark(3);
                 // stage B: the survivors, densely packed over the lanes, go to the L2 bucket table
@@ -565,7 +632,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
 }  // namespace
 
 static size_t scan5_fixed_lds(uint32_t dual_entries, uint32_t short3_bytes, uint32_t shorts_words, uint32_t fpt_lds_bytes) {
-    return ((512 + (size_t)dual_entries * 8 + short3_bytes + fpt_lds_bytes + (size_t)shorts_words * 4 + 15) & ~(size_t)15) + 16;
+    return ((768 + (size_t)dual_entries * 8 + short3_bytes + fpt_lds_bytes + (size_t)shorts_words * 4 + 15) & ~(size_t)15) + 16;
 }
 static size_t scan5_wave_lds(uint32_t fifo_cap, uint32_t cand_cap) {
     return (size_t)fifo_cap * 4 + kScan5SurvX * 4 + (((size_t)cand_cap * 2 + 15) & ~(size_t)15);
@@ -596,7 +663,9 @@ hipError_t launch_scan5(const Scan2Params& P, unsigned n_cus, hipStream_t st) {
     const size_t lds = scan5_fixed_lds(P.s5_dual, P.short3_bytes, P.shorts_words, fl ? kScan2FptSize : 0) +
                        (size_t)kScan5Waves * scan5_wave_lds(P.s5_fifo_cap, P.cand_cap);
     using Kern = void (*)(const Scan2Params);
-    const Kern fn = P.dbg ? (fl ? k_scan5<true, true> : k_scan5<false, true>) : (fl ? k_scan5<true, false> : k_scan5<false, false>);
+    // (the timing-study instantiations exist for the direct short-term table only)
+    const Kern fn = P.s5_sG ? (fl ? k_scan5<true, false, true> : k_scan5<false, false, true>)
+                    : P.dbg ? (fl ? k_scan5<true, true, false> : k_scan5<false, true, false>) : (fl ? k_scan5<true, false, false> : k_scan5<false, false, false>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     uint64_t g = (P.n_units + kScan5Waves - 1) / kScan5Waves;

@@ -25,7 +25,10 @@ void build_scan2_tables(const AcTables& ac, Scan2Tables& t) {
     const uint64_t kp3 = (uint64_t)kp * kp * kp;
     bool any_short = false;
     for (const auto& s : ac.terms) any_short |= !s.empty() && s.size() < kWin;
-    if (any_short && kp3 > kScan2Short3Max) { t.why_not = "terms shorter than 4 bytes over a large alphabet"; return; }
+    // (too many byte classes for a direct K^3 table of the short terms: gft_scan2.hip cannot run, the tables of the long terms
+    // are built all the same -- gft_scan5.hip takes its short terms from Scan3Tables then)
+    t.short_direct = !(any_short && kp3 > kScan2Short3Max);
+    if (!t.short_direct) t.why_not = "terms shorter than 4 bytes over a large alphabet";
 
     // ---- terms of length >= 4: buckets keyed by the four classes of their window ----------------------------------
     // The window ends `off` bytes before the term's end (gft_kernels.hpp, kScan2MaxOff).  Every text position whose last
@@ -74,7 +77,7 @@ void build_scan2_tables(const AcTables& ac, Scan2Tables& t) {
     std::unordered_map<uint32_t, std::vector<Ent>> buckets;
     buckets.reserve(ac.terms.size() * 2);
     std::vector<std::vector<uint32_t>> content;   // per 3-window: short terms ending there
-    if (any_short) content.resize((size_t)kp3);
+    if (any_short && t.short_direct) content.resize((size_t)kp3);
     // term blob: 4 bytes of slack in front of every term (the kernel compares unaligned dwords that may start up to
     // 3 bytes before a term); term_off[id] points at the term's first byte
     t.term_off.clear();
@@ -92,7 +95,7 @@ void build_scan2_tables(const AcTables& ac, Scan2Tables& t) {
         for (uint32_t i = L1 - m; i < L1; i++) tail = tail * kp + ac.byte_class[(uint8_t)s[i]];
         if (L >= kWin) {
             buckets[tail].push_back(Ent{(uint32_t)id, L1, off});
-        } else {
+        } else if (t.short_direct) {
             // a short term ends every 3-window whose last L classes are the term
             uint32_t scale = 1, combos = 1;
             for (uint32_t i = 0; i < L; i++) scale *= kp;
@@ -116,7 +119,7 @@ void build_scan2_tables(const AcTables& ac, Scan2Tables& t) {
 
     // ---- short3: records of up to three short terms, longest first -------------------------------------------------------
     t.shorts.assign(1, Scan2Short{0, {0, 0, 0}, {0, 0, 0}, 0});
-    if (any_short) {
+    if (any_short && t.short_direct) {
         t.short3.assign(((size_t)kp3 + 15) & ~(size_t)15, 0);
         std::map<std::vector<uint32_t>, uint32_t> ids;
         for (size_t w = 0; w < content.size(); w++) {
@@ -256,8 +259,9 @@ void build_scan2_tables(const AcTables& ac, Scan2Tables& t) {
     t.term_blob.insert(t.term_blob.end(), 8, 0);
     t.term_off.push_back((uint32_t)t.term_blob.size());
     if (t.more.empty()) t.more.push_back(Scan2Slot{kScan2EmptyKey, 0, 0, {0, 0, 0, 0, 0}});
-    t.supported = t.more.size() < (1u << 31);
-    if (!t.supported) t.why_not = "bucket table too large";
+    t.long_ok = t.more.size() < (1u << 31);
+    if (!t.long_ok) t.why_not = "bucket table too large";
+    t.supported = t.long_ok && t.short_direct;
 }
 
 }  // namespace gft
@@ -292,16 +296,42 @@ void build_scan5_tables(const AcTables& ac, const Scan2Tables& s2, uint32_t G, S
     }
     t.pad_group = group_of[s2.pad_class];
     for (int b = 0; b < 256; b++) { t.grp[b] = (uint8_t)group_of[s2.cls[b]]; t.grp_fold[b] = (uint8_t)group_of[s2.cls_fold[b]]; }
-    // every window (a, b, c, d) the exact filter flags, in group space, under both of its 3-grams
+    // Every anchor window (a, b, c, d), in group space, under both of its 3-grams: bit a of the low word of entry (b, c, d) --
+    // the probe at the window's last byte --, bit d of the high word of entry (a, b, c) -- the probe one byte earlier.  The
+    // windows of the long terms are the keys of the bucket table; a term of length L <= 3 ends every window whose last L
+    // classes are the term (what Scan2Tables::filter holds as bits, when it is direct; built here from the terms themselves,
+    // so that an alphabet too large for that filter is served as well).
     t.filter.assign((size_t)G * G * G, 0);
-    const uint64_t kbits = (uint64_t)kp * kp * kp * kp;
-    for (uint64_t key = 0; key < kbits && !s2.hashed; key++) {
-        if (!(s2.filter[key >> 5] >> (key & 31) & 1)) continue;
-        const uint32_t d = group_of[key % kp], c = group_of[key / kp % kp], b = group_of[key / ((uint64_t)kp * kp) % kp],
-                       a = group_of[key / ((uint64_t)kp * kp * kp)];
+    auto add_window = [&](uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
         t.filter[((size_t)b * G + c) * G + d] |= 1ull << a;
         t.filter[((size_t)a * G + b) * G + c] |= 1ull << (32 + d);
+    };
+    for (const Scan2Slot& sl : s2.slots) {
+        if (sl.key == kScan2EmptyKey) continue;
+        const uint64_t key = sl.key;
+        add_window(group_of[key / ((uint64_t)kp * kp * kp)], group_of[key / ((uint64_t)kp * kp) % kp], group_of[key / kp % kp], group_of[key % kp]);
     }
+    const uint64_t all_lo = (1ull << G) - 1, all_hi = all_lo << 32;
+    for (const auto& term : ac.terms) {
+        const size_t L = term.size();
+        if (L == 0 || L >= kWin) continue;
+        uint32_t g[3] = {0, 0, 0};
+        for (size_t i = 0; i < L; i++) g[i] = group_of[ac.byte_class[(uint8_t)term[i]]];
+        if (L == 3) {
+            t.filter[((size_t)g[0] * G + g[1]) * G + g[2]] |= all_lo;                                       // (any, t0, t1, t2)
+            for (uint32_t a = 0; a < G; a++) t.filter[((size_t)a * G + g[0]) * G + g[1]] |= 1ull << (32 + g[2]);
+        } else if (L == 2) {
+            for (uint32_t b = 0; b < G; b++) {
+                t.filter[((size_t)b * G + g[0]) * G + g[1]] |= all_lo;                                      // (any, any, t0, t1)
+                for (uint32_t a = 0; a < G; a++) t.filter[((size_t)a * G + b) * G + g[0]] |= 1ull << (32 + g[1]);
+            }
+        } else {
+            for (size_t e = 0; e < t.filter.size(); e++) t.filter[e] |= 1ull << (32 + g[0]);              // (any, any, any, t0)
+            for (uint32_t b = 0; b < G; b++)
+                for (uint32_t c = 0; c < G; c++) t.filter[((size_t)b * G + c) * G + g[0]] |= all_lo;
+        }
+    }
+    (void)all_hi;
 }
 
 }  // namespace gft

@@ -32,7 +32,10 @@ constexpr uint32_t kFilterHashedBits = 1u << 19;    // 64 KB when hashed
 constexpr uint64_t kMaxWindowKeys = 1u << 21;       // budget for the expansion of terms shorter than the window
 
 struct Scan2Tables {
-    bool supported = false;
+    bool supported = false;          // gft_scan2.hip / gft_scan4.hip can run on these tables
+    bool long_ok = false;            // ... the tables of the terms of length >= 4 (slots, more, fpt, classes) are complete: what
+                                     // gft_scan5.hip needs; with short_direct == false its short terms come from Scan3Tables
+    bool short_direct = true;        // short3 (K^3 bytes, exact classes) exists; false: too many byte classes for it
     const char* why_not = "";
     uint32_t kp = 0;                 // K' = n_classes + 1 (the extra class is PAD = "before the document start")
     uint32_t pad_class = 0;

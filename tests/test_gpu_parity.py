@@ -561,7 +561,8 @@ def test_rune_offsets_are_the_anknown_engine_positions(eng):
 def test_mixed_alphabet_workload(eng, scan_kernel):
     """a real word list's shape (benchmarks/benchmark_test.go:72-83): capitals, digits, punctuation, two-byte UTF-8
     letters -- more than 48 byte classes after folding, 2- and 3-byte terms included.  The round-1 kernel refuses such a
-    dictionary; the stride-2 kernel merges byte classes into filter groups and must stay bit-exact."""
+    dictionary; the stride-2 kernel merges byte classes into filter groups, the two-positions-per-probe kernel does the same
+    for its filter and takes the short terms from the stride-2 kernel's group-indexed tables: both must stay bit-exact."""
     from gofindthem_amd import _lib
     from gofindthem_amd.workload import Workload, make_expressions
     w = Workload(3000, alphabet="mixed")
@@ -569,7 +570,7 @@ def test_mixed_alphabet_workload(eng, scan_kernel):
     assert len({b for t in kws for b in t}) >= 48 and min(len(t) for t in kws) <= 3
     o = both(eng, kws)
     L = _lib.load()
-    assert L.gft_scan_kernel(eng._h).decode() == {"scan5": "dfa", "scan4": "dfa", "scan3": "scan3", "scan2": "dfa", "scan2-ordered": "dfa", "dfa": "dfa"}[scan_kernel]
+    assert L.gft_scan_kernel(eng._h).decode() == {"scan5": "scan5", "scan4": "dfa", "scan3": "scan3", "scan2": "dfa", "scan2-ordered": "dfa", "dfa": "dfa"}[scan_kernel]
     text, off = w.docs_host(0, 400)
     assert_csr_equal(eng.scan(text, off, fold=True), o.scan(text, off, fold=True))
     assert_csr_equal(eng.scan(text, off, fold=False), o.scan(text, off, fold=False))

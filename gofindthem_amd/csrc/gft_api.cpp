@@ -14,6 +14,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_set>
 #include <vector>
 
 #include <cstdlib>
@@ -1390,7 +1391,7 @@ static int install_tables(gft_engine* e, uint32_t flags) {
     const bool k3_fits = e->s3.supported && scan3_plan((uint32_t)e->s3.filter.size(), (uint32_t)e->s3.short3.size(), (uint32_t)e->s3.srec.size(),
                                                         bloom_lds_bytes, e->lds_max - 512, &e->scan3_waves, &e->scan3_cand_cap);
     const std::string forced = force ? force : "";
-    e->use_scan3 = k3_fits && forced != "dfa" && forced != "scan2" && forced != "scan4" && forced != "scan5" && (forced == "scan3" || !e->use_scan2);
+    e->use_scan3 = k3_fits && forced != "dfa" && forced != "scan2" && forced != "scan4" && (forced == "scan3" || !e->use_scan2);   // (scan5 asked for but not applicable: the stride-2 kernel, as by default)
     if (e->use_scan3) {
         if ((rc = upload(e, e->d_s3_filter, e->s3.filter, "table upload"))) return rc;
         s3v = e->s3.short3;
@@ -2088,7 +2089,7 @@ int gft_debug_scan5_filter(const uint8_t* terms_blob, const uint64_t* term_off, 
     build_ac_tables(std::move(terms), tab);
     Scan2Tables s2;
     build_scan2_tables(tab, s2);
-    if (!s2.supported || s2.hashed || s2.kp > 32) return GFT_E_UNSUPPORTED;
+    if (!s2.long_ok) return GFT_E_UNSUPPORTED;
     Scan5Tables s5;
     build_scan5_tables(tab, s2, groups && groups < s2.kp ? groups : s2.kp, s5);
     if (groups_used) *groups_used = s5.G;
@@ -2096,12 +2097,30 @@ int gft_debug_scan5_filter(const uint8_t* terms_blob, const uint64_t* term_off, 
     const uint8_t* cls = fold ? s2.cls_fold : s2.cls;
     const uint8_t* grp = fold ? s5.grp_fold : s5.grp;
     const uint32_t kp = s2.kp, G = s5.G;
-    // the exact filter: bit (c[i-3], c[i-2], c[i-1], c[i]) of Scan2Tables::filter, the pad class in front of the document
+    // the exact filter, from first principles (whatever the alphabet): the 4-window of exact classes that ends at i is the
+    // anchor window of a long term (= a key of the bucket table), or a term of length <= 3 ends at i; the pad class stands in
+    // front of the document
     auto cl = [&](int64_t i) { return i < 0 ? s2.pad_class : (uint32_t)cls[text[i]]; };
     auto gr = [&](int64_t i) { return i < 0 ? s5.pad_group : (uint32_t)grp[text[i]]; };
+    std::unordered_set<uint32_t> keys;
+    for (const Scan2Slot& sl : s2.slots) if (sl.key != kScan2EmptyKey) keys.insert(sl.key);
+    std::vector<std::vector<uint32_t>> shorts;
+    for (const auto& term : tab.terms)
+        if (!term.empty() && term.size() < 4) {
+            std::vector<uint32_t> v;
+            for (unsigned char ch : term) v.push_back(tab.byte_class[ch]);
+            shorts.push_back(v);
+        }
     for (uint32_t i = 0; i < len; i++) {
-        const uint64_t key = (((uint64_t)cl((int64_t)i - 3) * kp + cl((int64_t)i - 2)) * kp + cl((int64_t)i - 1)) * kp + cl(i);
-        out_exact[i] = (uint8_t)(s2.filter[key >> 5] >> (key & 31) & 1);
+        const uint32_t key = (uint32_t)((((uint64_t)cl((int64_t)i - 3) * kp + cl((int64_t)i - 2)) * kp + cl((int64_t)i - 1)) * kp + cl(i));
+        bool f = keys.count(key) != 0;
+        for (size_t k = 0; k < shorts.size() && !f; k++) {
+            const auto& v = shorts[k];
+            bool eq = true;
+            for (size_t j = 0; j < v.size() && eq; j++) eq = cl((int64_t)i - (int64_t)(v.size() - 1 - j)) == v[j];
+            f = eq;
+        }
+        out_exact[i] = f ? 1 : 0;
         out_dual[i] = 0;
     }
     // gft_scan5.hip: probes at lane_start, lane_start + 2, ...; the probe at j reads entry (g[j-2], g[j-1], g[j]): bit g[j-3] of

@@ -318,7 +318,8 @@ int gft_debug_emulate_scan(const uint8_t* terms_blob, const uint64_t* term_off, 
  * kernel's lanes do -- a probe at every even offset from `lane_start` answers that position from the low word and the next
  * one from the high word.  out_exact[i] / out_dual[i] = 1 when the one-probe-per-byte filter of gft_scan2.hip / this filter
  * flags a window ending at byte i.  The second must flag whatever the first flags (and is equal to it when no classes are
- * merged); *groups_used = the number of groups.  GFT_E_UNSUPPORTED when the dictionary has no direct suffix-window tables.
+ * merged); *groups_used = the number of groups.  The first is computed from the bucket table's keys and the short terms
+ * themselves, so any alphabet is served.  GFT_E_UNSUPPORTED when the dictionary has no suffix-window tables at all.
  * No HIP device is needed. */
 int gft_debug_scan5_filter(const uint8_t* terms_blob, const uint64_t* term_off, uint32_t n_terms, const uint8_t* text, uint32_t len,
                            uint32_t lane_start, uint32_t scan_flags, uint32_t groups, uint8_t* out_exact, uint8_t* out_dual,

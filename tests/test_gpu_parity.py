@@ -586,6 +586,38 @@ def test_mixed_alphabet_workload(eng, scan_kernel):
     assert L.gft_last_nonascii(eng._h) == 1
 
 
+def test_large_alphabet_on_a_fresh_engine_and_through_import(scan_kernel, monkeypatch):
+    """the two-positions-per-probe kernel on a dictionary over more than 32 byte classes, on engines that never held another
+    dictionary (the launch geometry must not lean on what an earlier build left behind) and on one that IMPORTS the tables
+    (the long-term tables travel; the importer rebuilds what the blob marks as unsupported for the round-1 kernel);
+    GFT_SCAN5_LARGE=0 keeps such a dictionary on the stride-2 kernel"""
+    if scan_kernel != "scan5":
+        pytest.skip("one kernel's business")
+    from gofindthem_amd import _lib
+    from gofindthem_amd.engine import Engine
+    from gofindthem_amd.workload import Workload
+    L = _lib.load()
+    w = Workload(3000, alphabet="mixed")
+    kws = sorted({t.decode("utf-8").lower().encode("utf-8") for t in w.terms()})
+    o = Oracle(kws, POS_START)
+    text, off = w.docs_host(0, 2000)
+    want = o.scan(text, off, fold=True)
+    e1, e2, e3 = Engine(), Engine(), Engine()
+    try:
+        e1.build(kws)
+        assert L.gft_scan_kernel(e1._h).decode() == "scan5"
+        assert_csr_equal(e1.scan(text, off, fold=True), want)
+        e2.import_tables(e1.export_tables())
+        assert L.gft_scan_kernel(e2._h).decode() == "scan5" and e2.terms() == e1.terms()
+        assert_csr_equal(e2.scan(text, off, fold=True), want)
+        monkeypatch.setenv("GFT_SCAN5_LARGE", "0")
+        e3.build(kws)
+        assert L.gft_scan_kernel(e3._h).decode() == "scan3"
+        assert_csr_equal(e3.scan(text, off, fold=True), want)
+    finally:
+        e1.close(), e2.close(), e3.close()
+
+
 def _fold_safe_doc(b: bytes) -> bool:
     """the rule of gft_foldsafe_dev.hpp / k_fold_safe for ONE document: ASCII, C2 80..BF, C3 9F..BF and C3 97 only"""
     i = 0

@@ -87,6 +87,26 @@ def test_benchmark_dictionary_at_the_planned_group_count():
     assert np.array_equal(ex1, ex) and abs(int(du1.sum()) - int(du.sum())) <= 0.02 * du.sum()
 
 
+def test_large_alphabet_mixed_word_list():
+    """more than 32 byte classes (capitals folded away, digits, punctuation, two-byte UTF-8 letters: 54 classes): no direct
+    short-term table, the long-term tables and the 3-gram filter are built all the same -- every flag of the exact filter, and
+    with it every match of the oracle, must survive the merge of 54 classes into 22 groups"""
+    w = Workload(3000, alphabet="mixed")
+    kws = sorted({t.decode("utf-8").lower().encode("utf-8") for t in w.terms()})
+    assert len({b for t in kws for b in t}) > 32
+    text, off = w.docs_host(0, 30)
+    body = bytes(text[:int(off[30])])
+    ends = match_ends(kws, body, fold=True)
+    for start in (0, 1):
+        ex, du, g = flags(kws, body, lane_start=start, groups=22, fold=True)
+        assert g == 22 and not (ex & ~du & 1).any()
+        assert du.sum() <= 1.25 * ex.sum(), (int(ex.sum()), int(du.sum()))
+        for p, length in ends:
+            assert ex[max(p - 4, 0):p + 1].any(), (p, length)
+    ex, du, g = flags(kws, body, fold=True)            # nothing merged: one group per class
+    assert g > 32 and not (ex & ~du & 1).any()
+
+
 def test_input_edges():
     ex, du, _ = flags([b"ab"], b"")
     assert ex.size == 0 and du.size == 0

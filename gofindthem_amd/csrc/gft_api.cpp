@@ -98,7 +98,10 @@ struct gft_engine {
     bool use_scan5 = false;
     Scan5Plan s5plan{0, 0, 0, 0};
     Scan5Tables s5;
-    DevBuf d_s5_grp, d_s5_grp_fold, d_s5_filter;
+    DevBuf d_s5_grp, d_s5_grp_fold, d_s5_filter, d_s5_bloom;
+    std::vector<uint32_t> s5_bloom;                     // the Bloom level in front of a global fingerprint table (gft_kernels.hpp scan5_bloom_g)
+    uint32_t s5_bloom_lg = 0;                           // 2^lg bits; 0: none
+    uint32_t opt_scan5_bloom_kb = 32;                   // GFT_SCAN5_BLOOM_KB: its size in LDS (0: none; a power of two up to 64)
     uint32_t s5_term_bits = 0, s5_pos_bias = 0;
     bool s5_short_groups = false;                       // scan5 takes its short terms from the stride-2 kernel's tables (> 32 byte classes)
     uint32_t opt_scan5_large = 1;                       // GFT_SCAN5_LARGE=0: dictionaries over more than 32 byte classes stay on the stride-2 kernel
@@ -193,6 +196,7 @@ void refresh_options(gft_engine* e) {
     e->opt_scan4_round = (uint32_t)num("GFT_SCAN4_ROUND", 0);
     e->opt_scan5_groups = (uint32_t)num("GFT_SCAN5_GROUPS", 0);
     e->opt_scan5_large = num("GFT_SCAN5_LARGE", 1) ? 1u : 0u;
+    e->opt_scan5_bloom_kb = (uint32_t)std::min<long>(std::max<long>(num("GFT_SCAN5_BLOOM_KB", 32), 0), 64);
     e->opt_scan5_fifo = (uint32_t)std::min<long>(std::max<long>(num("GFT_SCAN5_FIFO", 0), 0), 4096) & ~63u;
     e->opt_solve_dbg = (uint32_t)num("GFT_SOLVE_DEBUG", 0);
     e->opt_solve_group = (int)num("GFT_SOLVE_GROUP_DOCS", -1);
@@ -737,6 +741,7 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
                 P.s5_sG = e->s3.G;
             }
             P.s5_term_bits = e->s5_term_bits; P.s5_pos_bias = e->s5_pos_bias;
+            P.s5_bloom = e->s5_bloom_lg ? e->d_s5_bloom.as<uint32_t>() : nullptr; P.s5_bloom_lg = e->s5_bloom_lg;
             const uint64_t n_waves5 = (uint64_t)e->n_cus * kScan5Waves;
             P.slab = (uint32_t)std::min<uint64_t>(kScan2Slab, std::max<uint64_t>(64, e->pool_cap / (2 * n_waves5)));
             e->last_static_slabs = std::min<uint64_t>(std::max<uint64_t>((n_units + kScan5Waves - 1) / kScan5Waves, 1), e->n_cus) * kScan5Waves * P.slab;
@@ -1279,7 +1284,7 @@ void gft_engine_destroy(gft_engine* e) {
                          &e->d_s2_term_off, &e->d_ctl, &e->d_dbg, &e->d_s2_short3, &e->d_s2_shorts_packed, &e->d_s2_short3_big, &e->d_s2_fpt,
                          &e->d_s3_filter, &e->d_s3_short3, &e->d_s3_srec, &e->d_s3_short3_big, &e->d_s3_srec_big, &e->d_s3_bloom, &e->d_s3_slots,
                          &e->d_s3_more, &e->d_s3_cls, &e->d_s3_cls_fold, &e->d_s3_term_blob, &e->d_s3_term_off,
-                         &e->d_s5_grp, &e->d_s5_grp_fold, &e->d_s5_filter,
+                         &e->d_s5_grp, &e->d_s5_grp_fold, &e->d_s5_filter, &e->d_s5_bloom,
 &e->d_unit_cnt, &e->d_unit_base, &e->d_units, &e->d_partial,
                          &e->d_pool_term, &e->d_pool_pos, &e->d_unit_start, &e->d_unit_count, &e->d_unit_out,
                          &e->d_term, &e->d_pos, &e->d_match_off, &e->d_text, &e->d_doc_off, &e->d_bitmap, &e->d_xoff,
@@ -1371,13 +1376,42 @@ static int install_tables(gft_engine* e, uint32_t flags) {
         const bool packs = (uint64_t)kScan2UnitMax + e->s5_pos_bias + 8 < (1ull << (32 - tb));
         const uint32_t short_bytes = large5 ? (uint32_t)e->s3.short3.size() : (uint32_t)e->s2.short3.size();
         const uint32_t rec_words = large5 ? (uint32_t)e->s3.srec.size() : (uint32_t)std::min<size_t>(e->s2.shorts_packed.size(), 255 * 3);
-        if (packs && scan5_plan(e->s2.kp, short_bytes, rec_words, e->s2.fpt_lg ? 0u : kScan2FptSize, e->lds_max - 512,
-                                e->opt_scan5_fifo ? e->opt_scan5_fifo : kScan2FifoCap, &e->s5plan)) {
+        // a fingerprint table too large for LDS (fpt_lg != 0) gets a Bloom level there instead: 2^lg bits, as large as
+        // GFT_SCAN5_BLOOM_KB allows but not more than eight bits per item would take
+        e->s5_bloom_lg = 0;
+        e->s5_bloom.clear();
+        if (e->s2.fpt_lg && e->opt_scan5_bloom_kb) {
+            uint32_t lg = 13;
+            while ((2u << lg) / 8 <= e->opt_scan5_bloom_kb * 1024u && (1ull << lg) < 8 * e->s2.n_keys) lg++;
+            e->s5_bloom_lg = lg;
+        }
+        bool fits5 = false;
+        for (int attempt = 0; attempt < 2 && packs && !fits5; attempt++) {
+            const uint32_t in_lds = e->s2.fpt_lg ? (e->s5_bloom_lg ? (1u << e->s5_bloom_lg) / 8 : 0u) : kScan2FptSize;
+            fits5 = scan5_plan(e->s2.kp, short_bytes, rec_words, in_lds, e->lds_max - 512, e->opt_scan5_fifo ? e->opt_scan5_fifo : kScan2FifoCap, &e->s5plan);
+            if (!fits5) e->s5_bloom_lg = 0;                      // (no room: without the Bloom level)
+        }
+        if (fits5) {
             if (e->opt_scan5_groups && e->opt_scan5_groups < e->s5plan.G) {      // (tests: more merging than LDS asks for)
                 e->s5plan.G = std::max<uint32_t>(e->opt_scan5_groups, 2);
                 e->s5plan.dual_entries = e->s5plan.G * e->s5plan.G * e->s5plan.G;
             }
             build_scan5_tables(e->tab, e->s2, e->s5plan.G, e->s5);
+            if (e->s5_bloom_lg) {
+                // one bit per owner of a fingerprint cell, read off the bucket table: (window key, byte in front of the
+                // window with its case bit cleared), or the window key alone where the window is the term's first four bytes
+                e->s5_bloom.assign((size_t)1 << (e->s5_bloom_lg - 5), 0u);
+                auto set = [&](uint32_t h) { e->s5_bloom[h >> 5] |= 1u << (h & 31); };
+                auto add = [&](const Scan2Slot& t) {
+                    if ((t.len & kScan2LenMask) == 4) set(scan5_bloom_x(t.key, e->s5_bloom_lg));
+                    else set(scan5_bloom_g(t.key, (t.front[0] >> 24) & 0xDFu, e->s5_bloom_lg));
+                };
+                for (const Scan2Slot& sl : e->s2.slots) {
+                    if (sl.key == kScan2EmptyKey) continue;
+                    if (!(sl.info & kScan2Multi)) { add(sl); continue; }
+                    for (uint32_t j = 0; j < sl.len; j++) add(e->s2.more[(sl.info & ~kScan2Multi) + j]);
+                }
+            }
             e->use_scan5 = true;
             e->s5_short_groups = large5;
             e->use_scan2 = true;           // (the scan2 family's path through scan_pipeline; gft_scan2.hip itself runs only when s2.supported)
@@ -1458,9 +1492,14 @@ static int install_tables(gft_engine* e, uint32_t flags) {
         if ((rc = upload(e, e->d_s5_grp, s5g, "table upload"))) return rc;
         if ((rc = upload(e, e->d_s5_grp_fold, s5gf, "table upload"))) return rc;
         if ((rc = upload(e, e->d_s5_filter, e->s5.filter, "table upload"))) return rc;
-        if (getenv("GFT_SCAN_DEBUG"))
-            fprintf(stderr, "[gft build debug] scan5: G=%u of %u classes, filter %zu entries, list %u, term bits %u\n",
-                    e->s5.G, e->s2.kp, e->s5.filter.size(), e->s5plan.cand_cap, e->s5_term_bits);
+        if (e->s5_bloom_lg && (rc = upload(e, e->d_s5_bloom, e->s5_bloom, "table upload"))) return rc;
+        if (getenv("GFT_SCAN_DEBUG")) {
+            size_t set_bits = 0;
+            for (uint32_t w : e->s5_bloom) set_bits += (size_t)__builtin_popcount(w);
+            fprintf(stderr, "[gft build debug] scan5: G=%u of %u classes, filter %zu entries, list %u, term bits %u; Bloom level 2^%u bits, %.1f %% set\n",
+                    e->s5.G, e->s2.kp, e->s5.filter.size(), e->s5plan.cand_cap, e->s5_term_bits, e->s5_bloom_lg,
+                    e->s5_bloom_lg ? 100.0 * (double)set_bits / (double)(1ull << e->s5_bloom_lg) : 0.0);
+        }
     }
     HIP_TRY(hipStreamSynchronize(e->stream), "table upload");
     e->built = true;

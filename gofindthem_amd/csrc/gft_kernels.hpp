@@ -283,7 +283,17 @@ struct Scan2Params {
     uint32_t s5_sG;              // their number of groups (0: the direct table of exact classes)
     const uint32_t* s5_srec_big; // records of the cells with id 255 ({n, n x 2 words})
     uint32_t s5_term_bits, s5_pos_bias;   // with positions a fifo entry is term | (pos - (unit.lo - pos_bias)) << term_bits
+    // ... with the fingerprint table in global memory (fpt_lg != 0): a Bloom level of 2^s5_bloom_lg bits in LDS in front of it
+    const uint32_t* s5_bloom;    // bit scan5_bloom_g(key, b1) / scan5_bloom_x(key) set for every cell owner of the fingerprint table
+    uint32_t s5_bloom_lg;        // 0: none
 };
+// Bloom level of gft_scan5.hip's stage A for large dictionaries (one bit per (window, byte in front) that some term of
+// length >= 4 has, one per window that is a term's first four bytes): a position whose two bits are both clear cannot anchor
+// a long term and spares the three L2 gathers of the global fingerprint table
+GFT_HD inline uint32_t scan5_bloom_g(uint32_t x, uint32_t b1n, uint32_t lg) {
+    return (scan2_mul24c<0xC2B2AFu>(x ^ (x >> 20)) + scan2_mul24c<0x27D4EBu>(b1n + 1)) >> (32 - lg);
+}
+GFT_HD inline uint32_t scan5_bloom_x(uint32_t x, uint32_t lg) { return scan2_mul24c<0x3779B1u>(x ^ (x >> 20)) >> (32 - lg); }
 // waves per workgroup (16, 12, 8 or 4) and candidate-list capacity that fit lds_max; false if nothing fits
 bool scan2_plan(uint32_t filter_words, uint32_t short3_bytes, uint32_t shorts_words, uint32_t fpt_lds_bytes, size_t lds_max,
                 uint32_t* waves, uint32_t* cand_cap);

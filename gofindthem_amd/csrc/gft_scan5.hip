@@ -248,7 +248,10 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
     uint64_t* dual = reinterpret_cast<uint64_t*>(smem + 768);     // [G^3] the filter
     uint8_t* short3 = reinterpret_cast<uint8_t*>(dual + P.s5_dual);
     uint8_t* fpt = short3 + P.short3_bytes;                       // (short3_bytes is a multiple of 16)
-    uint32_t* lrec = reinterpret_cast<uint32_t*>(fpt + (FPT_LDS ? kScan2FptSize : 0));
+    // (the fingerprint table in global memory: its place holds the Bloom level in front of it, if there is one)
+    const uint32_t bloom_lg = FPT_LDS ? 0u : __builtin_amdgcn_readfirstlane(P.s5_bloom_lg);
+    const uint32_t bloom_bytes = bloom_lg ? (1u << bloom_lg) / 8 : 0u;
+    uint32_t* lrec = reinterpret_cast<uint32_t*>(fpt + (FPT_LDS ? kScan2FptSize : bloom_bytes));
     uint32_t* wg_next = reinterpret_cast<uint32_t*>(smem + (((size_t)(reinterpret_cast<uint8_t*>(lrec) - smem) + P.shorts_words * 4 + 15) & ~(size_t)15));
     uint8_t* wave_lds_all = reinterpret_cast<uint8_t*>(wg_next) + 16;
 
@@ -258,6 +261,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
         reinterpret_cast<uint32_t*>(short3)[i] = reinterpret_cast<const uint32_t*>(P.short3)[i];
     for (uint32_t i = threadIdx.x; FPT_LDS && i < kScan2FptSize / 4; i += blockDim.x)
         reinterpret_cast<uint32_t*>(fpt)[i] = reinterpret_cast<const uint32_t*>(P.fpt)[i];
+    for (uint32_t i = threadIdx.x; !FPT_LDS && i < bloom_bytes / 4; i += blockDim.x) reinterpret_cast<uint32_t*>(fpt)[i] = P.s5_bloom[i];
     for (uint32_t i = threadIdx.x; i < P.shorts_words; i += blockDim.x) lrec[i] = P.shorts_packed[i];
     if (threadIdx.x == 0) { wg_next[0] = kScan5Waves; wg_next[1] = wg_next[2] = wg_next[3] = 0; }
     __syncthreads();
@@ -499,7 +503,18 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
                         }
                     }
 #pragma unroll
-                    for (int q = 0; q < kWays5; q++) cand_decide<FPT_LDS>(c, k[q]);
+                    for (int q = 0; q < kWays5; q++) {
+                        if (FPT_LDS || !bloom_lg) cand_decide<FPT_LDS>(c, k[q]);
+                        else {
+                            // large dictionary: the three cells of the fingerprint table are L2 gathers -- only for the positions
+                            // whose (window, byte in front) or window alone is some term's, by the Bloom level in LDS
+                            const uint32_t* bl = reinterpret_cast<const uint32_t*>(fpt);
+                            const uint32_t hg = scan5_bloom_g(k[q].x, (k[q].tw >> 24) & 0xDFu, bloom_lg), hx = scan5_bloom_x(k[q].x, bloom_lg);
+                            const uint32_t wg = bl[hg >> 5], wx = bl[hx >> 5];
+                            k[q].go_long = false;
+                            if (((wg >> (hg & 31)) | (wx >> (hx & 31))) & 1u) cand_decide<false>(c, k[q]);
+                        }
+                    }
 #pragma unroll
                     for (int q = 0; q < kWays5; q++)
                         if (i0 + 64 * q < ptotal)                  // (positions in front of the unit: long terms only)
@@ -660,7 +675,7 @@ bool scan5_plan(uint32_t kp, uint32_t short3_bytes, uint32_t shorts_words, uint3
 hipError_t launch_scan5(const Scan2Params& P, unsigned n_cus, hipStream_t st) {
     if (!P.n_units) return hipSuccess;
     const bool fl = P.fpt_lg == 0;
-    const size_t lds = scan5_fixed_lds(P.s5_dual, P.short3_bytes, P.shorts_words, fl ? kScan2FptSize : 0) +
+    const size_t lds = scan5_fixed_lds(P.s5_dual, P.short3_bytes, P.shorts_words, fl ? kScan2FptSize : P.s5_bloom_lg ? (1u << P.s5_bloom_lg) / 8 : 0) +
                        (size_t)kScan5Waves * scan5_wave_lds(P.s5_fifo_cap, P.cand_cap);
     using Kern = void (*)(const Scan2Params);
     // (the timing-study instantiations exist for the direct short-term table only)

@@ -727,6 +727,8 @@ hipError_t launch_g(const SolveParams& S, bool p_in_lds, bool prog_in_lds, unsig
     Kern run = fn;
     // timing studies: the benchmark's shape only (presence matrix and programs in LDS, 64 documents per group)
     if (S.dbg && G == 64 && p_in_lds && prog_in_lds) run = io ? k_solve_groups<true, true, 64, true, true> : k_solve_groups<true, true, 64, false, true>;
+    // ... and the shape of a 100 000-term dictionary (8 documents per group, programs in L2)
+    if (S.dbg && G == 8 && p_in_lds && !prog_in_lds) run = io ? k_solve_groups<true, false, 8, true, true> : k_solve_groups<true, false, 8, false, true>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(run), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     run<<<dim3(grid), dim3(kSolveBlockThreads), lds, st>>>(S);

@@ -618,6 +618,41 @@ def test_large_alphabet_on_a_fresh_engine_and_through_import(scan_kernel, monkey
         e1.close(), e2.close(), e3.close()
 
 
+def test_bloom_level_in_front_of_a_global_fingerprint_table(scan_kernel, monkeypatch):
+    """a dictionary whose fingerprint table does not fit LDS (here forced: GFT_SCAN_FPT_GLOBAL) gets a Bloom level in LDS in
+    front of it (gft_kernels.hpp scan5_bloom_g / _x): positions whose bits are clear skip the table's three L2 gathers.
+    Terms whose anchor window is their first four bytes are keyed by the window alone, all others by (window, byte in
+    front); a tiny Bloom (GFT_SCAN5_BLOOM_KB=1: 8 192 bits, nearly full at 3 000 terms) and none at all must give the same
+    matches as the oracle, folded and exact"""
+    if scan_kernel != "scan5":
+        pytest.skip("one kernel's business")
+    from gofindthem_amd.engine import Engine
+    from gofindthem_amd.workload import Workload
+    monkeypatch.setenv("GFT_SCAN_FPT_GLOBAL", "1")
+    w = Workload(3000)
+    terms = w.terms()
+    text, off = w.docs_host(0, 600)
+    o = Oracle(terms, POS_START)
+    want_f, want_x = o.scan(text, off, fold=True), o.scan(text, off, fold=False)
+    rng = np.random.default_rng(5)
+    alpha = b"abcdefgh"
+    rterms = sorted({bytes(alpha[i] for i in rng.integers(0, len(alpha), int(rng.integers(1, 9)))) for _ in range(800)})
+    rtexts = [bytes(alpha[i] for i in rng.integers(0, len(alpha), n)) for n in (0, 3, 4, 5, 64, 1000, 9000, 30000)]
+    rblob, roff = docs(rtexts)
+    ro = Oracle(rterms, POS_END)
+    for kb in ("1", "32", "0"):
+        monkeypatch.setenv("GFT_SCAN5_BLOOM_KB", kb)
+        e = Engine()
+        try:
+            e.build(terms)
+            assert_csr_equal(e.scan(text, off, fold=True), want_f)
+            assert_csr_equal(e.scan(text, off, fold=False), want_x)
+            e.build(rterms, pos_end=True)
+            assert_csr_equal(e.scan(rblob, roff), ro.scan(rblob, roff))
+        finally:
+            e.close()
+
+
 def _fold_safe_doc(b: bytes) -> bool:
     """the rule of gft_foldsafe_dev.hpp / k_fold_safe for ONE document: ASCII, C2 80..BF, C3 9F..BF and C3 97 only"""
     i = 0

@@ -427,6 +427,112 @@ __device__ __forceinline__ AT run_program(const SolveParams& S, const PT* P, con
     return acc;
 }
 
+// The same interpreter for programs that are read from global memory (a 100 000-term dictionary's do not fit LDS): FOUR
+// chunks are requested in front of the one being interpreted, each in a register set of its own that is loaded again as soon
+// as its words are copied out.  run_program's rotation (nx = nx2) copies a set that a load is still filling and so waits for
+// that load: its distance is one trip, which does not cover an L2 round trip -- the longest program of a group was a chain of
+// exposed round trips.  (configs[4]: solve 3.03 -> 2.89 ms with 50 % INORD expressions, 2.82 -> 2.60 without.  What remains
+// is instruction issue: ~34 vector instructions per program word at 8 documents per group; leaving a block of INORD
+// conjunctions as soon as no document is left in any accumulator removes 45 % of that work and not a microsecond -- the
+// group waits for its longest program, 59 trips that one wave issues alone.)
+template <bool P_LDS, uint32_t R, bool RARE, class PT, class AT>
+__device__ __forceinline__ AT run_program_far(const SolveParams& S, const PT* P, const uint4* prog, uint32_t stride, uint32_t chunks,
+                                              AT valid, uint64_t d0) {
+    static_assert(R == 0 || R == kSolveRegStack || R == kSolveRegStackDeep, "three interpreters");
+    constexpr bool DEEP = R > kSolveRegStack;
+    // HBM-resident P was written with L2 atomics by other waves: read it past this CU's L1
+    // (LDS: the field of a word is the slot's byte offset in a P of 8-byte elements, one v_and away)
+    auto ld = [&](uint32_t w) -> AT {
+        constexpr uint32_t kDown = sizeof(PT) == 8 ? 0 : sizeof(PT) == 4 ? 1 : sizeof(PT) == 2 ? 2 : 3;
+        const uint32_t byte = (w & kDwFieldMask) >> kDown;
+        // (P sits at LDS address 0 -- checked in the kernel --, so the byte offset IS the address: no add of the base)
+        if (P_LDS) return (AT)*reinterpret_cast<const __attribute__((address_space(3))) PT*>((size_t)byte);
+        return (AT)__hip_atomic_load(&P[byte / sizeof(PT)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    AT acc = AT(0), s0 = AT(0), s1 = AT(0), s2 = AT(0), s3 = AT(0), deep[DEEP ? kMaxBoolDepth : 1];
+    uint32_t sp = 0;                                            // DEEP: entries on the stack (registers + scratch)
+    const uint4 nops = make_uint4(kDwNop, kDwNop, kDwNop, kDwNop);
+    uint4 q0 = chunks > 0 ? prog[0] : nops, q1 = chunks > 1 ? prog[stride] : nops;
+    uint4 q2 = chunks > 2 ? prog[2 * (size_t)stride] : nops, q3 = chunks > 3 ? prog[3 * (size_t)stride] : nops;
+    const uint32_t wchunks = wave_max_u32(chunks);
+    auto trip = [&](uint4& q, const uint32_t c) __attribute__((always_inline)) {
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+        q = nops;
+        if (c + 4 < chunks) q = prog[(size_t)(c + 4) * stride];
+        AT pv[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            pv[q] = ld(RARE && (int32_t)w[q] < 0 ? 0u : w[q]);            // (a rare word's field is a group, not a slot)
+        }
+        // wave-uniform: a NOT / INORD word in this chunk, or a lane whose stack leaves the registers in it
+        bool careful = RARE && __any((int32_t)(w[0] | w[1] | w[2] | w[3]) < 0);
+        if (DEEP) {
+            uint32_t high = sp;                                  // an upper bound of the depth inside this chunk
+#pragma unroll
+            for (int q = 0; q < 4; q++) high += (w[q] >> bit_index(kDwPush)) & 1u;
+            careful |= __any(high > R);
+        }
+        auto step = [&](const uint32_t wq, const AT pvq, const bool care) __attribute__((always_inline)) {
+            const AT neg = bit_mask<AT, bit_index(kDwNeg)>(wq), sel = bit_mask<AT, bit_index(kDwSel)>(wq);
+            const AT ones = bit_mask<AT, bit_index(kDwOnes)>(wq), orr = bit_mask<AT, bit_index(kDwOr)>(wq);
+            const AT pop = bit_mask<AT, bit_index(kDwPop)>(wq), push = bit_mask<AT, bit_index(kDwPush)>(wq);
+            const AT v = pvq ^ neg;                             // (bits past the group are never stored)
+            const AT x = R ? pick(pop, s0, v) : v;
+            const AT before = acc;
+            acc = (acc & pick(sel, x, ones)) | (x & orr);
+            if (R == 0) {
+                // flat programs: no push, no pop
+            } else if (!DEEP) {
+                const AT n0 = pick(push, before, pick(pop, s1, s0));
+                s1 = pick(push, s0, s1);
+                s0 = n0;
+            } else {
+                if (care && push && sp >= R) deep[sp - R] = s3;
+                const AT n0 = pick(push, before, pick(pop, s1, s0)), n1 = pick(push, s0, pick(pop, s2, s1));
+                const AT n2 = pick(push, s1, pick(pop, s3, s2)), n3 = pick(push, s2, s3);
+                s0 = n0; s1 = n1; s2 = n2; s3 = n3;
+                sp = sp - bit_mask<uint32_t, bit_index(kDwPush)>(wq) + bit_mask<uint32_t, bit_index(kDwPop)>(wq);   // 0 or ~0 == -1
+                if (care && pop && sp >= R) {
+                    s3 = deep[sp - R];
+                    // (waited for here: a scratch load left pending would have the compiler wait for ALL vector loads, the
+                    // prefetch of the next group included, wherever the fast path touches the same register)
+                    __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0)
+                }
+            }
+            if (RARE && care) {
+                const bool rare = (int32_t)wq < 0, is_not = rare && (wq & kDwNeg), is_inord = rare && !(wq & kDwNeg);
+                if (is_not) acc = ~acc;
+                // candidates: documents where the group's boolean value is true (rval, expression.go:137)
+                const AT in = AT(inord_wave(S, is_inord, (wq & kDwFieldMask) >> kDwFieldShift, (uint64_t)(acc & valid), d0));
+                if (is_inord) acc = in;
+            }
+        };
+        if (!careful) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) step(w[q], pv[q], false);
+        } else {
+            // one copy of the slow code: the chunk's words one after the other in a rolled loop.  The words rotate through
+            // fixed registers -- indexing w[] / pv[] with the loop counter would move both arrays to scratch memory, for
+            // the fast path above as well
+            uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+            AT p0 = pv[0], p1 = pv[1], p2 = pv[2], p3 = pv[3];
+#pragma nounroll
+            for (int q = 0; q < 4; q++) {
+                step(w0, p0, true);
+                w0 = w1; w1 = w2; w2 = w3;
+                p0 = p1; p1 = p2; p2 = p3;
+            }
+        }
+    };
+    for (uint32_t c = 0; c < wchunks; c += 4) {
+        trip(q0, c);
+        if (c + 1 < wchunks) trip(q1, c + 1);
+        if (c + 2 < wchunks) trip(q2, c + 2);
+        if (c + 3 < wchunks) trip(q3, c + 3);
+    }
+    return acc;
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() is a barrier plus a fence over ALL memory: the compiler
 // puts s_waitcnt vmcnt(0) in front of it, i.e. every barrier would wait for the prefetch loads in flight and a group would
 // pay their whole latency (measured: 4 400 of 24 000 cycles per group).  The loads' registers are tracked by the
@@ -644,9 +750,15 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
                     const uint32_t stride = PROG_LDS ? 1u : 64u;
                     const uint32_t cls = uniform_word(S.blk_class, (e0 >> 6) + b);
                     const uint32_t chunks = has ? len / 4 : 0;
-                    const AT r = cls == 0   ? run_program<P_LDS, 0, RARE, PT, AT>(S, P, prog, stride, chunks, AT(valid), d0)
-                                 : cls == 1 ? run_program<P_LDS, kSolveRegStack, RARE, PT, AT>(S, P, prog, stride, chunks, AT(valid), d0)
-                                            : run_program<P_LDS, kSolveRegStackDeep, RARE, PT, AT>(S, P, prog, stride, chunks, AT(valid), d0);
+                    AT r;
+                    if constexpr (PROG_LDS)
+                        r = cls == 0   ? run_program<P_LDS, 0, RARE, PT, AT>(S, P, prog, stride, chunks, AT(valid), d0)
+                            : cls == 1 ? run_program<P_LDS, kSolveRegStack, RARE, PT, AT>(S, P, prog, stride, chunks, AT(valid), d0)
+                                       : run_program<P_LDS, kSolveRegStackDeep, RARE, PT, AT>(S, P, prog, stride, chunks, AT(valid), d0);
+                    else
+                        r = cls == 0   ? run_program_far<P_LDS, 0, RARE, PT, AT>(S, P, prog, stride, chunks, AT(valid), d0)
+                            : cls == 1 ? run_program_far<P_LDS, kSolveRegStack, RARE, PT, AT>(S, P, prog, stride, chunks, AT(valid), d0)
+                                       : run_program_far<P_LDS, kSolveRegStackDeep, RARE, PT, AT>(S, P, prog, stride, chunks, AT(valid), d0);
                     if (has) R[e - e0] = (uint64_t)r;
                 }
             }

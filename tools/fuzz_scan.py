@@ -30,7 +30,7 @@ def run(iters, seed, budget_s, eng=None, progress=False):
     own = eng is None
     if own:
         eng = Engine()
-    saved = {k: os.environ.get(k) for k in ("GFT_SCAN_ORDERED", "GFT_SCAN_KERNEL", "GFT_SOLVE_GROUP_DOCS")}
+    saved = {k: os.environ.get(k) for k in ("GFT_SCAN_ORDERED", "GFT_SCAN_KERNEL", "GFT_SOLVE_GROUP_DOCS", "GFT_SCAN_FPT_GLOBAL", "GFT_SCAN5_BLOOM_KB")}
     t_start = time.time()
     done = 0
     try:
@@ -152,6 +152,14 @@ def one(eng, seed, it):
     os.environ["GFT_SCAN_KERNEL"] = {"dfa": "dfa", "scan3": "scan3", "scan2": "scan2", "ordered": "scan2", "scan4": "scan4", "scan5": "scan5"}.get(variant, "auto")
     if variant == "ordered":
         os.environ["GFT_SCAN_ORDERED"] = "1"
+    # a third of the builds: the fingerprint table in global memory as for a 100 000-term dictionary, behind Bloom levels of
+    # 8 192 bits (crowded) or the default size
+    os.environ.pop("GFT_SCAN_FPT_GLOBAL", None)
+    os.environ.pop("GFT_SCAN5_BLOOM_KB", None)
+    if rng.integers(3) == 0:
+        os.environ["GFT_SCAN_FPT_GLOBAL"] = "1"
+        if rng.integers(2):
+            os.environ["GFT_SCAN5_BLOOM_KB"] = "1"
     tl = sorted(terms)
     eng.build(tl, pos_end=(pos_mode == POS_END))
     o = Oracle(tl, pos_mode)

@@ -2130,7 +2130,8 @@ int gft_debug_scan5_filter(const uint8_t* terms_blob, const uint64_t* term_off, 
     build_scan2_tables(tab, s2);
     if (!s2.long_ok) return GFT_E_UNSUPPORTED;
     Scan5Tables s5;
-    build_scan5_tables(tab, s2, groups && groups < s2.kp ? groups : s2.kp, s5);
+    // (a filter word has one bit per group: 32 at most, whatever the caller asks for; the kernel's plan stops at kScan5MaxGroups)
+    build_scan5_tables(tab, s2, std::min<uint32_t>(groups && groups < s2.kp ? groups : s2.kp, 32u), s5);
     if (groups_used) *groups_used = s5.G;
     const bool fold = (scan_flags & GFT_FOLD_ASCII) != 0;
     const uint8_t* cls = fold ? s2.cls_fold : s2.cls;

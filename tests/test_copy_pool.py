@@ -20,10 +20,11 @@ def test_copy_pool_under_tsan(tmp_path):
     if tsan.returncode != 0:
         subprocess.check_call(base)
     env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1 exitcode=66")
+    env.pop("LD_PRELOAD", None)             # (tools/asan_host.sh preloads the ASan runtime: not into a TSan binary)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
     if tsan.returncode == 0 and r.returncode != 0 and "unexpected memory mapping" in r.stderr:
         # (ThreadSanitizer cannot map its shadow under this kernel's address-space layout: run the plain build instead)
         subprocess.check_call(base)
-        r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "copy pool ok" in r.stdout

@@ -103,8 +103,8 @@ def test_large_alphabet_mixed_word_list():
         assert du.sum() <= 1.25 * ex.sum(), (int(ex.sum()), int(du.sum()))
         for p, length in ends:
             assert ex[max(p - 4, 0):p + 1].any(), (p, length)
-    ex, du, g = flags(kws, body, fold=True)            # nothing merged: one group per class
-    assert g > 32 and not (ex & ~du & 1).any()
+    ex, du, g = flags(kws, body, fold=True)            # as little merging as a filter word's 32 bits allow
+    assert g == 32 and not (ex & ~du & 1).any()
 
 
 def test_input_edges():

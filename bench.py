@@ -161,6 +161,18 @@ def main():
     scan_ms, scan_n = prof("scan")
     solve_ms, solve_n = prof("solve")
     aux_ms, aux_n = prof("aux")
+    # the spread of the dominant kernel from launch to launch: the same step again, every launch read on its own (behind the
+    # timed region -- reading the events synchronises)
+    scan_each = []
+    L.gft_profile_enable(eh, 1)
+    for _ in range(min(args.steps, 20)):
+        L.gft_profile_reset(eh)
+        step()
+        fence()
+        ms1, n1 = prof("scan")
+        if n1:
+            scan_each.append(ms1 / n1)
+    L.gft_profile_enable(eh, 0)
 
     # ---- same-run consistency that needs no oracle: the corpus generator's host and device forms agree on a sample,
     # and (N > 1) rank 0's slice of the gathered result is what it computed itself --------------------------------
@@ -213,6 +225,24 @@ def main():
                          % (n_cpu, float(c_off[-1]) / 1e6, cores, tc, same)}
 
     if rank == 0:
+        import shutil
+        # the unmodified reference is timed beside the path only where a Go toolchain and a module cache exist
+        go_ref = ("Go reference not runnable (no `go` binary on this box, and the module github.com/pedroegsilva/ahocorasick is not "
+                  "vendored); CPU baseline = C++ restatement (oracle/ac_oracle.cpp)") if shutil.which("go") is None else \
+                 "a `go` binary exists here, but /root/reference does not travel to the GPU box: CPU baseline = C++ restatement (oracle/ac_oracle.cpp)"
+        # which BASELINE.json configuration the arguments describe
+        if args.alphabet != "lower":
+            cfg_name = "BASELINE.json configs[2] shape on the MIXED alphabet (not a BASELINE configuration)"
+        elif args.terms == 10_000 and args.exprs == 1_000 and args.inord == 0:
+            cfg_name = "BASELINE.json configs[2]" if world == 1 else "BASELINE.json configs[2] sharded over %d GPUs" % world
+        elif args.terms == 10_000 and args.exprs == 1_000:
+            cfg_name = "BASELINE.json configs[3]" + (" (one GPU's part of it)" if world == 1 else "")
+        elif args.terms == 100_000:
+            cfg_name = "BASELINE.json configs[4], device half (no regex leaves)"
+        elif args.terms == 1_000:
+            cfg_name = "BASELINE.json configs[1] dictionary through the ProcessText path"
+        else:
+            cfg_name = "custom (not a BASELINE configuration)"
         scan_kernel = (L.gft_scan_kernel(eh) or b"").decode()
         kernel_names = {"scan5": "k_scan5 (suffix-window scan, one probe per two bytes)", "scan2": "k_scan2 (suffix-window scan)", "scan4": "k_scan4 (streaming suffix-window scan)", "scan3": "k_scan3 (stride-2 suffix-window scan)", "dfa": "k_scan_units (two-tier DFA)"}
         docs_total = total_docs * args.steps
@@ -228,7 +258,7 @@ def main():
         # HBM traffic of the scan kernel from rocprofv3 PMC passes (profiles/r3_pmc_traffic.json; it cannot be
         # collected from inside this process) -- only attached when this run uses the profiled configuration
         traffic = None
-        for name in ("r3_pmc_traffic.json", "r3_scan4_pmc_traffic.json", "r2_pmc_traffic.json"):   # (the newest set that has this kernel)
+        for name in ("r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json"):   # (the newest set that has this kernel)
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as fh:
                     pmc = json.load(fh)
@@ -247,9 +277,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[2]: %d terms + %d %s expressions, %d docs x ~4 KB on this GPU "
+            "config": {"workload": "%s: %d terms + %d %s expressions, %d docs x ~4 KB on this GPU "
                                    "(SURVEY.md 8(d) generator%s), case-insensitive finder, inputs resident in HBM"
-                                   % (args.terms, args.exprs, "AND/OR/NOT" if args.inord == 0 else
+                                   % (cfg_name, args.terms, args.exprs, "AND/OR/NOT" if args.inord == 0 else
                                       "AND/OR/NOT + %.0f%% INORD" % (args.inord * 100), args.docs,
                                       "" if args.alphabet == "lower" else ", MIXED alphabet: capitals, digits, punctuation, UTF-8 letters"),
                        "alphabet": args.alphabet, "keywords": n_keywords,
@@ -259,10 +289,16 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kernel_names.get(scan_kernel, scan_kernel), "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,
                          "measured_read_ceiling": ceiling_gbps, "frac_of_measured_ceiling": achieved / ceiling_gbps,
-                         "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": scan_avg_ms, "launches": scan_n},
+                         "guide_achievable_read": 6300.0, "frac_of_guide_achievable": achieved / 6300.0,
+                         "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": scan_avg_ms, "launches": scan_n,
+                         "scan_ms_min": float(np.min(scan_each)) if scan_each else None,
+                         "scan_ms_median": float(np.median(scan_each)) if scan_each else None,
+                         "scan_ms_stddev": float(np.std(scan_each)) if scan_each else None,
+                         "scan_ms_spread_launches": len(scan_each)},
             "kernels_ms_per_step": {"scan": scan_ms / args.steps, "solve": solve_ms / args.steps,
                                     "aux(units+prefix sums+gather)": aux_ms / args.steps},
             "cpu_baseline": cpu,
+            "go_reference": go_ref,
             "parity": parity if parity_ok else "PARITY FAILED",
             "setup_s": setup_s,
         }

@@ -33,6 +33,7 @@ SYMBOLS = {
     "gft_engine_create_multi": (_i, [C.POINTER(_vp), _vp, _i]),
     "gft_n_devices": (_i, [_vp]),
     "gft_gather_mode": (C.c_char_p, [_vp]),
+    "gft_build_info": (C.c_char_p, []),
     "gft_device_engine": (_vp, [_vp, _i]),
     "gft_split_docs": (_i, [_vp, _vp, _u64, _vp]),
     "gft_process_device_multi": (_i, [_vp, _vp, _vp, _vp, _u32, _vp]),
@@ -106,13 +107,46 @@ FIND_FN = C.CFUNCTYPE(_i, _vp, _vp, _u64, EMIT_FN, _vp, _vp, _u32)
 _LIB = None
 
 
+def _mapped_hip_runtimes():
+    """paths of the libamdhip64 copies mapped into this process"""
+    try:
+        with open("/proc/self/maps") as f:
+            return sorted({ln.split()[-1] for ln in f if "libamdhip64.so" in ln})
+    except OSError:
+        return []
+
+
+def _hip_runtime_first():
+    """libgft.so links /opt/rocm's libamdhip64, PyTorch ships its own copy of the same soname.  Whichever is mapped first
+    serves both -- as long as torch comes FIRST: with libgft.so loaded before torch the process has carried two HIP runtimes
+    (the one abort in the records).  So a process that can import torch imports it before the library
+    is mapped; one without torch has a single runtime anyway.  GFT_NO_TORCH_PRELOAD=1 skips this (a caller that never
+    imports torch and does not want its start-up time)."""
+    import sys
+    if "torch" in sys.modules or os.environ.get("GFT_NO_TORCH_PRELOAD"):
+        return
+    import importlib.util
+    if importlib.util.find_spec("torch") is not None:
+        import torch  # noqa: F401
+
+
+def _check_one_hip_runtime():
+    libs = _mapped_hip_runtimes()
+    if len(libs) > 1:
+        import warnings
+        warnings.warn("two HIP runtimes are mapped into this process (%s): device pointers of one are not valid in the "
+                      "other -- import torch before gofindthem_amd loads libgft.so" % ", ".join(libs), RuntimeWarning)
+
+
 def load():
     global _LIB
     if _LIB is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("libgft.so is not built (run `python -m gofindthem_amd.build`); "
                                "gofindthem_amd has no CPU fallback for the hot path")
+        _hip_runtime_first()
         L = C.CDLL(LIB_PATH)
+        _check_one_hip_runtime()
         for name, (res, args) in SYMBOLS.items():
             f = getattr(L, name)            # AttributeError if a declared symbol is not exported
             f.restype, f.argtypes = res, args

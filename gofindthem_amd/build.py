@@ -14,7 +14,12 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libgft.so")
 ARCH = "gfx950"
 
-HIP_SOURCES = ["gft_kernels.hip", "gft_solve.hip", "gft_scan2.hip", "gft_scan3.hip", "gft_scan4.hip", "gft_scan5.hip"]
+# the product library carries the two production scan kernels (scan5, scan3) and the DFA kernel (an independent algorithm,
+# the cross-check); GFT_EXTRA_KERNELS=1 adds the earlier suffix-window kernels scan2 / scan4 (tools/ studies, the opt-in
+# cross-check job of tests/test_gpu_parity.py)
+EXTRA = os.environ.get("GFT_EXTRA_KERNELS", "0") == "1"
+HIP_SOURCES = ["gft_kernels.hip", "gft_solve.hip", "gft_scan3.hip", "gft_scan5.hip"] + (["gft_scan2.hip", "gft_scan4.hip"] if EXTRA else [])
+STAMP = os.path.join(CSRC, ".build_flags")
 CXX_SOURCES = ["gft_api.cpp", "ac_tables.cpp", "scan2_tables.cpp", "scan3_tables.cpp", "dsl_compile.cpp", "finder_host.cpp", "json_mini.cpp", "group_host.cpp", "host_solve.cpp"]
 
 
@@ -29,6 +34,9 @@ def build_lib(force=False, verbose=False):
     srcs = [os.path.join(CSRC, f) for f in HIP_SOURCES + CXX_SOURCES if os.path.exists(os.path.join(CSRC, f))]
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))]
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "gft.h"))
+    flags = "extra=%d" % int(EXTRA)
+    if not os.path.exists(STAMP) or open(STAMP).read() != flags:
+        force = True                 # (another set of kernels than the objects on disk were built for)
     if not force and not _newer(LIB, srcs + hdrs):
         return LIB
     objs, jobs = [], []
@@ -36,6 +44,8 @@ def build_lib(force=False, verbose=False):
         o = os.path.join(CSRC, os.path.basename(s) + ".o")
         if force or _newer(o, [s] + hdrs):
             cmd = ["hipcc", "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-c", s, "-o", o]
+            if EXTRA:
+                cmd.insert(1, "-DGFT_EXTRA_KERNELS")
             if s.endswith(".cpp"):
                 cmd[1:1] = ["-x", "hip"]   # host code that includes hip_runtime.h; no kernels inside
             jobs.append(cmd)
@@ -54,6 +64,8 @@ def build_lib(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(flags)
     return LIB
 
 

@@ -605,7 +605,7 @@ int gft_finder_force_build(gft_finder* f) try {
     if (!f) return GFT_E_INVALID;
     GFT_FLOCK(f);
     return finder_ret(f, f->finder->ForceBuild(), GFT_E_ENGINE);
-} GFT_CATCH_VALUE(0)
+} GFT_CATCH((f ? &f->err : nullptr))
 
 int gft_finder_process_text(gft_finder* f, const uint8_t* text, uint64_t text_len, uint32_t* out_idx, uint32_t cap,
                             uint32_t* n_true) try {

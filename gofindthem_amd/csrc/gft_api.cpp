@@ -52,6 +52,20 @@ struct ProfCat {
 
 }  // namespace
 
+#ifndef GFT_EXTRA_KERNELS
+// The earlier suffix-window kernels (gft_scan2.hip, gft_scan4.hip) are cross-checks and study objects: a product build
+// does not carry them (python -m gofindthem_amd.build with GFT_EXTRA_KERNELS=1 does).  Without them nothing "fits".
+namespace gft {
+bool scan2_plan(uint32_t, uint32_t, uint32_t, uint32_t, size_t, uint32_t*, uint32_t*) { return false; }
+hipError_t launch_scan2(const Scan2Params&, uint32_t, unsigned, hipStream_t) { return hipErrorNotSupported; }
+bool scan4_plan(uint32_t, uint32_t, uint32_t, uint32_t, size_t, bool, uint32_t*, uint32_t*) { return false; }
+hipError_t launch_scan4(const Scan2Params&, uint32_t, unsigned, hipStream_t) { return hipErrorNotSupported; }
+}  // namespace gft
+static constexpr bool kExtraKernels = false;
+#else
+static constexpr bool kExtraKernels = true;
+#endif
+
 struct gft_engine {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -134,6 +148,7 @@ struct gft_engine {
     std::vector<uint64_t> shard_cut;                     // document cuts of the last multi-device gft_process
     bool in_multi = false;                               // set while a multi-device call runs this engine's own share
     std::vector<void*> comms;                            // RCCL communicators (ncclCommInitAll), one per device; empty: none
+    bool rccl_self = false;                              // GFT_RCCL_SELF=1 over one device named several times: ONE communicator of one rank
     void* rccl_lib = nullptr;
 
     // programs
@@ -503,6 +518,11 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         HIP_TRY(hipMemsetAsync(e->d_match_off.p, 0, 8, st), "memset");
         HIP_TRY(hipStreamSynchronize(st), "sync");
         e->last_n_units = e->last_total = 0;
+        // (nothing was scanned: the verdict and the text range of the batch BEFORE must not be judged against this one's
+        // pointers -- refine_nonascii would launch k_fold_safe over a stale range of a text that may be NULL)
+        e->last_nonascii = false;
+        e->last_nonascii_bits = 0;
+        e->last_text_lo = e->last_text_hi = 0;
         return GFT_OK;
     }
     const uint32_t warm = e->tab.max_term_len ? e->tab.max_term_len - 1 : 0;
@@ -1187,6 +1207,15 @@ const char* validate_tables(const AcTables& a, const Scan2Tables& t, const Scan3
     if (t.supported) {
         if (t.kp == 0 || t.kp > 256 || t.pad_class >= t.kp) return "scan2 classes";
         for (int b = 0; b < 256; b++) if (t.cls[b] >= t.kp || t.cls_fold[b] >= t.kp) return "scan2 byte class";
+        // build_scan5_tables (run on imported tables too) indexes its class counters by the automaton's byte classes and splits
+        // every bucket key into four classes: the two class maps must be one, and a key must be four classes
+        if (t.kp != a.n_classes) return "scan2 class count differs from the automaton's";
+        for (int b = 0; b < 256; b++) if (t.cls[b] != a.byte_class[b]) return "scan2 byte class differs from the automaton's";
+        {
+            const uint64_t kp4 = (uint64_t)t.kp * t.kp * t.kp * t.kp;
+            for (const Scan2Slot& s : t.slots) if (s.key != kScan2EmptyKey && s.key >= kp4) return "bucket key";
+            for (const Scan2Slot& s : t.more) if (s.key != kScan2EmptyKey && s.key >= kp4) return "bucket list key";
+        }
         if (t.hashed ? (t.hash_shift < 1 || t.hash_shift > 31 || t.filter_bits != (1u << (32 - t.hash_shift)))
                      : (uint64_t)t.kp * t.kp * t.kp * t.kp > t.filter_bits) return "scan2 filter size";
         if (!t.short3.empty() && t.short3.size() < (uint64_t)t.kp * t.kp * t.kp) return "scan2 short3 size";
@@ -1317,6 +1346,7 @@ int gft_set_stream(gft_engine* e, void* hip_stream) try {
     return GFT_OK;
 } GFT_CATCH((e ? &e->err : nullptr))
 
+
 // e->tab / e->s2 hold compiled tables (from gft_build or gft_import_tables): check them against the device, upload
 static int install_tables(gft_engine* e, uint32_t flags) {
     if (e->tab.max_term_len + 1024 > kTextBuf)
@@ -1342,6 +1372,8 @@ static int install_tables(gft_engine* e, uint32_t flags) {
     if ((rc = upload(e, e->d_term_len, e->tab.term_len, "table upload"))) return rc;
     // GFT_SCAN_KERNEL=dfa forces the general two-tier DFA kernel
     const char* force = getenv("GFT_SCAN_KERNEL");
+    if (!kExtraKernels && force && (std::string(force) == "scan2" || std::string(force) == "scan4"))
+        return fail(e, GFT_E_UNSUPPORTED, std::string("GFT_SCAN_KERNEL=") + force + ": this library was built without the cross-check kernels (GFT_EXTRA_KERNELS=1 python -m gofindthem_amd.build --force)");
     const bool k2_fits = e->s2.supported && scan2_plan((uint32_t)e->s2.filter.size(), (uint32_t)e->s2.short3.size(),
                                                         (uint32_t)std::min<size_t>(e->s2.shorts_packed.size(), 255 * 3),
                                                         e->s2.fpt_lg ? 0u : kScan2FptSize, e->lds_max - 512,
@@ -1368,7 +1400,9 @@ static int install_tables(gft_engine* e, uint32_t flags) {
     e->s5_short_groups = false;
     const bool want5 = !force || std::string(force) == "scan5" || std::string(force) == "auto" || !*force;
     const bool large5 = e->s2.long_ok && !e->s2.short_direct && e->s3.supported && e->opt_scan5_large;
-    if ((e->use_scan2 || large5) && e->s2.long_ok && want5) {
+    // (the tables that kernel needs: the direct short-term table of small alphabets, or the group-indexed one)
+    const bool direct5 = e->s2.supported && !(force && std::string(force) == "dfa");
+    if ((direct5 || large5) && e->s2.long_ok && want5) {
         uint32_t tb = 1;
         while ((1ull << tb) < e->tab.terms.size()) tb++;
         e->s5_term_bits = tb;
@@ -1533,6 +1567,7 @@ uint32_t gft_n_terms(const gft_engine* e) { return e ? (uint32_t)e->tab.terms.si
 uint32_t gft_n_states(const gft_engine* e) { return e ? e->tab.n_states : 0; }
 uint32_t gft_n_exprs(const gft_engine* e) { return e ? e->n_exprs : 0; }
 int gft_last_nonascii(const gft_engine* e) { return e && e->last_nonascii ? 1 : 0; }
+const char* gft_build_info(void) { return kExtraKernels ? "gfx950 extra_kernels=1" : "gfx950 extra_kernels=0"; }
 const char* gft_scan_kernel(const gft_engine* e) {
     if (!e || !e->built) return "";
     return e->use_scan3 ? "scan3" : e->use_scan4 ? "scan4" : e->use_scan5 ? "scan5" : e->use_scan2 ? "scan2" : "dfa";
@@ -1974,10 +2009,18 @@ int gft_process_device(gft_engine* e, const uint8_t* d_text_blob, const uint64_t
     if (want_hx) {
         xo.resize(n_docs + 1);
         HIP_TRY(hipMemcpy(xo.data(), d_extra->off, (n_docs + 1) * 8, hipMemcpyDeviceToHost), "extra read-back");
+        // (the host walks these arrays now, not only the kernel: offsets must ascend, slots must exist -- what upload_extra
+        // checks for host arrays)
+        for (uint64_t d = 0; d < n_docs; d++)
+            if (xo[d] > xo[d + 1]) return fail(e, GFT_E_INVALID, "extra offsets are not ascending");
+        if (xo[n_docs] > (1ull << 40)) return fail(e, GFT_E_INVALID, "extra offsets are out of range");
         xs.resize(xo[n_docs] + 1); xp.resize(xo[n_docs] + 1);
         if (xo[n_docs]) {
             HIP_TRY(hipMemcpy(xs.data(), d_extra->slot, xo[n_docs] * 4, hipMemcpyDeviceToHost), "extra read-back");
             HIP_TRY(hipMemcpy(xp.data(), d_extra->pos, xo[n_docs] * 4, hipMemcpyDeviceToHost), "extra read-back");
+            const uint64_t n_slots = e->tab.terms.size() + e->n_extra;
+            for (uint64_t i = xo[0]; i < xo[n_docs]; i++)
+                if (xs[i] >= n_slots) return fail(e, GFT_E_INVALID, "extra slot out of range");
         }
         hx.off = xo.data(); hx.slot = xs.data(); hx.pos = xp.data();
     }
@@ -2534,16 +2577,24 @@ int gft_engine_create_multi(gft_engine** out, const int* devices, int n_devices)
     std::vector<int> uniq(devs);
     std::sort(uniq.begin(), uniq.end());
     const bool distinct = std::adjacent_find(uniq.begin(), uniq.end()) == uniq.end();
-    if (devs.size() > 1 && distinct) {
+    // GFT_RCCL_SELF=1: a list that names ONE device several times gets a communicator of one rank, and the gather moves every
+    // further shard's bitmap with a grouped ncclSend / ncclRecv of that rank to itself -- the same dlopen, the same bound
+    // entry points, the same group and stream ordering as the N-device gather, on the one GPU a test box has
+    const char* self_env = getenv("GFT_RCCL_SELF");
+    e->rccl_self = devs.size() > 1 && uniq.front() == uniq.back() && self_env && self_env[0] == '1';
+    if (devs.size() > 1 && (distinct || e->rccl_self)) {
         RcclApi& api = rccl_api();
         if (!api.ok()) {
+            e->rccl_self = false;
             e->err = "RCCL (librccl.so) could not be loaded: bitmaps will be gathered by device-to-device copies";
             return GFT_W_NO_RCCL;
         }
-        std::vector<ncclComm_t> comms(devs.size());
-        const ncclResult_t r = api.CommInitAll(comms.data(), (int)devs.size(), devs.data());
+        std::vector<ncclComm_t> comms(e->rccl_self ? 1 : devs.size());
+        DeviceGuard dg(devs[0]);
+        const ncclResult_t r = api.CommInitAll(comms.data(), (int)comms.size(), devs.data());
         if (r != ncclSuccess) {
             // the handle is complete without communicators, but the caller is TOLD that its gathers are not RCCL's
+            e->rccl_self = false;
             e->err = std::string("ncclCommInitAll: ") + api.GetErrorString(r) + " (bitmaps will be gathered by device-to-device copies)";
             return GFT_W_NO_RCCL;
         }
@@ -2597,12 +2648,18 @@ int gft_process_device_multi(gft_engine* e, const uint8_t* const* d_text, const 
     if (n > 1 && words) {
         RcclApi& api = rccl_api();
         if (!e->comms.empty() && api.ok()) {
+            DeviceGuard dgr(e->device);
             ncclResult_t r = api.GroupStart();
             for (size_t i = 1; i < n && r == ncclSuccess; i++) {
                 if (!n_docs[i]) continue;
-                r = api.Recv(d_bitmap_root + first[i] * words, n_docs[i] * words, ncclUint32, (int)i, (ncclComm_t)e->comms[0], e->stream);
+                // (one rank for all shards under GFT_RCCL_SELF: peer 0 on communicator 0, both halves on the root's stream --
+                // the shard's stream was drained when its gft_process_device returned)
+                const int from = e->rccl_self ? 0 : (int)i;
+                ncclComm_t send_comm = (ncclComm_t)e->comms[e->rccl_self ? 0 : i];
+                hipStream_t send_stream = e->rccl_self ? e->stream : eng[i]->stream;
+                r = api.Recv(d_bitmap_root + first[i] * words, n_docs[i] * words, ncclUint32, from, (ncclComm_t)e->comms[0], e->stream);
                 if (r == ncclSuccess)
-                    r = api.Send(eng[i]->d_bitmap.p, n_docs[i] * words, ncclUint32, 0, (ncclComm_t)e->comms[i], eng[i]->stream);
+                    r = api.Send(eng[i]->d_bitmap.p, n_docs[i] * words, ncclUint32, 0, send_comm, send_stream);
             }
             const ncclResult_t r2 = api.GroupEnd();
             if (r != ncclSuccess || r2 != ncclSuccess)

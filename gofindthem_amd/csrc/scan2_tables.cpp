@@ -273,6 +273,8 @@ void build_scan5_tables(const AcTables& ac, const Scan2Tables& s2, uint32_t G, S
     const uint32_t kp = s2.kp;
     if (G > kp) G = kp;
     if (G > 32) G = 32;              // (a filter word holds one bit per group)
+    if (G < 2 && kp > 1) G = 2;      // (group 0 is class 0's alone: the other classes need one of their own)
+    if (G < 1) G = 1;
     t.G = G;
     // class -> group.  Weights: how often a class occurs in the dictionary (the build's only model of the text, as in
     // pick_off); class 0 is "everything else" -- blanks, punctuation, the bytes of other alphabets -- and frequent in any text.

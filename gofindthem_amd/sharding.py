@@ -51,28 +51,31 @@ class BitmapGather:
     batch i travels over xGMI while batch i + 1 is scanned and solved (the collective runs on the process group's own
     stream); `drain()` completes everything that is still in flight."""
 
-    def __init__(self, local_bitmap, rows_per_rank=None):
+    def __init__(self, local_bitmap, rows_per_rank=None, force_collective=False):
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
+        # a group of ONE rank normally skips the exchange; force_collective sends it through the process group all the same
+        # (dist.gather / all_gather of one rank over RCCL: how the collective path is exercised on a one-GPU box)
+        self.collective = self.world > 1 or (force_collective and dist.is_initialized())
         self.locals = list(local_bitmap) if isinstance(local_bitmap, (list, tuple)) else [local_bitmap]
         self.local = self.locals[0]
         self.slot_parts = [None] * len(self.locals)
         self.pending = [None] * len(self.locals)
-        if self.world > 1 and self.rank == 0:
+        if self.collective and self.rank == 0:
             rows = rows_per_rank or [self.local.shape[0]] * self.world
             self.slot_parts = [[torch.empty((r, self.local.shape[1]), dtype=self.local.dtype, device=self.local.device)
                                 for r in rows] for _ in self.locals]
         self.parts = self.slot_parts[0]
-        if self.world > 1 and rows_per_rank is not None and len(set(rows_per_rank)) > 1:
+        if self.collective and rows_per_rank is not None and len(set(rows_per_rank)) > 1:
             raise ValueError("dist.gather needs equal shard sizes; pad the last shard or use split sizes that divide")
 
     def __call__(self):
-        if self.world > 1:
+        if self.collective:
             dist.gather(self.local, self.parts, dst=0)
-        return self.parts if self.world > 1 else [self.local]
+        return self.parts if self.collective else [self.local]
 
     def start(self, slot):
-        if self.world > 1:
+        if self.collective:
             self.pending[slot] = dist.gather(self.locals[slot], self.slot_parts[slot], dst=0, async_op=True)
 
     def wait(self, slot):
@@ -86,7 +89,7 @@ class BitmapGather:
 
     def full(self, slot=0):
         """rank 0: the bitmap of all documents in document order"""
-        parts = self.slot_parts[slot] if self.world > 1 else [self.locals[slot]]
+        parts = self.slot_parts[slot] if self.collective else [self.locals[slot]]
         return torch.cat(parts, 0) if self.rank == 0 else None
 
 
@@ -103,7 +106,7 @@ def verify_gather(gather, slot, rows):
     `slot` into a checksum on its device; one tiny all_gather brings the checksums (and row counts) together; rank 0
     computes the same checksums over what the gather delivered and compares.  -> (ok on rank 0 / True elsewhere, shards
     checked).  Outside any timed region: it synchronises."""
-    if gather.world == 1:
+    if not gather.collective:
         return True, 1
     local = gather.locals[slot][:rows]
     dev = local.device

@@ -148,9 +148,13 @@ uint32_t gft_n_exprs(const gft_engine* e);
  * bytes on their way; only such a batch pays one more pass over its text for this answer.
  * gft_finder_process_device checks it and repeats an unsafe batch through the host's ToLower. */
 int gft_last_nonascii(const gft_engine* e);
-/* which scan kernel the built dictionary runs on: "scan2" (suffix-window kernel, small alphabets), "scan3" (stride-2
- * suffix-window kernel, any alphabet) or "dfa" (general two-tier DFA kernel: only when forced) */
+/* which scan kernel the built dictionary runs on: "scan5" (suffix-window kernel, one filter probe per two bytes: the
+ * default wherever the long-term tables exist), "scan3" (stride-2 suffix-window kernel, any alphabet: the fallback) or
+ * "dfa" (general two-tier DFA kernel: only when forced with GFT_SCAN_KERNEL); "scan2" / "scan4" (the earlier
+ * suffix-window kernels) only in a library built with GFT_EXTRA_KERNELS (tools/, the opt-in cross-check job) */
 const char* gft_scan_kernel(const gft_engine* e);
+/* how this library was built: "gfx950 extra_kernels=0|1" (1: the cross-check kernels scan2 / scan4 are compiled in) */
+const char* gft_build_info(void);
 
 /* Caller-supplied matches (regex engine output, or the output of a foreign SubstringEngine), CSR per document.
  * `slot` is ABSOLUTE: n_terms + j for extra literal j, or a dictionary term id when a regex literal has the same
@@ -292,7 +296,9 @@ int gft_engine_create_multi(gft_engine** out, const int* devices, int n_devices)
 int gft_n_devices(const gft_engine* e);
 /* how gft_process_device_multi moves the shards' bitmaps to the first device: "rccl" (ncclSend / ncclRecv over xGMI),
  * "copy" (device-to-device copies: RCCL unavailable, or a device named twice) or "" (single-device handle).
- * NOTE: the "rccl" branch has not run on hardware yet -- the build's GPU boxes have one device. */
+ * GFT_RCCL_SELF=1 in the environment when the handle is created: a list that names ONE device several times gets one
+ * communicator of one rank and the gather is that rank's grouped ncclSend / ncclRecv to itself ("rccl") -- how the RCCL
+ * branch is exercised on a one-GPU box (tests/test_gpu_multi.py). */
 const char* gft_gather_mode(const gft_engine* e);
 gft_engine* gft_device_engine(gft_engine* e, int i);     /* the per-device engine (its stream, its profile counters) */
 /* the document cuts gft_process would use: device i gets documents [cut[i], cut[i+1]); cut has n_devices + 1 entries */

@@ -101,10 +101,18 @@ def test_finder_over_two_devices_with_regex_terms():
     assert np.array_equal(got[0], got[1]) and got[0].any()
 
 
-def test_device_resident_shards_and_the_gather():
+@pytest.mark.parametrize("mode", ["default", "rccl-self"])
+def test_device_resident_shards_and_the_gather(mode, monkeypatch):
     """gft_process_device_multi: every device's shard is already in its HBM; the bitmaps are gathered to the first device
-    (RCCL when the devices are distinct)"""
+    (RCCL when the devices are distinct).  "rccl-self": on a one-GPU box GFT_RCCL_SELF=1 gives the handle over [0, 0, 0] ONE
+    communicator of one rank (ncclCommInitAll) and the gather is that rank's grouped ncclSend / ncclRecv to itself -- dlopen,
+    every bound entry point, the group and the stream ordering of the N-device gather."""
     devs = _devices()
+    if mode == "rccl-self":
+        if torch.cuda.device_count() >= 2:
+            pytest.skip("distinct devices: the default case already gathers with RCCL")
+        monkeypatch.setenv("GFT_RCCL_SELF", "1")
+        devs = [0, 0, 0]
     w = Workload(1000)
     terms = w.terms()
     exprs = make_expressions(terms, 96, inord_fraction=0.3, cover=True)
@@ -113,6 +121,8 @@ def test_device_resident_shards_and_the_gather():
     f.ForceBuild()
     L = _lib.load()
     eh = f.engine_handle()
+    want_mode = b"rccl" if mode == "rccl-self" or torch.cuda.device_count() >= 2 else b"copy"
+    assert L.gft_gather_mode(eh) == want_mode, L.gft_last_error(eh)
     text, off = w.docs_host(0, 300)
     cut = np.zeros(len(devs) + 1, np.uint64)
     assert L.gft_split_docs(eh, off.ctypes.data, 300, cut.ctypes.data) == 0
@@ -134,7 +144,19 @@ def test_device_resident_shards_and_the_gather():
     assert rc == 0, L.gft_last_error(eh)
     o = Oracle(sorted(k.encode() for k in f.GetKeywords()))
     o.set_expressions(exprs, False)
-    assert np.array_equal(bm.cpu().numpy().astype(np.uint32), o.process(text, off, fold=True))
+    want = o.process(text, off, fold=True)
+    assert np.array_equal(bm.cpu().numpy().astype(np.uint32), want)
+    # a second batch through the same communicators (smaller last shard, an empty middle one)
+    bm.zero_()
+    nd2 = list(nd)
+    if len(devs) == 3:
+        nd2[1] = 0
+    rc = L.gft_process_device_multi(eh, (C.c_void_p * len(devs))(*tp), (C.c_void_p * len(devs))(*op),
+                                    (C.c_uint64 * len(devs))(*nd2), _lib.GFT_FOLD_ASCII, bm.data_ptr())
+    assert rc == 0, L.gft_last_error(eh)
+    got = bm.cpu().numpy().astype(np.uint32)
+    rows = [want[int(cut[i]):int(cut[i]) + nd2[i]] for i in range(len(devs))]
+    assert np.array_equal(got[:sum(nd2)], np.concatenate(rows))
     f.close()
 
 
@@ -167,3 +189,29 @@ def test_non_ascii_text_in_the_first_shard_only_is_reported():
         assert mo.tolist() == [0] and ti.size == 0
     finally:
         e.close()
+
+
+def test_empty_batch_after_a_non_ascii_one_forgets_the_verdict():
+    """an empty batch scans nothing, so the non-ASCII verdict (and the text range it was taken over) of the
+    batch BEFORE must not survive into it -- single handle and multi-device handle (where an empty device-0 shard used
+    to carry the stale flag)."""
+    L = _lib.load()
+    for kw in (dict(device=0), dict(devices=_devices())):
+        e = Engine(**kw)
+        try:
+            e.build([b"ecole", "école".encode()])
+            blob, off = pack_strings(["ÉCOLE nationale", "plain ascii"])
+            e.scan(blob, off, fold=True)
+            assert L.gft_last_nonascii(e._h) == 1
+            mo, ti, po = e.scan(np.zeros(0, np.uint8), np.zeros(1, np.uint64), fold=True)
+            assert mo.tolist() == [0] and ti.size == 0
+            assert L.gft_last_nonascii(e._h) == 0
+            # ... and the device-resident entry point with NULL text for an empty batch
+            e.set_programs([[1 << 28]])
+            e.scan(blob, off, fold=True)
+            assert L.gft_last_nonascii(e._h) == 1
+            if "device" in kw:
+                assert L.gft_process_device(e._h, None, None, 0, _lib.GFT_FOLD_ASCII, None, None) == 0, L.gft_last_error(e._h)
+                assert L.gft_last_nonascii(e._h) == 0
+        finally:
+            e.close()

@@ -10,11 +10,29 @@ from oracle.pyoracle import Oracle, POS_END, POS_START
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["scan5", "scan4", "scan3", "scan2", "scan2-ordered", "dfa"], autouse=True)
+def _kernels():
+    """the scan kernels of THIS build of libgft.so: the two production kernels and the DFA kernel (an independent
+    algorithm); a library built with GFT_EXTRA_KERNELS=1 (the opt-in cross-check job) also has the earlier suffix-window
+    kernels scan2 / scan4"""
+    from gofindthem_amd import _lib
+    try:
+        extra = b"extra_kernels=1" in _lib.load().gft_build_info()
+    except Exception:                       # (no library: the tests themselves will say so)
+        extra = False
+    return ["scan5", "scan3", "dfa"] + (["scan4", "scan2", "scan2-ordered"] if extra else [])
+
+
+KERNELS = _kernels()
+needs_extra_kernels = pytest.mark.skipif("scan4" not in KERNELS, reason="libgft.so was built without GFT_EXTRA_KERNELS=1")
+
+
+@pytest.fixture(params=KERNELS, autouse=True)
 def scan_kernel(request, monkeypatch):
-    """every test runs against the suffix-window kernel with the unit's text in LDS (scan5), its streaming form (scan4), the stride-2 suffix-window kernel (scan3), the
-    round-1 suffix-window kernel (GFT_SCAN_KERNEL=scan2: balanced path, and its in-kernel ordered path with
-    GFT_SCAN_ORDERED=1) and the general two-tier DFA kernel (GFT_SCAN_KERNEL=dfa); the variable is read by gft_build"""
+    """every test runs against the suffix-window kernel with one filter probe per two bytes (scan5, the default), the stride-2
+    suffix-window kernel (scan3, the fallback) and the general two-tier DFA kernel (GFT_SCAN_KERNEL=dfa) -- and, in a
+    GFT_EXTRA_KERNELS=1 build, against scan5's streaming form (scan4) and the round-1 suffix-window kernel
+    (GFT_SCAN_KERNEL=scan2: balanced path, and its in-kernel ordered path with GFT_SCAN_ORDERED=1); the variable is read
+    by gft_build"""
     monkeypatch.setenv("GFT_SCAN_KERNEL", request.param.split("-")[0])
     if request.param.endswith("-ordered"):
         monkeypatch.setenv("GFT_SCAN_ORDERED", "1")
@@ -451,6 +469,7 @@ def test_unique_terms_mode_is_the_cloudflare_engine_output(eng):
     assert int(m.n_matches) == int(mo[-1])
 
 
+@needs_extra_kernels
 def test_streaming_kernel_chunks_of_eight_units_and_regions_that_overflow(monkeypatch):
     """gft_scan4 on small batches takes one unit per chunk; GFT_SCAN4_CHUNK=8 forces the production shape (eight units per
     chunk: documents that share a stream, slices of long documents, empty documents in between).  A fresh engine sizes a unit's

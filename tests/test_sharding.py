@@ -25,12 +25,19 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, use_gpu, out_path):
+def _worker(rank, world, port, use_gpu, out_path, backend="gloo"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # (the process group comes first: nothing has touched the GPU yet when the launcher's rendezvous runs)
+    if backend == "nccl":
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda:0"))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    dev = "cuda:0" if backend == "nccl" else "cpu"
+    force = world == 1            # a group of one rank takes the collective path on request
     from gofindthem_amd.sharding import BitmapGather, all_ranks_ok, max_over_ranks, shard_range
     from gofindthem_amd.workload import Workload, make_expressions
     from oracle.pyoracle import Oracle
@@ -45,16 +52,17 @@ def _worker(rank, world, port, use_gpu, out_path):
         from gofindthem_amd.finder import EmptyRgxEngine, Finder, GpuEngine
         f = Finder(GpuEngine.__new__(GpuEngine), EmptyRgxEngine(), False, device=0)
         f.AddExpressions(exprs)
-        local = torch.from_numpy(f.ProcessTexts(blob=text, doc_off=off).view(np.int32))
+        local = torch.from_numpy(f.ProcessTexts(blob=text, doc_off=off).view(np.int32)).to(dev)
     else:
         o = Oracle(terms)
         o.set_expressions(exprs, False)
-        local = torch.from_numpy(o.process(text, off, fold=True).view(np.int32))
-    g = BitmapGather(local)
+        local = torch.from_numpy(o.process(text, off, fold=True).view(np.int32)).to(dev)
+    g = BitmapGather(local, force_collective=force)
+    assert g.collective
     g()
     # pipelined form (bench.py, N > 1): two result buffers, gathers in flight while the next batch is computed
     other = local ^ 0x55
-    gp = BitmapGather([local.clone(), other])
+    gp = BitmapGather([local.clone(), other], force_collective=force)
     gp.start(0)
     gp.start(1)
     gp.wait(0)
@@ -71,10 +79,10 @@ def _worker(rank, world, port, use_gpu, out_path):
     damaged, _ = verify_gather(gp, 1, n)
     if rank == 0:
         pipelined_ok = pipelined_ok and not damaged
-    ok = all_ranks_ok(pipelined_ok, "cpu")
-    t = max_over_ranks(float(rank), "cpu")
+    ok = all_ranks_ok(pipelined_ok, dev)
+    t = max_over_ranks(float(rank), dev)
     if rank == 0:
-        full = g.full().numpy().view(np.uint32)
+        full = g.full().cpu().numpy().view(np.uint32)
         o = Oracle(terms)
         o.set_expressions(exprs, False)
         wtext, woff = wl.docs_host(0, per * world)
@@ -84,21 +92,35 @@ def _worker(rank, world, port, use_gpu, out_path):
     dist.destroy_process_group()
 
 
-def _run(use_gpu, tmp_path):
+def _run(use_gpu, tmp_path, world=2, backend="gloo"):
     out = str(tmp_path / "res.npy")
     port = _free_port()
-    mp.start_processes(_worker, args=(2, port, use_gpu, out), nprocs=2, join=True, start_method="spawn")
+    mp.start_processes(_worker, args=(world, port, use_gpu, out, backend), nprocs=world, join=True, start_method="spawn")
     res = np.load(out)
-    assert res.tolist() == [1, 1, 1, N_DOCS]
+    assert res.tolist() == [1, 1, 1, N_DOCS // world * world]
 
 
 def test_gather_two_ranks_gloo_cpu(tmp_path):
     _run(False, tmp_path)
 
 
+def test_gather_one_rank_takes_the_collective_path_on_request_gloo_cpu(tmp_path):
+    """BitmapGather(force_collective=True) / verify_gather in a group of ONE rank: the exchange goes through the process
+    group instead of being skipped (the form the one-rank nccl test below runs on the GPU box)"""
+    _run(False, tmp_path, world=1)
+
+
 @pytest.mark.gpu
 def test_gather_two_ranks_gpu_compute(tmp_path):
     _run(True, tmp_path)
+
+
+@pytest.mark.gpu
+def test_gather_one_rank_nccl_is_rccl(tmp_path):
+    """ONE rank with backend "nccl" (= RCCL on ROCm; the process group is created before anything
+    touches the GPU) runs the HIP path on its shard and sends its bitmap through start / wait / drain / verify_gather --
+    dist.gather and all_gather of device tensors over RCCL -- and rank 0 checks the result against the oracle."""
+    _run(True, tmp_path, world=1, backend="nccl")
 
 
 def test_split_docs():

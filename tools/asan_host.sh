@@ -10,7 +10,7 @@ mkdir -p $OUT
 CS=gofindthem_amd/csrc
 SAN="-fsanitize=address,undefined -fno-omit-frame-pointer -g"
 objs=""
-for f in gft_kernels.hip gft_solve.hip gft_scan2.hip gft_scan3.hip gft_scan4.hip gft_scan5.hip; do
+for f in gft_kernels.hip gft_solve.hip gft_scan3.hip gft_scan5.hip; do
   o=$OUT/$f.o
   [ $o -nt $CS/$f ] || hipcc --offload-arch=gfx950 -O1 -std=c++17 -fPIC -c $CS/$f -o $o
   objs="$objs $o"

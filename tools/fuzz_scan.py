@@ -25,6 +25,14 @@ ALPHAS = [b"ab", b"abc", b"abcdefgh", b"abcdefghijklmnopqrstuvwxyz ", b"abcdefgh
           bytes(range(1, 120)), bytes(range(256))]
 
 
+def _have(kernel):
+    """scan2 / scan4 exist only in a GFT_EXTRA_KERNELS=1 build of libgft.so: a product build takes its own choice instead"""
+    from gofindthem_amd import _lib
+    if kernel in ("scan2", "scan4") and b"extra_kernels=1" not in _lib.load().gft_build_info():
+        return "auto"
+    return kernel
+
+
 def run(iters, seed, budget_s, eng=None, progress=False):
     """-> (iterations done, None) or (iterations done, description of the first difference)"""
     own = eng is None
@@ -69,7 +77,7 @@ def one_process(eng, seed, it):
         terms.add(A[rng.integers(0, len(alpha), int(rng.integers(1, maxlen + 1)))].tobytes())
     tl = sorted(terms)
     pos_mode = POS_END if rng.integers(2) else POS_START
-    os.environ["GFT_SCAN_KERNEL"] = ["auto", "scan2", "scan3", "scan4", "scan5"][int(rng.integers(5))]     # (auto: the library's own choice)
+    os.environ["GFT_SCAN_KERNEL"] = _have(["auto", "scan2", "scan3", "scan4", "scan5"][int(rng.integers(5))])     # (auto: the library's own choice)
     os.environ.pop("GFT_SCAN_ORDERED", None)
     g = [None, None, "32", "16", "8", "0"][int(rng.integers(6))]
     if g is None:
@@ -149,8 +157,8 @@ def one(eng, seed, it):
     pos_mode = POS_END if rng.integers(2) else POS_START
     variant = ["", "ordered", "dfa", "scan3", "scan2", "scan5"][int(rng.choice([0, 0, 1, 2, 3, 3, 4, 5, 5]))]
     os.environ.pop("GFT_SCAN_ORDERED", None)
-    os.environ["GFT_SCAN_KERNEL"] = {"dfa": "dfa", "scan3": "scan3", "scan2": "scan2", "ordered": "scan2", "scan4": "scan4", "scan5": "scan5"}.get(variant, "auto")
-    if variant == "ordered":
+    os.environ["GFT_SCAN_KERNEL"] = _have({"dfa": "dfa", "scan3": "scan3", "scan2": "scan2", "ordered": "scan2", "scan4": "scan4", "scan5": "scan5"}.get(variant, "auto"))
+    if variant == "ordered" and os.environ["GFT_SCAN_KERNEL"] == "scan2":
         os.environ["GFT_SCAN_ORDERED"] = "1"
     # a third of the builds: the fingerprint table in global memory as for a 100 000-term dictionary, behind Bloom levels of
     # 8 192 bits (crowded) or the default size

@@ -28,6 +28,10 @@
 
 namespace gft {
 
+#ifndef GFT_S5_PIPE
+#define GFT_S5_PIPE 0
+#endif
+
 namespace {
 
 #include "gft_scan2_dev.hpp"
@@ -350,6 +354,75 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
             const bool want_fold = P.fold && P.nonascii;
             const uint32_t ndw = C >> 2;                         // dwords per lane (wave-uniform, <= 32)
             const uint32_t npieces = (ndw + 3) >> 2;
+#if GFT_S5_PIPE
+            // Whole pieces are software-pipelined: the sixteen group lookups of piece q + 1 are issued between the probes of
+            // piece q and the flag shifts that consume them, so a piece costs ONE LDS round trip instead of two (lookups ->
+            // keys -> probes -> flags in a row).  Two register sets for the groups (ga / gb), the loop body twice.
+            auto lookups = [&](const U128u& pw, uint32_t (&g)[16]) {
+                const uint32_t w[4] = {pw.x, pw.y, pw.z, pw.w};
+#pragma unroll
+                for (int i = 0; i < 16; i++) g[i] = lgrp[(w[i >> 2] >> (8 * (i & 3))) & 0xFF];
+            };
+            U128u pw = nxt, pn{0, 0, 0, 0};                     // words of piece q and of piece q + 1
+            if (npieces > 1 && 16 < nvalid) pn = *reinterpret_cast<const U128u*>(src + 16);
+            uint32_t ga[16], gb[16];
+            if (ndw >= 4) lookups(pw, ga);
+            auto piece = [&](uint32_t q, uint32_t (&g)[16], uint32_t (&gn)[16]) {
+                const uint32_t w[4] = {pw.x, pw.y, pw.z, pw.w};
+                if (q * 16 < nvalid) hib |= (w[0] | w[1]) | (w[2] | w[3]);   // (may take in up to 15 bytes behind the lane's range: conservative)
+                U128u pn2{0, 0, 0, 0};
+                if (q + 2 < npieces && (q + 2) * 16 < nvalid) pn2 = *reinterpret_cast<const U128u*>(src + (q + 2) * 16);
+                const uint32_t nd = ndw - 4 * q;                 // dwords of this piece that belong to the lane (>= 1)
+                if (nd >= 4) {
+                    uint32_t xk[8];
+                    xk[0] = mad24s(pq, G, g[0]);
+                    // probe t >= 1 sits at byte 2t: the 3-gram of the bytes 2t - 2 .. 2t
+#pragma unroll
+                    for (int t = 1; t < 8; t++) xk[t] = mad24s(mad24s(g[2 * t - 2], G, g[2 * t - 1]), G, g[2 * t]);
+                    u32x2 fk[8];
+#pragma unroll
+                    for (int t = 0; t < 8; t++) fk[t] = ldual[xk[t]];
+                    const bool nfull = q + 1 < npieces && ndw - 4 * (q + 1) >= 4;      // wave-uniform
+                    if (nfull) lookups(pn, gn);
+                    // flags: window ends at byte 2t: cc[2t] stands in front; at byte 2t + 1: cc[4 + 2t] behind
+                    acc = __builtin_amdgcn_alignbit(fk[0].x >> h3, acc, 1);
+                    acc = __builtin_amdgcn_alignbit(fk[0].y >> g[1], acc, 1);
+                    acc = __builtin_amdgcn_alignbit(fk[1].x >> h1, acc, 1);
+                    acc = __builtin_amdgcn_alignbit(fk[1].y >> g[3], acc, 1);
+#pragma unroll
+                    for (int t = 2; t < 8; t++) {
+                        acc = __builtin_amdgcn_alignbit(fk[t].x >> g[2 * t - 3], acc, 1);
+                        acc = __builtin_amdgcn_alignbit(fk[t].y >> g[2 * t + 1], acc, 1);
+                    }
+                    pq = mad24s(g[14], G, g[15]);
+                    h3 = g[13]; h2 = g[14]; h1 = g[15];
+                } else {
+                    auto dword = [&](uint32_t wd) {
+                        const uint32_t c0 = lgrp[wd & 0xFF], c1 = lgrp[(wd >> 8) & 0xFF], c2 = lgrp[(wd >> 16) & 0xFF], c3 = lgrp[wd >> 24];
+                        const uint32_t xa = mad24s(pq, G, c0);
+                        const uint32_t xb = mad24s(mad24s(c0, G, c1), G, c2);
+                        const u32x2 fa = ldual[xa], fb = ldual[xb];
+                        acc = __builtin_amdgcn_alignbit(fa.x >> h3, acc, 1);
+                        acc = __builtin_amdgcn_alignbit(fa.y >> c1, acc, 1);
+                        acc = __builtin_amdgcn_alignbit(fb.x >> h1, acc, 1);
+                        acc = __builtin_amdgcn_alignbit(fb.y >> c3, acc, 1);
+                        pq = mad24s(c2, G, c3);
+                        h3 = c1; h2 = c2; h1 = c3;
+                    };
+                    dword(w[0]);
+                    if (nd >= 2) dword(w[1]);
+                    if (nd >= 3) dword(w[2]);
+                }
+                if ((q & 1) && nd >= 4) {                        // 32 positions complete
+                    if ((q >> 1) == 0) m0 = acc; else if ((q >> 1) == 1) m1 = acc; else if ((q >> 1) == 2) m2 = acc; else m3 = acc;
+                }
+                pw = pn; pn = pn2;
+            };
+            for (uint32_t q = 0; q < npieces; q += 2) {
+                piece(q, ga, gb);
+                if (q + 1 < npieces) piece(q + 1, gb, ga);
+            }
+#else
             for (uint32_t q = 0; q < npieces; q++) {
                 const uint32_t w[4] = {nxt.x, nxt.y, nxt.z, nxt.w};
                 if (q * 16 < nvalid) hib |= (w[0] | w[1]) | (w[2] | w[3]);   // (may take in up to 15 bytes behind the lane's range: conservative)
@@ -397,6 +470,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
                     if ((q >> 1) == 0) m0 = acc; else if ((q >> 1) == 1) m1 = acc; else if ((q >> 1) == 2) m2 = acc; else m3 = acc;
                 }
             }
+#endif
             if (ndw & 7) {                                       // the last, partial group of 32 positions
                 const uint32_t v = acc >> (32 - 4 * (ndw & 7));
                 const uint32_t k = ndw >> 3;
@@ -536,15 +610,39 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
                     }
                 }
                 wave_lds_sync();
+                // stage B: the survivors, densely packed over the lanes, go to the L2 bucket table.  The first trip's loads -- the
+                // slots its keys name (they came along from stage A) and the text around the positions, the longest single wait
+                // of a unit -- are issued in FRONT of the short-term trips, which touch LDS only, and consumed behind them
+                static_assert(kScan5SurvX >= 64, "the first stage-B trip takes its keys from survx");
+                const bool b_on = lane < ns;
+                const uint32_t b_rel = ns ? cand[b_on ? lane : 0] : 0;
+                Cand b_k;
+                b_k.p = ubase + b_rel; b_k.x3 = 0; b_k.sid = 0; b_k.go_long = true; b_k.x = 0; b_k.tw = 0;
+                Slot b_s0{}, b_s1{};
+                Text8 b_t8{0, 0};
+                Front b_fr{};
+                uint32_t b_tl = 0;
+                if (ns) {
+                    b_k.x = survx[b_on ? lane : 0];
+                    b_s0 = slot_load(&P.slots[scan2_slot_hash(b_k.x, 0, P.slot_shift, P.slot_seed)]);
+                    b_s1 = slot_load(&P.slots[scan2_slot_hash(b_k.x, 1, P.slot_shift, P.slot_seed)]);
+                    b_t8 = cand_load(c, b_k.p);
+                    b_fr = front_load(c, b_k.p, 0);
+                    b_tl = tail_load(c, b_k.p);
+                }
                 while (o.npend) { if (SG) short_trip_g(c, o, lsg, ubase, o.npend < 64 ? o.npend : 64); else short_trip(c, o, ubase, o.npend < 64 ? o.npend : 64); }
                 if (DBG && (P.dbg & 2)) { if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(KARG(dbg_counters) + 2), (unsigned long long)ns); }
                 mark(3);
-                // stage B: the survivors, densely packed over the lanes, go to the L2 bucket table
                 Deferred dfr;
                 dfr.list = reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(cand) + ((ns * 2 + 7) & ~7u));
                 dfr.cap = (P.cand_cap * 2 - ((ns * 2 + 7) & ~7u)) / 8;
                 dfr.n = 0;
-                for (uint32_t i0 = 0; i0 < ns; i0 += 64) {
+                if (ns) {
+                    b_k.tw = b_t8.tw;
+                    b_fr.f[0] = b_t8.tw;
+                    finish_long5(c, o, b_on, b_rel, b_k, b_s0, b_s1, b_fr, b_tl, dfr);
+                }
+                for (uint32_t i0 = 64; i0 < ns; i0 += 64) {
                     const bool on = i0 + lane < ns;
                     const uint32_t rel = cand[on ? i0 + lane : 0];
                     const uint32_t p = ubase + rel;

@@ -53,6 +53,7 @@ SYMBOLS = {
     "gft_scan_device": (_i, [_vp, _vp, _vp, _u64, _u32, C.POINTER(GftMatches)]),
     "gft_set_programs": (_i, [_vp, _vp, _vp, _u32, _u32]),
     "gft_n_exprs": (_u32, [_vp]),
+    "gft_n_host_exprs": (_u32, [_vp]),
     "gft_process": (_i, [_vp, _vp, _vp, _u64, _u32, C.POINTER(GftExtra), _vp]),
     "gft_process_again": (_i, [_vp, _u64, C.POINTER(GftExtra), _vp]),
     "gft_process_device": (_i, [_vp, _vp, _vp, _u64, _u32, C.POINTER(GftExtra), _vp]),

@@ -168,6 +168,7 @@ struct gft_engine {
     DevBuf d_patch;                        // bit patches of host-solved results for a device-resident bitmap
     DevBuf d_prog, d_prog_off;            // public postfix words (INORD group subtrees are read from these)
     DevBuf d_fprog, d_fprog_off, d_groups; // fused internal form + INORD group table
+    DevBuf d_wide_slot, d_wide_theta;      // pairs of wide INORD groups, a region per wave of the solver's grid
     DevBuf d_solve_dbg;                    // GFT_SOLVE_DEBUG & 8: phase clocks
     // batches in a row that were one unit per document (k_units_single serves the next one from 2 on; a batch that took
     // that path and held a longer document after all sets it well below zero, so that a corpus whose batches alternate does
@@ -181,6 +182,7 @@ struct gft_engine {
     DevBuf d_fprog_t, d_fblk_off;          // fused programs per sorted block of 64, transposed (read when they do not fit LDS)
     uint32_t fprog_words = 0;
     uint32_t n_inord_groups = 0;           // fused INORD ops: 0 = the solver never reads positions
+    uint32_t wide_pairs = 0;               // the widest INORD group the device solves through its scratch path (0: none); d_wide_*
     uint32_t n_rare_words = 0;             // fused NOT + INORD ops: 0 = the solver variant without their slow path
     DevBuf d_pscratch;                    // HBM presence matrices when n_slots * 8 B does not fit LDS
 
@@ -274,7 +276,7 @@ int upload(gft_engine* e, DevBuf& buf, const std::vector<T>& v, const char* what
 // traits != nullptr: a program beyond the device solver's limits is not refused but marked (it is solved on the host),
 // and the slots of its multi-leaf INORD groups are listed
 int check_program(const gft_engine* e, const uint32_t* w, uint64_t len, uint32_t n_slots, uint32_t idx, ProgramTraits* traits = nullptr) {
-    uint32_t sp = 0, psp = 0;
+    uint32_t sp = 0, psp = 0, g_tot = 0, g_psp = 0;           // g_*: the most pairs / the deepest pair stack of the group being read
     std::vector<uint32_t> group_slots;
     std::vector<uint32_t> pcnt;   // pair counts of the INORD operand stack
     bool in_group = false;
@@ -307,6 +309,11 @@ int check_program(const gft_engine* e, const uint32_t* w, uint64_t len, uint32_t
         case GFT_OP_INORD:
             if (sp < 1 || pcnt.size() != 1) return bad("malformed INORD group");
             pcnt.clear(); in_group = false;
+            if (traits && (g_tot > kMaxPairs || g_psp > kMaxPairDepth) && g_tot <= kMaxPairsWide && g_psp <= kMaxPairDepthWide) {
+                traits->wide_pairs = std::max(traits->wide_pairs, g_tot);
+                traits->wide_groups.push_back(pc);
+            }
+            g_tot = g_psp = 0;
             // (a group of ONE leaf is true exactly when the leaf is present: no position is ever compared)
             if (traits && group_slots.size() > 1) traits->inord_slots.insert(traits->inord_slots.end(), group_slots.begin(), group_slots.end());
             group_slots.clear();
@@ -314,18 +321,19 @@ int check_program(const gft_engine* e, const uint32_t* w, uint64_t len, uint32_t
         default:
             return bad("unknown opcode");
         }
-        if (sp > kMaxBoolDepth) {
-            if (!traits)
-                return fail(e, GFT_E_UNSUPPORTED, "program " + std::to_string(idx) + ": operand stack deeper than " +
-                                                       std::to_string(kMaxBoolDepth));
-            traits->over_limit = true;
-        }
+        // (the depth of the PUBLIC postfix form binds only a caller without traits; gft_set_programs judges the depth of the
+        // fused form, which is what the device interprets: operands are reordered there, a chain nested to one side is flat)
+        if (sp > kMaxBoolDepth && !traits)
+            return fail(e, GFT_E_UNSUPPORTED, "program " + std::to_string(idx) + ": operand stack deeper than " +
+                                                   std::to_string(kMaxBoolDepth));
         uint32_t tot = 0;
         for (uint32_t c : pcnt) tot += c;
         psp = (uint32_t)pcnt.size();
+        g_tot = std::max(g_tot, tot); g_psp = std::max(g_psp, psp);
         if (tot > kMaxPairs || psp > kMaxPairDepth) {
             if (!traits) return fail(e, GFT_E_UNSUPPORTED, "program " + std::to_string(idx) + ": INORD group too wide for the device solver");
-            traits->over_limit = true;
+            // (more than a pair per lane: the device's scratch path up to kMaxPairsWide, the host beyond)
+            if (tot > kMaxPairsWide || psp > kMaxPairDepthWide) traits->over_limit = true;
         }
     }
     if (sp != 1 || !pcnt.empty()) return bad("program does not reduce to one value");
@@ -340,7 +348,7 @@ int check_program(const gft_engine* e, const uint32_t* w, uint64_t len, uint32_t
 // `gbase` = offset of this program inside the uploaded public word array.
 // public postfix words -> fused words (gft_kernels.hpp FusedOp); returns the deepest the accumulator stack gets
 uint32_t fuse_program(const uint32_t* w, uint64_t len, uint64_t gbase, std::vector<uint32_t>& out,
-                      std::vector<uint32_t>& groups) {
+                      std::vector<uint32_t>& groups, const std::vector<uint64_t>* wide_groups = nullptr) {
     // postfix -> tree (node = operator or leaf, with the range of public words it covers)
     struct Node { uint32_t op, slot; int64_t l, r; uint64_t s, e; };
     std::vector<Node> nodes;
@@ -416,7 +424,9 @@ uint32_t fuse_program(const uint32_t* w, uint64_t len, uint64_t gbase, std::vect
                 if (nodes[nd.l].op != GFT_OP_UNIT) {
                     out.push_back(kFopInord << 28 | (uint32_t)(groups.size() / 2));
                     groups.push_back((uint32_t)(gbase + nodes[nd.l].s));
-                    groups.push_back((uint32_t)(nodes[nd.l].e - nodes[nd.l].s + 1));
+                    // (the group's closing INORD word follows its subtree: wide groups are named by that word's index)
+                    const bool wide = wide_groups && std::binary_search(wide_groups->begin(), wide_groups->end(), nodes[nd.l].e + 1);
+                    groups.push_back((uint32_t)(nodes[nd.l].e - nodes[nd.l].s + 1) | (wide ? kGroupWide : 0u));
                 }
                 if (neg) out.push_back(kFopNot << 28);
             }
@@ -1023,6 +1033,16 @@ int solve_pipeline(gft_engine* e, uint64_t n_docs, const gft_extra_matches* d_ex
         HIP_TRY(e->d_pscratch.ensure((size_t)grid * S.n_slots * 8), "presence scratch alloc");
         S.p_scratch = e->d_pscratch.as<uint64_t>();
     }
+    S.wide_slot = nullptr; S.wide_theta = nullptr; S.wide_cap = 0;
+    if (e->wide_pairs) {
+        // (a region per wave of the grid; 12 bytes per pair: 8 192 pairs x 4 096 waves = 400 MB at the very most)
+        const uint64_t n_waves = (uint64_t)grid * (kSolveBlockThreads / 64);
+        S.wide_cap = (e->wide_pairs + 63u) & ~63u;
+        HIP_TRY(e->d_wide_slot.ensure(n_waves * S.wide_cap * 4), "INORD scratch alloc");
+        HIP_TRY(e->d_wide_theta.ensure(n_waves * S.wide_cap * 8), "INORD scratch alloc");
+        S.wide_slot = e->d_wide_slot.as<uint32_t>();
+        S.wide_theta = e->d_wide_theta.as<long long>();
+    }
     e->last_solve_group_docs = p_in_lds ? group_docs : 0;
     ProfScope ps(e, "solve");
     HIP_TRY(launch_solve(S, group_docs, p_in_lds, prog_in_lds, grid, e->stream), "solve kernel launch");
@@ -1308,7 +1328,7 @@ void gft_engine_destroy(gft_engine* e) {
         for (auto& kv : e->prof)
             for (auto& p : kv.second.ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
         DevBuf* all[] = {&e->d_byte_class, &e->d_delta, &e->d_out_term, &e->d_out_link, &e->d_term_len, &e->d_prog,
-                         &e->d_prog_off, &e->d_fprog, &e->d_fprog_off, &e->d_groups, &e->d_order, &e->d_blk_class, &e->d_wave_blk, &e->d_fprog_t, &e->d_fblk_off, &e->d_pscratch, &e->d_solve_dbg, &e->d_s2_filter,
+                         &e->d_prog_off, &e->d_fprog, &e->d_fprog_off, &e->d_groups, &e->d_wide_slot, &e->d_wide_theta, &e->d_order, &e->d_blk_class, &e->d_wave_blk, &e->d_fprog_t, &e->d_fblk_off, &e->d_pscratch, &e->d_solve_dbg, &e->d_s2_filter,
                          &e->d_s2_slots, &e->d_s2_more, &e->d_s2_cls, &e->d_s2_cls_fold, &e->d_s2_term_blob,
                          &e->d_s2_term_off, &e->d_ctl, &e->d_dbg, &e->d_s2_short3, &e->d_s2_shorts_packed, &e->d_s2_short3_big, &e->d_s2_fpt,
                          &e->d_s3_filter, &e->d_s3_short3, &e->d_s3_srec, &e->d_s3_short3_big, &e->d_s3_srec_big, &e->d_s3_bloom, &e->d_s3_slots,
@@ -1566,6 +1586,7 @@ int gft_build(gft_engine* e, const uint8_t* terms_blob, const uint64_t* term_off
 uint32_t gft_n_terms(const gft_engine* e) { return e ? (uint32_t)e->tab.terms.size() : 0; }
 uint32_t gft_n_states(const gft_engine* e) { return e ? e->tab.n_states : 0; }
 uint32_t gft_n_exprs(const gft_engine* e) { return e ? e->n_exprs : 0; }
+uint32_t gft_n_host_exprs(const gft_engine* e) { return e ? (uint32_t)e->host_only.size() : 0; }
 int gft_last_nonascii(const gft_engine* e) { return e && e->last_nonascii ? 1 : 0; }
 const char* gft_build_info(void) { return kExtraKernels ? "gfx950 extra_kernels=1" : "gfx950 extra_kernels=0"; }
 const char* gft_scan_kernel(const gft_engine* e) {
@@ -1861,7 +1882,17 @@ int gft_set_programs(gft_engine* e, const uint32_t* prog_words, const uint64_t* 
             const uint32_t stub = GFT_OP_UNIT << 28 | n_slots;
             fdepth.push_back(fuse_program(&stub, 1, 0, fw, groups));
         } else {
-            fdepth.push_back(fuse_program(prog_words + prog_off[i], prog_off[i + 1] - prog_off[i], prog_off[i], fw, groups));
+            const size_t fw0 = fw.size(), g0 = groups.size();
+            uint32_t depth = fuse_program(prog_words + prog_off[i], prog_off[i + 1] - prog_off[i], prog_off[i], fw, groups, &traits[i].wide_groups);
+            if (depth > kMaxBoolDepth) {
+                // the fused form still nests deeper than the interpreter's stack (a balanced tree of 2^128 sub-trees would):
+                // the host's
+                fw.resize(fw0); groups.resize(g0);
+                traits[i].over_limit = true;
+                const uint32_t stub = GFT_OP_UNIT << 28 | n_slots;
+                depth = fuse_program(&stub, 1, 0, fw, groups);
+            }
+            fdepth.push_back(depth);
         }
         while (fw.size() % 4) fw.push_back((uint32_t)kFopNop << 28);       // the interpreter reads 4-word chunks
         fo.push_back(fw.size());
@@ -1979,6 +2010,9 @@ int gft_set_programs(gft_engine* e, const uint32_t* prog_words, const uint64_t* 
             for (uint32_t sl : traits[i].inord_slots) e->inord_slot[sl] = 1;
         }
     }
+    e->wide_pairs = 0;
+    for (uint32_t i = 0; i < n_exprs; i++)
+        if (!traits[i].over_limit) e->wide_pairs = std::max(e->wide_pairs, traits[i].wide_pairs);
     e->traits.swap(traits);
     e->fprog_words = (uint32_t)fw.size();
     e->n_inord_groups = e->n_rare_words = 0;

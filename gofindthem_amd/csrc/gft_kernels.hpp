@@ -11,6 +11,11 @@ constexpr uint32_t kSolveBlockThreads = 1024;    // 16 waves: 64 documents x 16-
 constexpr uint32_t kMaxPairs = 64;               // (slot, theta) pairs alive inside one INORD group
 constexpr uint32_t kMaxPairDepth = 32;           // operand-stack depth inside one INORD group
 constexpr uint32_t kMaxBoolDepth = 128;          // operand-stack depth of a whole program
+// wider INORD groups keep their pairs in a per-wave scratch region in HBM (gft_solve.hip inord_group_wide): chunks of 64 pairs
+// go through the lanes.  Beyond these the expression is solved on the host (host_solve.hpp)
+constexpr uint32_t kMaxPairsWide = 8192;
+constexpr uint32_t kMaxPairDepthWide = 64;       // (a stack entry per lane)
+constexpr uint32_t kGroupWide = 0x80000000u;     // SolveParams::groups: top bit of a group's length word
 
 #define GFT_K_INORD_FLAG (1u << 27)
 #define GFT_K_SLOT_MASK ((1u << 27) - 1u)
@@ -127,6 +132,9 @@ struct SolveParams {
                                  // 8 phase clocks: cycles per phase and wave summed into dbg_out[wave * 8 + phase]
     unsigned long long* dbg_out;
     uint64_t* p_scratch;         // presence matrix in HBM when it does not fit LDS: [grid][n_slots]
+    uint32_t* wide_slot;         // pairs of wide INORD groups: [grid * waves][wide_cap] slots ...
+    long long* wide_theta;       // ... and thresholds (null: no program has a wide group)
+    uint32_t wide_cap;
     uint32_t* bitmap;
 };
 

@@ -37,7 +37,10 @@ namespace {
 #include "gft_scan2_dev.hpp"
 #include "gft_foldsafe_dev.hpp"
 
-constexpr int kWays5 = 2;           // stage A: candidates a lane works on at once
+#ifndef GFT_S5_WAYS
+#define GFT_S5_WAYS 2
+#endif
+constexpr int kWays5 = GFT_S5_WAYS;  // stage A: candidates a lane works on at once
 
 struct Ctx5 {
     uint32_t* fifo;              // LDS
@@ -363,15 +366,20 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
 #pragma unroll
                 for (int i = 0; i < 16; i++) g[i] = lgrp[(w[i >> 2] >> (8 * (i & 3))) & 0xFF];
             };
-            U128u pw = nxt, pn{0, 0, 0, 0};                     // words of piece q and of piece q + 1
-            if (npieces > 1 && 16 < nvalid) pn = *reinterpret_cast<const U128u*>(src + 16);
+            // (every load of the loop is UNCONDITIONAL -- a lane without such a piece reads the unit's first bytes instead and
+            // ignores them --: behind an exec-masked load the compiler cannot count, and waits for the youngest request too)
+            const uint8_t* safe = c.dbase + un.lo;
+            auto piece_load = [&](uint32_t at) {
+                const uint8_t* a = at < nvalid ? src + at : safe;
+                return *reinterpret_cast<const U128u*>(a);
+            };
+            U128u pw = nxt, pn = piece_load(16);                // words of piece q and of piece q + 1
             uint32_t ga[16], gb[16];
             if (ndw >= 4) lookups(pw, ga);
             auto piece = [&](uint32_t q, uint32_t (&g)[16], uint32_t (&gn)[16]) {
                 const uint32_t w[4] = {pw.x, pw.y, pw.z, pw.w};
                 if (q * 16 < nvalid) hib |= (w[0] | w[1]) | (w[2] | w[3]);   // (may take in up to 15 bytes behind the lane's range: conservative)
-                U128u pn2{0, 0, 0, 0};
-                if (q + 2 < npieces && (q + 2) * 16 < nvalid) pn2 = *reinterpret_cast<const U128u*>(src + (q + 2) * 16);
+                const U128u pn2 = piece_load((q + 2) * 16);
                 const uint32_t nd = ndw - 4 * q;                 // dwords of this piece that belong to the lane (>= 1)
                 if (nd >= 4) {
                     uint32_t xk[8];

@@ -195,6 +195,71 @@ __device__ bool inord_group_wave(const uint32_t* __restrict__ prog, uint32_t len
     return wave_succ_min(M, my_slot, my_theta, b, top - b) != INT64_MAX;
 }
 
+// The same algebra for a group of more than kMaxPairs pairs alive at once (or a pair stack deeper than kMaxPairDepth): the
+// pairs live in this wave's scratch region in HBM (ws / wt, SolveParams::wide_*) and pass through the lanes 64 at a time;
+// the operand stack -- the first pair of every range -- is one entry per lane (kMaxPairDepthWide).  A rare shape (an INORD
+// over an OR of dozens of terms): correctness and no host round trip matter here, not the last cycle; not inlined, so
+// that the register allocation of the common path stays what it is.  The scratch region is this wave's alone; its lanes
+// exchange pairs through it, so stores are made visible (workgroup scope: the CU's own L1) before other lanes load them.
+__device__ __attribute__((noinline)) bool inord_group_wide(const uint32_t* __restrict__ prog, uint32_t len, const DocHits* Mp,
+                                                            uint32_t* ws, long long* wt) {
+    const DocHits& M = *Mp;
+    const uint32_t lane = lane_id();
+    uint32_t st = 0;                                             // lane k: first pair of stack entry k
+    uint32_t sp = 0, top = 0;
+    auto visible = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    auto range_min = [&](uint32_t b, uint32_t e) {               // min over the pairs [b, e) of succ(slot, theta)
+        int64_t m = INT64_MAX;
+        for (uint32_t c0 = b; c0 < e; c0 += 64) {
+            const uint32_t n = e - c0 < 64u ? e - c0 : 64u;
+            const uint32_t sl = lane < n ? ws[c0 + lane] : kNoSlot;
+            const int64_t th = lane < n ? (int64_t)wt[c0 + lane] : -1;
+            const int64_t r = wave_succ_min(M, sl, th, 0, n);
+            m = r < m ? r : m;
+        }
+        return m;
+    };
+    for (uint32_t pc = 0; pc < len; pc++) {
+        const uint32_t w = __builtin_amdgcn_readfirstlane(prog[pc]);
+        const uint32_t op = w >> 28;
+        if (op == 1) {                                           // UNIT
+            if (lane == 0) { ws[top] = w & GFT_K_SLOT_MASK; wt[top] = -1; }
+            if (lane == sp) st = top;
+            sp++; top++;
+        } else if (op == 2) {                                    // AND
+            const uint32_t rb = __builtin_amdgcn_readlane(st, sp - 1), lb = __builtin_amdgcn_readlane(st, sp - 2);
+            const uint32_t rc = top - rb;
+            visible();
+            const int64_t m = range_min(lb, rb);
+            if (m == INT64_MAX) {
+                if (lane == 0) { ws[lb] = kNoSlot; wt[lb] = -1; }
+                top = lb + 1;
+            } else {
+                // R's pairs move down to lb, thresholds raised to m (ascending chunks: a chunk's target lies below every
+                // pair that is still to be read)
+                for (uint32_t c0 = 0; c0 < rc; c0 += 64) {
+                    const uint32_t i = c0 + lane;
+                    uint32_t sl = 0;
+                    int64_t th = 0;
+                    if (i < rc) { sl = ws[rb + i]; th = (int64_t)wt[rb + i]; }
+                    visible();                                   // (every lane has its pair before a lane overwrites one)
+                    if (i < rc) { ws[lb + i] = sl; wt[lb + i] = th < m ? m : th; }
+                }
+                top = lb + rc;
+            }
+            sp--;                                                // (entry sp - 1 keeps its start, lb)
+        } else if (op == 3) {                                    // OR: adjacent ranges, union == concatenation
+            sp--;
+        }
+    }
+    if (!top || !sp) return false;
+    visible();
+    return range_min(__builtin_amdgcn_readlane(st, sp - 1), top) != INT64_MAX;
+}
+
 // 64 x 64 bit-matrix transpose across a wave: lane i holds row i; afterwards lane j holds column j (bit i = old row
 // i's bit j).  Six exchange steps with the partner lane i ^ s, swapping the off-diagonal s x s blocks -- all in the
 // vector ALU (no LDS permutes, the LDS pipe is busy enough here):
@@ -274,7 +339,13 @@ __device__ __forceinline__ uint64_t inord_wave(const SolveParams& S, bool is_ino
                 const uint64_t x0 = S.x_off[d];
                 M.xslot = S.x_slot + x0; M.xpos = S.x_pos + x0; M.nx = (uint32_t)(S.x_off[d + 1] - x0);
             }
-            const bool r = inord_group_wave(S.gprog + goff, glen, M);
+            bool r;
+            if (__builtin_expect((glen & kGroupWide) != 0, 0)) {
+                const uint64_t wv = (uint64_t)blockIdx.x * (kSolveBlockThreads / 64) + (threadIdx.x >> 6);
+                r = S.wide_slot != nullptr && inord_group_wide(S.gprog + goff, glen & ~kGroupWide, &M, S.wide_slot + wv * S.wide_cap, S.wide_theta + wv * S.wide_cap);
+            } else {
+                r = inord_group_wave(S.gprog + goff, glen, M);
+            }
             if (r && lane == L) res |= 1ull << j;
         }
     }

@@ -26,6 +26,10 @@ bool host_solve(const uint32_t* words, uint64_t len, const SlotLists& m);
 // what gft_set_programs learns about one program besides its validity
 struct ProgramTraits {
     bool over_limit = false;                 // exceeds a limit of the device solver: always solved on the host
+    uint32_t wide_pairs = 0;                 // > 0: an INORD group of more than kMaxPairs (slot, theta) pairs alive at once (or a pair
+                                             // stack deeper than kMaxPairDepth) -- the device keeps such a group's pairs in a scratch
+                                             // region of this many pairs per wave instead of one pair per lane
+    std::vector<uint64_t> wide_groups;       // ... which groups: word index (inside the program) of their closing INORD word, ascending
     std::vector<uint32_t> inord_slots;       // slots read inside INORD groups of more than one leaf (sorted, unique):
                                              // documents in which one of them has a non-ascending list go to the host
 };

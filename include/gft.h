@@ -141,6 +141,10 @@ int gft_scan_device(gft_engine* e, const uint8_t* d_text_blob, const uint64_t* d
 int gft_set_programs(gft_engine* e, const uint32_t* prog_words, const uint64_t* prog_off, uint32_t n_exprs,
                      uint32_t n_extra);
 uint32_t gft_n_exprs(const gft_engine* e);
+/* how many of them the HOST solves for every document (host_solve: the reference's recursion, dsl/expression.go:66-142): the
+ * ones beyond the device solver's limits -- an INORD group of more than 8 192 (slot, threshold) pairs alive at once or a
+ * pair stack deeper than 64, a fused form that nests deeper than 128.  0 for any rule set a person would write. */
+uint32_t gft_n_host_exprs(const gft_engine* e);
 /* 1 when the last scan / process call on this engine ran with GFT_FOLD_ASCII over text for which lower-casing A-Z is
  * not provably the whole of strings.ToLower (finder/finder.go:140-142): it holds bytes >= 0x80 other than the two-byte
  * sequences C2 80..BF and C3 9F..BF / C3 97 (Latin-1 signs and LOWER-case letters) -- i.e. possibly an upper-case

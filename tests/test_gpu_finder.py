@@ -444,10 +444,12 @@ def test_foreign_engines_with_the_same_literal_share_one_list():
 
 
 def test_expressions_beyond_the_device_solver_limits_are_solved_on_the_host():
-    """The device solver holds at most 64 (slot, threshold) pairs per INORD group and 128 operand-stack entries; the
-    reference's recursion has no such limits (dsl/expression.go:66-142).  An expression beyond them no longer makes
-    gft_set_programs fail: it is solved on the host from the scan's matches while the other 1 000 expressions of the set
-    run on the device as before."""
+    """The device solver keeps an INORD group's (slot, threshold) pairs one per lane -- 64 --, a wider group's in a scratch
+    region per wave (up to 8 192 pairs: `wide`, round 4), and nests 128 operands deep in its FUSED form (`deep_right`, 200
+    operands waiting on the public postfix stack, is flat there); the reference's recursion has no limits at all
+    (dsl/expression.go:66-142).  What is still beyond the device (`huge`: an INORD over 2 x 4 500 OR-ed leaves) does not make
+    gft_set_programs fail: it is solved on the host from the scan's matches while the other expressions of the set run on
+    the device as before."""
     import torch
     from gofindthem_amd.workload import Workload, make_expressions
     w = Workload(2000)
@@ -458,9 +460,13 @@ def test_expressions_beyond_the_device_solver_limits_are_solved_on_the_host():
     deep_right = '"%s"' % terms[500]
     for i in range(200):                                 # nests to the right: 200 operands wait on the postfix stack
         deep_right = '("%s" %s %s)' % (terms[501 + i], "and" if i % 3 else "or", deep_right)
-    exprs = exprs[:400] + [wide] + exprs[400:900] + [deep_right, deep] + exprs[900:]
+    huge = "inord((%s) and (%s))" % (" or ".join('"%s"' % terms[i % 700] for i in range(4500)),
+                                     " or ".join('"%s"' % terms[700 + i % 700] for i in range(4500)))
+    exprs = exprs[:400] + [wide] + exprs[400:900] + [deep_right, deep] + exprs[900:] + [huge]
     f = Finder(GpuEngine(), EmptyRgxEngine(), False)
     f.AddExpressions(exprs)
+    f.ForceBuild()
+    assert _lib_load().gft_n_host_exprs(f.engine_handle()) == 1          # `huge` alone
     o = Oracle(sorted(f.GetKeywords()))
     o.set_expressions(exprs, False)
     text, off = w.docs_host(0, 300)

@@ -37,6 +37,9 @@ namespace {
 #include "gft_scan2_dev.hpp"
 #include "gft_foldsafe_dev.hpp"
 
+#ifndef GFT_S5_PREFETCH
+#define GFT_S5_PREFETCH 0
+#endif
 #ifndef GFT_S5_WAYS
 #define GFT_S5_WAYS 2
 #endif
@@ -309,7 +312,16 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
     Unit un_n{0, 0, 0};
     uint64_t abs_n = 0, end_n = 0;                               // the next unit's document: blob offsets of its first byte and of the byte behind it
     if (u < P.n_units) { un_n = P.units[u]; abs_n = P.doc_off[un_n.doc]; end_n = P.doc_off[un_n.doc + 1]; }
+    // GFT_S5_PREFETCH: the next unit's first bytes (a lane's first piece and the four bytes in front of it) are requested as the
+    // YOUNGEST loads of the unit before it -- behind the first stage-B trip's, in front of the short-term trips --, so that no
+    // later wait of that unit inherits their trip to HBM (vector-memory results return in order), and are in the registers
+    // when the next unit begins
+    bool pf_ok = false;                                           // wave-uniform: pf_* hold this unit's first bytes
+    U128u pf_nxt{0, 0, 0, 0};
+    uint32_t pf_hist = 0;
     for (; u < P.n_units; u = nu) {
+        const bool pf_have = GFT_S5_PREFETCH && pf_ok;
+        pf_ok = false;
         const Unit un{(uint32_t)__builtin_amdgcn_readfirstlane(un_n.doc), (uint32_t)__builtin_amdgcn_readfirstlane(un_n.lo),
                       (uint32_t)__builtin_amdgcn_readfirstlane(un_n.hi)};
         const uint64_t doc_abs = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(abs_n >> 32)) << 32 |
@@ -342,7 +354,15 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
             (void)h2;
             const uint8_t* src = c.dbase + my_lo;
             U128u nxt{0, 0, 0, 0};
-            if (nvalid) {
+            if (pf_have) {
+                nxt = pf_nxt;
+                if (nvalid) {
+                    const uint32_t hist = pf_hist;
+                    if (my_lo >= 1) h1 = lgrp[hist >> 24];
+                    if (my_lo >= 2) h2 = lgrp[(hist >> 16) & 0xFF];
+                    if (my_lo >= 3) h3 = lgrp[(hist >> 8) & 0xFF];
+                }
+            } else if (nvalid) {
                 uint32_t hist = 0;
                 if (doc_abs + my_lo >= 4) hist = load_u32_unaligned(src - 4);
                 else for (uint32_t i = 1; i <= 3 && i <= doc_abs + my_lo; i++) hist |= (uint32_t)src[-(int)i] << (32 - 8 * i);
@@ -637,6 +657,21 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
                     b_t8 = cand_load(c, b_k.p);
                     b_fr = front_load(c, b_k.p, 0);
                     b_tl = tail_load(c, b_k.p);
+                }
+                if (GFT_S5_PREFETCH && more_units && !pf_ok) {
+                    // (unconditional loads: a lane without bytes of its own reads the next unit's first ones -- the compiler counts
+                    // the requests in flight only behind loads that every lane issues)
+                    const uint32_t n_lo = __builtin_amdgcn_readfirstlane(un_n.lo), n_hi = __builtin_amdgcn_readfirstlane(un_n.hi);
+                    const uint64_t n_abs = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(abs_n >> 32)) << 32 |
+                                           (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)abs_n);
+                    if (n_hi > n_lo && n_abs + n_lo >= 4) {
+                        const uint32_t n_C = ((n_hi - n_lo + 63) / 64 + 3) & ~3u;
+                        const uint32_t n_my = n_lo + lane * n_C;
+                        const uint8_t* a = P.text + n_abs + (n_my < n_hi ? n_my : n_lo);
+                        pf_hist = load_u32_unaligned(a - 4);
+                        pf_nxt = *reinterpret_cast<const U128u*>(a);
+                        pf_ok = true;
+                    }
                 }
                 while (o.npend) { if (SG) short_trip_g(c, o, lsg, ubase, o.npend < 64 ? o.npend : 64); else short_trip(c, o, ubase, o.npend < 64 ? o.npend : 64); }
                 if (DBG && (P.dbg & 2)) { if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(KARG(dbg_counters) + 2), (unsigned long long)ns); }

@@ -222,8 +222,10 @@ __device__ __attribute__((noinline)) bool inord_group_wide(const uint32_t* __res
         }
         return m;
     };
+    uint32_t wl = 0;                                             // the group's words, 64 at a time, one per lane
     for (uint32_t pc = 0; pc < len; pc++) {
-        const uint32_t w = __builtin_amdgcn_readfirstlane(prog[pc]);
+        if ((pc & 63u) == 0) wl = pc + lane < len ? prog[pc + lane] : 0u;
+        const uint32_t w = __builtin_amdgcn_readlane(wl, pc & 63u);
         const uint32_t op = w >> 28;
         if (op == 1) {                                           // UNIT
             if (lane == 0) { ws[top] = w & GFT_K_SLOT_MASK; wt[top] = -1; }
@@ -258,6 +260,93 @@ __device__ __attribute__((noinline)) bool inord_group_wide(const uint32_t* __res
     if (!top || !sp) return false;
     visible();
     return range_min(__builtin_amdgcn_readlane(st, sp - 1), top) != INT64_MAX;
+}
+
+// A wide group in the lanes after all: of an OR over hundreds of terms a document holds a handful, and the presence matrix
+// says which.  The group's words pass through the lanes 128 at a time; every UNIT lane looks its slot up in the presence
+// matrix (Pw: LDS or HBM, element slot * G + j for document j of the group), an absent UNIT that an OR follows is dropped
+// together with that OR (X or {} == X), and what is left is interpreted as in inord_group_wave with one addition: ranges that
+// are the empty list (the dummy pair) are remembered (`empt`, by their first pair) and vanish in an OR, so the pairs alive
+// are the PRESENT leaves plus a dummy per empty operand.  Returns 0 / 1, or 2 when more than 64 pairs are alive after all
+// (a document that holds dozens of the group's terms): the caller then takes the scratch path above.
+__device__ __attribute__((noinline)) uint32_t inord_group_sparse(const uint32_t* __restrict__ prog, uint32_t len, const DocHits* Mp,
+                                                                  const uint32_t* Pw, uint32_t G, uint32_t j) {
+    const DocHits& M = *Mp;
+    const uint32_t lane = lane_id();
+    uint32_t my_slot = kNoSlot;
+    int64_t my_theta = -1;
+    uint64_t starts = 0, empt = 0;
+    uint32_t top = 0;
+    auto fetch = [&](uint32_t at) { return at + lane < len ? prog[at + lane] : 0u; };
+    uint32_t n0 = fetch(0), n1 = fetch(64);
+    for (uint32_t c0 = 0; c0 < len; c0 += 128) {
+        const uint32_t w2[2] = {n0, n1};
+        n0 = fetch(c0 + 128); n1 = fetch(c0 + 192);              // (the next round's words travel while this one is interpreted)
+        bool pres[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t bp = (w2[h] & GFT_K_SLOT_MASK) * G + j;
+            // (agent scope: a presence matrix in HBM was built by other waves' atomics; for the LDS one this is a plain read)
+            pres[h] = (w2[h] >> 28) == 1 && ((__hip_atomic_load(&Pw[bp >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> (bp & 31)) & 1u);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            if (c0 + 64 * h >= len) break;
+            const uint32_t wl = w2[h];
+            const uint64_t mU = __ballot((wl >> 28) == 1), mP = __ballot(pres[h]), mO = __ballot((wl >> 28) == 3);
+            uint64_t skip = (mU & ~mP) & (mO >> 1);              // an absent UNIT and the OR behind it
+            skip |= skip << 1;
+            uint64_t todo = ~skip & (len - (c0 + 64 * h) >= 64 ? ~0ull : (1ull << (len - (c0 + 64 * h))) - 1);
+            while (todo) {
+                const uint32_t i = (uint32_t)__builtin_ctzll(todo);
+                todo &= todo - 1;
+                const uint32_t w = __builtin_amdgcn_readlane(wl, i);
+                const uint32_t op = w >> 28;
+                if (op == 1) {                                   // UNIT
+                    if (top >= 64) return 2;
+                    const bool here = (mP >> i) & 1;
+                    if (lane == top) { my_slot = here ? (w & GFT_K_SLOT_MASK) : kNoSlot; my_theta = -1; }
+                    starts |= 1ull << top;
+                    if (!here) empt |= 1ull << top;
+                    top++;
+                } else if (op == 2 || op == 3) {
+                    const uint32_t rb = 63u - (uint32_t)__builtin_clzll(starts);
+                    const uint64_t rest = starts & ~(1ull << rb);
+                    const uint32_t lb = 63u - (uint32_t)__builtin_clzll(rest);
+                    const uint32_t lc = rb - lb, rc = top - rb;
+                    const bool le = (empt >> lb) & 1, re = (empt >> rb) & 1;
+                    empt &= ~((1ull << lb) | (1ull << rb));
+                    if (op == 3) {                               // OR: union == concatenation, empty operands vanish
+                        if (re) { top = rb; if (le) empt |= 1ull << lb; }
+                        else if (le) {                           // (the dummy at lb goes: R moves down by one)
+                            const uint32_t r_slot = __shfl(my_slot, (int)((lane + 1) & 63u), 64);
+                            const int64_t r_theta = __shfl(my_theta, (int)((lane + 1) & 63u), 64);
+                            if (lane >= lb && lane < lb + rc) { my_slot = r_slot; my_theta = r_theta; }
+                            top = lb + rc;
+                        }
+                    } else {                                     // AND
+                        int64_t m = INT64_MAX;
+                        if (!le && !re) m = wave_succ_min(M, my_slot, my_theta, lb, lc);
+                        const uint32_t r_slot = __shfl(my_slot, (int)((lane + lc) & 63u), 64);
+                        const int64_t r_theta = __shfl(my_theta, (int)((lane + lc) & 63u), 64);
+                        if (m == INT64_MAX) {
+                            if (lane == lb) { my_slot = kNoSlot; my_theta = -1; }
+                            top = lb + 1;
+                            empt |= 1ull << lb;
+                        } else {
+                            if (lane >= lb && lane < lb + rc) { my_slot = r_slot; my_theta = r_theta < m ? m : r_theta; }
+                            top = lb + rc;
+                        }
+                    }
+                    starts = rest;
+                }
+            }
+        }
+    }
+    if (!top) return 0;
+    const uint32_t b = 63u - (uint32_t)__builtin_clzll(starts);
+    if ((empt >> b) & 1) return 0;
+    return wave_succ_min(M, my_slot, my_theta, b, top - b) != INT64_MAX ? 1u : 0u;
 }
 
 // 64 x 64 bit-matrix transpose across a wave: lane i holds row i; afterwards lane j holds column j (bit i = old row
@@ -309,7 +398,8 @@ __device__ __forceinline__ uint64_t wave_transpose64(uint64_t x) {
 // group's boolean value is true, rval of expression.go:137).  The (lane, document) pairs are taken one after the other
 // and each is evaluated by the whole wave, so a large document's matches are scanned 64 wide and a wave with few
 // candidates does not leave 63 lanes idle.  Returns the documents whose position list is non-empty.
-__device__ __forceinline__ uint64_t inord_wave(const SolveParams& S, bool is_inord, uint32_t grp, uint64_t cand, uint64_t d0) {
+__device__ __forceinline__ uint64_t inord_wave(const SolveParams& S, bool is_inord, uint32_t grp, uint64_t cand, uint64_t d0,
+                                               const uint32_t* Pw = nullptr, uint32_t G = 0) {
     const uint32_t lane = lane_id();
     uint64_t res = 0;
     uint64_t todo = __ballot(is_inord && cand != 0);
@@ -342,7 +432,9 @@ __device__ __forceinline__ uint64_t inord_wave(const SolveParams& S, bool is_ino
             bool r;
             if (__builtin_expect((glen & kGroupWide) != 0, 0)) {
                 const uint64_t wv = (uint64_t)blockIdx.x * (kSolveBlockThreads / 64) + (threadIdx.x >> 6);
-                r = S.wide_slot != nullptr && inord_group_wide(S.gprog + goff, glen & ~kGroupWide, &M, S.wide_slot + wv * S.wide_cap, S.wide_theta + wv * S.wide_cap);
+                const uint32_t q = Pw ? inord_group_sparse(S.gprog + goff, glen & ~kGroupWide, &M, Pw, G, j) : 2u;
+                r = q == 1;
+                if (q == 2) r = S.wide_slot != nullptr && inord_group_wide(S.gprog + goff, glen & ~kGroupWide, &M, S.wide_slot + wv * S.wide_cap, S.wide_theta + wv * S.wide_cap);
             } else {
                 r = inord_group_wave(S.gprog + goff, glen, M);
             }
@@ -474,7 +566,8 @@ __device__ __forceinline__ AT run_program(const SolveParams& S, const PT* P, con
                 const bool rare = (int32_t)wq < 0, is_not = rare && (wq & kDwNeg), is_inord = rare && !(wq & kDwNeg);
                 if (is_not) acc = ~acc;
                 // candidates: documents where the group's boolean value is true (rval, expression.go:137)
-                const AT in = AT(inord_wave(S, is_inord, (wq & kDwFieldMask) >> kDwFieldShift, (uint64_t)(acc & valid), d0));
+                const AT in = AT(inord_wave(S, is_inord, (wq & kDwFieldMask) >> kDwFieldShift, (uint64_t)(acc & valid), d0,
+                                            reinterpret_cast<const uint32_t*>(P), (uint32_t)sizeof(PT) * 8u));
                 if (is_inord) acc = in;
             }
         };
@@ -574,7 +667,8 @@ __device__ __forceinline__ AT run_program_far(const SolveParams& S, const PT* P,
                 const bool rare = (int32_t)wq < 0, is_not = rare && (wq & kDwNeg), is_inord = rare && !(wq & kDwNeg);
                 if (is_not) acc = ~acc;
                 // candidates: documents where the group's boolean value is true (rval, expression.go:137)
-                const AT in = AT(inord_wave(S, is_inord, (wq & kDwFieldMask) >> kDwFieldShift, (uint64_t)(acc & valid), d0));
+                const AT in = AT(inord_wave(S, is_inord, (wq & kDwFieldMask) >> kDwFieldShift, (uint64_t)(acc & valid), d0,
+                                            reinterpret_cast<const uint32_t*>(P), (uint32_t)sizeof(PT) * 8u));
                 if (is_inord) acc = in;
             }
         };

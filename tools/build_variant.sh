@@ -6,6 +6,7 @@ set -e
 cd "$(dirname "$0")/.."
 NAME=$1; shift
 CS=gofindthem_amd/csrc
+python3 -m gofindthem_amd.build > /dev/null      # (the other objects: current)
 mkdir -p build/variants
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall "$@" -c $CS/gft_scan5.hip -o build/variants/gft_scan5_$NAME.o
 objs=$(ls $CS/*.o | grep -v gft_scan5.hip.o)

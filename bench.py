@@ -103,20 +103,36 @@ def main():
     words = (args.exprs + 31) // 32
     # two result buffers: the gather of batch i (the path's only exchange step, RCCL over xGMI) is in flight on the
     # process group's stream while batch i + 1 is scanned and solved; everything is complete before the closing fence
-    bitmaps = [torch.zeros((rows, words), dtype=torch.int32, device=dev) for _ in range(2 if world > 1 else 1)]
+    bitmaps = [torch.zeros((rows, words), dtype=torch.int32, device=dev) for _ in range(2)]
     bitmap = bitmaps[0]
     gather = BitmapGather(bitmaps)         # rank 0 receives every rank's bitmap
     text_bytes = int(text.numel())
     n_steps_done = [0]
 
+    # Two batches in flight (gft_process_device_begin / _end): batch i + 1 is enqueued before the host reads batch i's verdict
+    # (the one 56-byte read-back of a step) and starts its gather, so neither the read-back nor the launches leave the device
+    # idle -- a tenth of a step at 125 000 documents per GPU.  Every step's work is complete behind the closing fence.
+    begun = []                             # slots of the batches begun and not ended yet
+
+    def end_oldest():
+        slot = begun.pop(0)
+        finder.ProcessDeviceEnd()
+        gather.start(slot)
+
     def step():
         slot = n_steps_done[0] % len(bitmaps)
         n_steps_done[0] += 1
+        if slot in begun:                  # (one result buffer: the batch that owns it ends first)
+            end_oldest()
         gather.wait(slot)                  # the previous exchange out of this buffer has landed
-        finder.ProcessDevice(text.data_ptr(), doc_off.data_ptr(), args.docs, bitmaps[slot].data_ptr())
-        gather.start(slot)
+        finder.ProcessDeviceBegin(text.data_ptr(), doc_off.data_ptr(), args.docs, bitmaps[slot].data_ptr())
+        begun.append(slot)
+        while len(begun) > 1:
+            end_oldest()
 
     def fence():
+        while begun:
+            end_oldest()
         gather.drain()
         if world > 1:
             dist.barrier()
@@ -176,6 +192,7 @@ def main():
 
     # ---- same-run consistency that needs no oracle: the corpus generator's host and device forms agree on a sample,
     # and (N > 1) rank 0's slice of the gathered result is what it computed itself --------------------------------
+    bitmap = bitmaps[(n_steps_done[0] - 1) % len(bitmaps)]     # what the last step wrote
     S = min(args.parity_docs, args.docs)
     h_text, h_off = wl.docs_host(first, S)
     d_off = doc_off[:S + 1].cpu().numpy().astype(np.uint64)

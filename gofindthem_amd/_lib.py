@@ -57,6 +57,8 @@ SYMBOLS = {
     "gft_process": (_i, [_vp, _vp, _vp, _u64, _u32, C.POINTER(GftExtra), _vp]),
     "gft_process_again": (_i, [_vp, _u64, C.POINTER(GftExtra), _vp]),
     "gft_process_device": (_i, [_vp, _vp, _vp, _u64, _u32, C.POINTER(GftExtra), _vp]),
+    "gft_process_device_begin": (_i, [_vp, _vp, _vp, _u64, _u32, C.POINTER(GftExtra), _vp]),
+    "gft_process_device_end": (_i, [_vp]),
     "gft_finder_create": (_i, [C.POINTER(_vp), _i, _i]),
     "gft_finder_create_multi": (_i, [C.POINTER(_vp), _i, _vp, _i]),
     "gft_finder_destroy": (None, [_vp]),
@@ -75,6 +77,8 @@ SYMBOLS = {
     "gft_finder_process_texts": (_i, [_vp, _vp, _vp, _u64, _vp]),
     "gft_finder_last_regex_docs": (_u64, [_vp]),
     "gft_finder_process_device": (_i, [_vp, _vp, _vp, _u64, _vp]),
+    "gft_finder_process_device_begin": (_i, [_vp, _vp, _vp, _u64, _vp]),
+    "gft_finder_process_device_end": (_i, [_vp]),
     "gft_finder_debug_add_literal": (_i, [_vp, _i, C.c_char_p, _u32]),
     "gft_finder_debug_set_updated": (_i, [_vp, _i, _i]),
     "gft_finder_debug_get_updated": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),

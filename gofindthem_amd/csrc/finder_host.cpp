@@ -446,6 +446,44 @@ Error Finder::ProcessDevice(const uint8_t* d_blob, const uint64_t* d_doc_off, ui
     int rc = gft_process_device(gpu_->handle(), d_blob, d_doc_off, n_docs, caseSensitive_ ? 0 : GFT_FOLD_ASCII, nullptr,
                                 d_bitmap);
     if (rc) return fail_gft(rc);
+    return repeat_if_not_ascii(d_blob, d_doc_off, n_docs, d_bitmap);
+}
+
+Error Finder::ProcessDeviceBegin(const uint8_t* d_blob, const uint64_t* d_doc_off, uint64_t n_docs, uint32_t* d_bitmap) {
+    last_code_ = 0;
+    if (!gpu_sub_ || !regexes_.empty()) {
+        last_code_ = GFT_E_UNSUPPORTED;
+        return "device-resident processing needs the GPU substring engine and no regex terms";
+    }
+    if (n_begun_ == 2) { last_code_ = GFT_E_INVALID; return "two batches are in flight already"; }
+    std::vector<Record> none;
+    Error err = collect(std::string(), false, none);
+    if (!err.empty()) return err;
+    int rc = gft_process_device_begin(gpu_->handle(), d_blob, d_doc_off, n_docs, caseSensitive_ ? 0 : GFT_FOLD_ASCII, nullptr, d_bitmap);
+    if (rc) return fail_gft(rc);
+    begun_[(first_begun_ + n_begun_) % 2] = Begun{d_blob, d_doc_off, n_docs, d_bitmap};
+    n_begun_++;
+    return "";
+}
+
+Error Finder::ProcessDeviceEnd() {
+    last_code_ = 0;
+    if (!n_begun_) { last_code_ = GFT_E_INVALID; return "no batch in flight"; }
+    const Begun b = begun_[first_begun_];
+    first_begun_ = (first_begun_ + 1) % 2;
+    n_begun_--;
+    int rc = gft_process_device_end(gpu_->handle());
+    if (rc) return fail_gft(rc);
+    if (n_begun_ && !caseSensitive_ && b.n_docs && gft_last_nonascii(gpu_->handle())) {
+        // (the host repeat below uses the handle's synchronous entry points: the younger batch is completed first -- its
+        // verdict is kept for its own End)
+        last_code_ = GFT_E_UNSUPPORTED;
+        return "a batch that leaves ASCII cannot be repeated on the host while another batch is in flight: end that one first (or use ProcessDevice)";
+    }
+    return repeat_if_not_ascii(b.d_blob, b.d_doc_off, b.n_docs, b.d_bitmap);
+}
+
+Error Finder::repeat_if_not_ascii(const uint8_t* d_blob, const uint64_t* d_doc_off, uint64_t n_docs, uint32_t* d_bitmap) {
     if (!caseSensitive_ && n_docs && gft_last_nonascii(gpu_->handle())) {
         // The kernels lower-case A-Z only; the reference runs strings.ToLower (finder.go:140-142), which also maps
         // non-ASCII upper-case letters, rewrites invalid UTF-8 and may change byte lengths.  A batch that holds bytes
@@ -631,6 +669,19 @@ int gft_finder_process_device(gft_finder* f, const uint8_t* d_text_blob, const u
     if (!f) return GFT_E_INVALID;
     GFT_FLOCK(f);
     return finder_ret(f, f->finder->ProcessDevice(d_text_blob, d_doc_off, n_docs, d_hit_bitmap), GFT_E_ENGINE);
+} GFT_CATCH((f ? &const_cast<gft_finder*>(f)->err : nullptr))
+
+int gft_finder_process_device_begin(gft_finder* f, const uint8_t* d_text_blob, const uint64_t* d_doc_off, uint64_t n_docs,
+                                    uint32_t* d_hit_bitmap) try {
+    if (!f) return GFT_E_INVALID;
+    GFT_FLOCK(f);
+    return finder_ret(f, f->finder->ProcessDeviceBegin(d_text_blob, d_doc_off, n_docs, d_hit_bitmap), GFT_E_ENGINE);
+} GFT_CATCH((f ? &const_cast<gft_finder*>(f)->err : nullptr))
+
+int gft_finder_process_device_end(gft_finder* f) try {
+    if (!f) return GFT_E_INVALID;
+    GFT_FLOCK(f);
+    return finder_ret(f, f->finder->ProcessDeviceEnd(), GFT_E_ENGINE);
 } GFT_CATCH((f ? &const_cast<gft_finder*>(f)->err : nullptr))
 
 int gft_finder_debug_add_literal(gft_finder* f, int which, const uint8_t* lit, uint32_t len) try {

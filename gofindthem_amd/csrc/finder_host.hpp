@@ -108,6 +108,9 @@ public:
     // batch extension: bitmap[d * words + (i >> 5)] bit (i & 31); words = ceil(n_expressions / 32)
     Error ProcessTexts(const uint8_t* blob, const uint64_t* doc_off, uint64_t n_docs, uint32_t* bitmap);
     Error ProcessDevice(const uint8_t* d_blob, const uint64_t* d_doc_off, uint64_t n_docs, uint32_t* d_bitmap);
+    // pipelined: Begin enqueues (gft_process_device_begin), End completes the oldest batch begun, host ToLower repeat included
+    Error ProcessDeviceBegin(const uint8_t* d_blob, const uint64_t* d_doc_off, uint64_t n_docs, uint32_t* d_bitmap);
+    Error ProcessDeviceEnd();
     Error ForceBuild();
     const std::vector<std::string>& GetKeywords() const { return keywords_; }
     const std::vector<std::string>& GetRegexes() const { return regexes_; }
@@ -161,6 +164,10 @@ private:
     std::unordered_map<std::string, uint32_t> slot_of_;
     Error solve_error_;                  // what Expression.Solve would return for every document, if anything
     int last_code_ = 0;
+    struct Begun { const uint8_t* d_blob; const uint64_t* d_doc_off; uint64_t n_docs; uint32_t* d_bitmap; };
+    Begun begun_[2] = {};                // batches of ProcessDeviceBegin that ProcessDeviceEnd has not completed yet
+    unsigned first_begun_ = 0, n_begun_ = 0;
+    Error repeat_if_not_ascii(const uint8_t* d_blob, const uint64_t* d_doc_off, uint64_t n_docs, uint32_t* d_bitmap);
 };
 
 }  // namespace gft

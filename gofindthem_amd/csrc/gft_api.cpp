@@ -177,6 +177,17 @@ struct gft_engine {
     uint64_t last_static_slabs = 0;        // pool entries the waves of the last scan launch owned from the start (gft_scan2 / 3)
     bool deferred_single = false;          // ... and this one took that path
     uint64_t deferred_n_docs = 0;
+    // gft_process_device_begin / _end: up to two batches enqueued, their read-backs landing in pinned slots of their own
+    struct Pending {
+        bool done = false;                 // completed inside begin (a batch that could not be deferred): rc is its status
+        int rc = 0;
+        const uint8_t* d_text = nullptr; const uint64_t* d_doc_off = nullptr; uint64_t n_docs = 0; uint32_t flags = 0;
+        uint32_t* d_bitmap = nullptr;
+        bool single = false; uint64_t n_docs_cap = 0, unit_cap = 0, static_slabs = 0;     // deferred_check's view of the launch
+        uint64_t* rb = nullptr; hipEvent_t ev = nullptr;
+    };
+    Pending pend[2];
+    unsigned pend_head = 0, pend_count = 0;
     DevBuf d_order, d_blk_class, d_wave_blk;            // evaluation order of the programs (gft_set_programs)
     uint32_t last_solve_group_docs = 64;   // documents per solver group of the last launch (0 = presence matrix in HBM)
     DevBuf d_fprog_t, d_fblk_off;          // fused programs per sorted block of 64, transposed (read when they do not fit LDS)
@@ -872,6 +883,10 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
 // After the last kernel of a batch whose scan was launched blind (scan_pipeline, defer_ok): ONE read-back of the control
 // block -- the batch's only host synchronisation.  *again = the unit table or the match pool was too small (they have
 // been grown): the caller runs the batch once more, this time with the sizes known.
+// (what the launch of a deferred batch knew: the engine's fields at that time, or a pipelined batch's snapshot of them)
+struct DeferredLaunch { bool single; uint64_t n_docs, unit_cap, static_slabs; };
+int deferred_interpret(gft_engine* e, const uint64_t* rb, const DeferredLaunch& dl, bool* again);
+
 int deferred_check(gft_engine* e, bool* again) {
     *again = false;
     if (!e->deferred) return GFT_OK;
@@ -881,20 +896,25 @@ int deferred_check(gft_engine* e, bool* again) {
     uint64_t* rb = e->pin_rb;
     HIP_TRY(hipMemcpyAsync(rb, e->d_ctl.p, 7 * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream), "readback");
     HIP_TRY(hipStreamSynchronize(e->stream), "process pipeline");
-    const uint64_t cursor = rb[1] + e->last_static_slabs, total = rb[2], n_units = rb[4], text_lo = rb[5], text_hi = rb[6];
+    return deferred_interpret(e, rb, DeferredLaunch{e->deferred_single, e->deferred_n_docs, e->deferred_unit_cap, e->last_static_slabs}, again);
+}
+
+int deferred_interpret(gft_engine* e, const uint64_t* rb, const DeferredLaunch& dl, bool* again) {
+    *again = false;
+    const uint64_t cursor = rb[1] + dl.static_slabs, total = rb[2], n_units = rb[4], text_lo = rb[5], text_hi = rb[6];
     e->last_nonascii_bits = (uint32_t)rb[3]; e->last_nonascii = e->last_nonascii_bits != 0;
-    if (e->deferred_single && (uint32_t)(rb[3] >> 32)) {         // a document of more than one unit: the general path
+    if (dl.single && (uint32_t)(rb[3] >> 32)) {                  // a document of more than one unit: the general path
         e->single_streak = -8;
         *again = true;
         return GFT_OK;
     }
-    e->single_streak = n_units == e->deferred_n_docs ? e->single_streak + 1 : std::min(e->single_streak, 0);
+    e->single_streak = n_units == dl.n_docs ? e->single_streak + 1 : std::min(e->single_streak, 0);
     e->last_text_lo = text_lo; e->last_text_hi = text_hi;
     e->last_n_units = n_units; e->last_total = total;
     if (text_hi < text_lo) return fail(e, GFT_E_INVALID, "doc_off is not ascending");
     if ((uint32_t)rb[0]) return fail(e, GFT_E_INVALID, "doc_off is not ascending, or a document is longer than 4 GiB - 1 bytes (positions are 32-bit)");
     // (the DFA kernel's cursor counts matches, the suffix-window kernels' slabs: both must fit the pool)
-    if (n_units > e->deferred_unit_cap || cursor > e->pool_cap) {
+    if (n_units > dl.unit_cap || cursor > e->pool_cap) {
         if (cursor > e->pool_cap) { int rc = ensure_pool(e, cursor + cursor / 16); if (rc) return rc; }
         *again = true;
         return GFT_OK;
@@ -1343,6 +1363,8 @@ void gft_engine_destroy(gft_engine* e) {
             if (e->pin[k]) (void)hipHostFree(e->pin[k]);
             if (k == 0 && e->pin_rb) (void)hipHostFree(e->pin_rb);
             if (e->pin_ev[k]) (void)hipEventDestroy(e->pin_ev[k]);
+            if (e->pend[k].rb) (void)hipHostFree(e->pend[k].rb);
+            if (e->pend[k].ev) (void)hipEventDestroy(e->pend[k].ev);
         }
         if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     }
@@ -2031,6 +2053,7 @@ int gft_process_device(gft_engine* e, const uint8_t* d_text_blob, const uint64_t
     if (!e->built) return fail(e, GFT_E_NOT_BUILT, "gft_build has not been called");
     if (!e->have_programs) return fail(e, GFT_E_NOT_BUILT, "gft_set_programs has not been called");
     if (n_docs && e->n_exprs && !d_hit_bitmap) return fail(e, GFT_E_INVALID, "null bitmap");
+    if (e->pend_count) return fail(e, GFT_E_INVALID, "batches of gft_process_device_begin are in flight: gft_process_device_end first");
     DeviceGuard g(e->device);
     // what the host solves (normally nothing): expressions beyond the device solver's limits, and INORD expressions in
     // documents where the caller's matches make a slot's list non-ascending -- for that the caller's (device) arrays are
@@ -2078,6 +2101,98 @@ int gft_process_device(gft_engine* e, const uint8_t* d_text_blob, const uint64_t
     int rc = refine_nonascii(e, d_text_blob, d_doc_off, n_docs, flags);
     if (rc) return rc;
     return host_eval(e, want_hx ? &hx : nullptr, n_docs, plan, nullptr, d_hit_bitmap);
+} GFT_CATCH((e ? &e->err : nullptr))
+
+// ---- two batches in flight (at 125 000 documents -- one GPU's share of 1 M over 8 -- a step is 0.5 ms of
+// kernels, and the read-back of the control block plus the launches of the next step are a tenth of it) -----------------------
+int gft_process_device_begin(gft_engine* e, const uint8_t* d_text_blob, const uint64_t* d_doc_off, uint64_t n_docs,
+                             uint32_t flags, const gft_extra_matches* d_extra, uint32_t* d_hit_bitmap) try {
+    if (!e || (n_docs && (!d_text_blob || !d_doc_off))) return e ? fail(e, GFT_E_INVALID, "null argument") : GFT_E_INVALID;
+    GFT_LOCK(e);
+    if (!e->peers.empty()) return fail(e, GFT_E_UNSUPPORTED, "gft_process_device_begin: single-device handles only");
+    if (e->pend_count == 2) return fail(e, GFT_E_INVALID, "gft_process_device_begin: two batches are in flight already (gft_process_device_end first)");
+    const unsigned k = (e->pend_head + e->pend_count) % 2;
+    gft_engine::Pending& pb = e->pend[k];
+    pb.done = false; pb.rc = GFT_OK;
+    pb.d_text = d_text_blob; pb.d_doc_off = d_doc_off; pb.n_docs = n_docs; pb.flags = flags; pb.d_bitmap = d_hit_bitmap;
+    auto sync_path = [&]() {
+        // (whatever cannot be deferred -- caller-supplied matches, host-solved expressions, the first batches of an engine,
+        // an empty batch -- completes here; _end then only hands its status back.  Batches before it are finished first: the
+        // synchronous path reuses the control block they are still to read)
+        int rc = GFT_OK;
+        while (e->pend_count && rc == GFT_OK) {
+            // (statuses of the older batches stay theirs: they are completed, not consumed)
+            gft_engine::Pending& o = e->pend[e->pend_head];
+            if (!o.done) {
+                if (hipEventSynchronize(o.ev) != hipSuccess) { o.rc = fail(e, GFT_E_HIP, "event wait"); o.done = true; break; }
+                bool again = false;
+                o.rc = deferred_interpret(e, o.rb, DeferredLaunch{o.single, o.n_docs_cap, o.unit_cap, o.static_slabs}, &again);
+                if (!o.rc && again) { e->pend_count = 0; o.rc = gft_process_device(e, o.d_text, o.d_doc_off, o.n_docs, o.flags, nullptr, o.d_bitmap); e->pend_count = 1; }
+                else if (!o.rc) { DeviceGuard g2(e->device); o.rc = refine_nonascii(e, o.d_text, o.d_doc_off, o.n_docs, o.flags); }
+                o.done = true;
+            }
+            break;                                              // (at most one older batch: k is the second slot then)
+        }
+        const unsigned keep_head = e->pend_head, keep_count = e->pend_count;
+        e->pend_count = 0;                                      // (the synchronous entry point refuses to run beside batches in flight)
+        pb.rc = gft_process_device(e, d_text_blob, d_doc_off, n_docs, flags, d_extra, d_hit_bitmap);
+        e->pend_head = keep_head; e->pend_count = keep_count;
+        pb.done = true;
+    };
+    const bool simple = n_docs && e->device >= 0 && e->built && e->have_programs && !(d_extra && d_extra->off) && e->host_only.empty() &&
+                        (!e->n_exprs || d_hit_bitmap);
+    if (!simple) { sync_path(); e->pend_count++; return GFT_OK; }
+    DeviceGuard g(e->device);
+    uint64_t nm = 0;
+    int rc = scan_pipeline(e, d_text_blob, d_doc_off, n_docs, flags, false, &nm, nullptr, true);
+    if (rc) { pb.rc = rc; pb.done = true; e->pend_count++; return GFT_OK; }
+    const bool was_deferred = e->deferred;
+    rc = solve_pipeline(e, n_docs, nullptr, d_hit_bitmap);
+    if (rc || !was_deferred) {
+        // (sizes were not known yet: this batch ran with its own synchronisations, like gft_process_device's first pass)
+        if (!rc) { rc = hipStreamSynchronize(e->stream) == hipSuccess ? GFT_OK : fail(e, GFT_E_HIP, "process pipeline"); }
+        if (!rc) rc = refine_nonascii(e, d_text_blob, d_doc_off, n_docs, flags);
+        pb.rc = rc; pb.done = true; e->pend_count++;
+        return GFT_OK;
+    }
+    e->deferred = false;
+    if (!pb.rb) HIP_TRY(hipHostMalloc((void**)&pb.rb, 64, hipHostMallocDefault), "pinned alloc");
+    if (!pb.ev) HIP_TRY(hipEventCreateWithFlags(&pb.ev, hipEventDisableTiming), "event");
+    pb.single = e->deferred_single; pb.n_docs_cap = e->deferred_n_docs; pb.unit_cap = e->deferred_unit_cap; pb.static_slabs = e->last_static_slabs;
+    HIP_TRY(hipMemcpyAsync(pb.rb, e->d_ctl.p, 7 * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream), "readback");
+    HIP_TRY(hipEventRecord(pb.ev, e->stream), "event");
+    e->pend_count++;
+    return GFT_OK;
+} GFT_CATCH((e ? &e->err : nullptr))
+
+int gft_process_device_end(gft_engine* e) try {
+    if (!e) return GFT_E_INVALID;
+    GFT_LOCK(e);
+    if (!e->pend_count) return fail(e, GFT_E_INVALID, "gft_process_device_end: no batch in flight");
+    gft_engine::Pending& pb = e->pend[e->pend_head];
+    auto pop = [&]() { e->pend_head = (e->pend_head + 1) % 2; e->pend_count--; };
+    if (pb.done) { const int rc = pb.rc; pop(); return rc; }
+    DeviceGuard g(e->device);
+    if (hipEventSynchronize(pb.ev) != hipSuccess) { pop(); return fail(e, GFT_E_HIP, "event wait"); }
+    bool again = false;
+    int rc = deferred_interpret(e, pb.rb, DeferredLaunch{pb.single, pb.n_docs_cap, pb.unit_cap, pb.static_slabs}, &again);
+    if (!rc && again) {
+        // this batch outgrew the unit table or the match pool (both have been grown): once more, with its own synchronisations.
+        // A younger batch in flight is behind it on the stream; it keeps its own bitmap and its own verdict.
+        const unsigned keep_head = e->pend_head, keep_count = e->pend_count;
+        gft_engine::Pending* young = keep_count == 2 ? &e->pend[(keep_head + 1) % 2] : nullptr;
+        if (young && !young->done) {
+            // (its read-back must be taken before the control block is used again)
+            if (hipEventSynchronize(young->ev) != hipSuccess) { pop(); return fail(e, GFT_E_HIP, "event wait"); }
+        }
+        e->pend_count = 0;
+        rc = gft_process_device(e, pb.d_text, pb.d_doc_off, pb.n_docs, pb.flags, nullptr, pb.d_bitmap);
+        e->pend_head = keep_head; e->pend_count = keep_count;
+    } else if (!rc) {
+        rc = refine_nonascii(e, pb.d_text, pb.d_doc_off, pb.n_docs, pb.flags);
+    }
+    pop();
+    return rc;
 } GFT_CATCH((e ? &e->err : nullptr))
 
 namespace {

@@ -282,6 +282,14 @@ class Finder:
     def ProcessDevice(self, d_text_ptr, d_doc_off_ptr, n_docs, d_bitmap_ptr):
         self._check(self._L.gft_finder_process_device(self._h, d_text_ptr, d_doc_off_ptr, n_docs, d_bitmap_ptr))
 
+    def ProcessDeviceBegin(self, d_text_ptr, d_doc_off_ptr, n_docs, d_bitmap_ptr):
+        """pipelined ProcessDevice: enqueue the batch and return; ProcessDeviceEnd() completes the oldest batch begun (at
+        most two in flight; inputs and bitmap stay untouched until then)"""
+        self._check(self._L.gft_finder_process_device_begin(self._h, d_text_ptr, d_doc_off_ptr, n_docs, d_bitmap_ptr))
+
+    def ProcessDeviceEnd(self):
+        self._check(self._L.gft_finder_process_device_end(self._h))
+
     def engine_handle(self):
         return self._L.gft_finder_engine(self._h)
 

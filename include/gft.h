@@ -183,6 +183,17 @@ int gft_process_again(gft_engine* e, uint64_t n_docs, const gft_extra_matches* e
  * and more, and offsets that descend, are refused with GFT_E_INVALID. */
 int gft_process_device(gft_engine* e, const uint8_t* d_text_blob, const uint64_t* d_doc_off, uint64_t n_docs,
                        uint32_t flags, const gft_extra_matches* d_extra, uint32_t* d_hit_bitmap);
+/* The same, pipelined: _begin enqueues the batch (units -> scan -> solve -> the read-back of its control block) on the
+ * engine's stream and returns WITHOUT waiting; _end completes the oldest batch begun and returns ITS status (and sets
+ * gft_last_nonascii for it).  At most two batches are in flight, so a caller that begins batch i + 1 before it ends
+ * batch i keeps the device busy while the host reads batch i's verdict and launches the next one -- what a step of 0.5 ms
+ * (125 000 documents: one GPU's share of 1 M over 8) needs.  Inputs and the bitmap of a batch must stay untouched until its
+ * _end has returned: a batch that outgrew the engine's unit table or match pool is run again there.  A batch that cannot be
+ * deferred (caller-supplied matches, host-solved expressions, an engine's first batches) completes inside _begin; _end
+ * then only hands its status back.  Single-device handles; no other entry point of the handle between _begin and _end. */
+int gft_process_device_begin(gft_engine* e, const uint8_t* d_text_blob, const uint64_t* d_doc_off, uint64_t n_docs,
+                             uint32_t flags, const gft_extra_matches* d_extra, uint32_t* d_hit_bitmap);
+int gft_process_device_end(gft_engine* e);
 
 /* ---- finder.Finder mirror (finder/finder.go:32-240) ---------------------------------------------------------
  * Host-side orchestration with the reference's semantics: expression registry, keyword / regex sets, lazy engine
@@ -234,6 +245,10 @@ uint64_t gft_finder_last_regex_docs(const gft_finder* f);
 /* Same with the corpus resident in HBM (GPU substring engine, no regex terms). */
 int gft_finder_process_device(gft_finder* f, const uint8_t* d_text_blob, const uint64_t* d_doc_off, uint64_t n_docs,
                               uint32_t* d_hit_bitmap);
+/* ... pipelined (gft_process_device_begin / _end): _end also repeats a batch that left ASCII through the host's ToLower */
+int gft_finder_process_device_begin(gft_finder* f, const uint8_t* d_text_blob, const uint64_t* d_doc_off, uint64_t n_docs,
+                                    uint32_t* d_hit_bitmap);
+int gft_finder_process_device_end(gft_finder* f);
 /* test hooks mirroring what finder_test.go does by poking struct fields (finder/finder_test.go:205-217) */
 int gft_finder_debug_add_literal(gft_finder* f, int which, const uint8_t* lit, uint32_t len);
 int gft_finder_debug_set_updated(gft_finder* f, int updated_sub, int updated_rgx);

@@ -555,3 +555,57 @@ def test_large_host_batch_folds_on_the_device_and_comes_back_when_it_cannot():
     got = f.ProcessTexts(docs)
     assert np.array_equal(got, want)
     assert want[2999, 41 >> 5] >> (40 & 31) & 1 and want[17, 40 >> 5] >> (40 & 31) & 1   # "\u00e9cole" is found in both
+
+
+def test_process_device_begin_end_pipelines_two_batches():
+    """gft_finder_process_device_begin / _end: two batches in flight, each with its own bitmap; _end
+    completes the oldest and hands back ITS verdict.  Covered: steady state (deferred batches), an engine's first batches
+    (completed inside _begin), a batch that outgrows the match pool the earlier ones left behind (run again inside its _end
+    while a younger batch is in flight), the errors of calling out of order, and the synchronous entry point refusing to run
+    beside batches in flight."""
+    import torch
+    from gofindthem_amd.workload import Workload, make_expressions
+    L = _lib_load()
+    w = Workload(1000)
+    exprs = make_expressions(w.terms(), 200, inord_fraction=0.3, cover=True)
+    f = Finder(GpuEngine(), EmptyRgxEngine(), False)
+    f.AddExpressions(exprs)
+    o = Oracle(sorted(f.GetKeywords()))
+    o.set_expressions(exprs, False)
+    words = (len(exprs) + 31) // 32
+
+    def batch(first, n):
+        text, off = w.docs_host(first, n)
+        want = o.process(text, off, fold=True)
+        docs = [bytes(text[int(off[d]):int(off[d + 1])]).decode() for d in range(n)]
+        t, od = _device_batch(docs)
+        return t, od, n, torch.zeros((n, words), dtype=torch.int32, device="cuda"), want
+
+    small = [batch(100 * i, 100) for i in range(6)]
+    big = batch(1000, 3000)                       # thirty times the matches of the batches that sized the pool
+    with pytest.raises(FinderError):
+        f.ProcessDeviceEnd()                      # nothing in flight
+    seq = small[:4] + [big] + small[4:]
+    inflight = []
+    for b in seq:
+        f.ProcessDeviceBegin(b[0].data_ptr(), b[1].data_ptr(), b[2], b[3].data_ptr())
+        inflight.append(b)
+        if len(inflight) == 2:
+            with pytest.raises(FinderError):      # a third batch does not fit
+                f.ProcessDeviceBegin(b[0].data_ptr(), b[1].data_ptr(), b[2], b[3].data_ptr())
+            with pytest.raises(FinderError):      # ... and the synchronous form does not run beside them
+                f.ProcessDevice(b[0].data_ptr(), b[1].data_ptr(), b[2], b[3].data_ptr())
+            done = inflight.pop(0)
+            f.ProcessDeviceEnd()
+            assert np.array_equal(done[3].cpu().numpy().astype(np.uint32), done[4])
+    while inflight:
+        done = inflight.pop(0)
+        f.ProcessDeviceEnd()
+        assert np.array_equal(done[3].cpu().numpy().astype(np.uint32), done[4])
+    # the synchronous form works again once nothing is in flight
+    b = small[0]
+    b[3].zero_()
+    f.ProcessDevice(b[0].data_ptr(), b[1].data_ptr(), b[2], b[3].data_ptr())
+    assert np.array_equal(b[3].cpu().numpy().astype(np.uint32), b[4])
+    assert L.gft_last_nonascii(f.engine_handle()) == 0
+    f.close()

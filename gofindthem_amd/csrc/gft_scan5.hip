@@ -28,17 +28,14 @@
 
 namespace gft {
 
-#ifndef GFT_S5_PIPE
-#define GFT_S5_PIPE 0
-#endif
 
 namespace {
 
 #include "gft_scan2_dev.hpp"
 #include "gft_foldsafe_dev.hpp"
 
-#ifndef GFT_S5_PREFETCH
-#define GFT_S5_PREFETCH 0
+#ifndef GFT_S5_ROUNDS
+#define GFT_S5_ROUNDS 1
 #endif
 #ifndef GFT_S5_WAYS
 #define GFT_S5_WAYS 2
@@ -312,16 +309,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
     Unit un_n{0, 0, 0};
     uint64_t abs_n = 0, end_n = 0;                               // the next unit's document: blob offsets of its first byte and of the byte behind it
     if (u < P.n_units) { un_n = P.units[u]; abs_n = P.doc_off[un_n.doc]; end_n = P.doc_off[un_n.doc + 1]; }
-    // GFT_S5_PREFETCH: the next unit's first bytes (a lane's first piece and the four bytes in front of it) are requested as the
-    // YOUNGEST loads of the unit before it -- behind the first stage-B trip's, in front of the short-term trips --, so that no
-    // later wait of that unit inherits their trip to HBM (vector-memory results return in order), and are in the registers
-    // when the next unit begins
-    bool pf_ok = false;                                           // wave-uniform: pf_* hold this unit's first bytes
-    U128u pf_nxt{0, 0, 0, 0};
-    uint32_t pf_hist = 0;
     for (; u < P.n_units; u = nu) {
-        const bool pf_have = GFT_S5_PREFETCH && pf_ok;
-        pf_ok = false;
         const Unit un{(uint32_t)__builtin_amdgcn_readfirstlane(un_n.doc), (uint32_t)__builtin_amdgcn_readfirstlane(un_n.lo),
                       (uint32_t)__builtin_amdgcn_readfirstlane(un_n.hi)};
         const uint64_t doc_abs = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(abs_n >> 32)) << 32 |
@@ -340,12 +328,135 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
         const uint32_t nborder = un.lo < kScan2MaxOff ? un.lo : kScan2MaxOff;
         const uint32_t ubase = un.lo - kScan2MaxOff;               // candidate lists hold p - ubase (may wrap; p never does)
         const uint32_t own = un.hi - un.lo;
+#if !GFT_S5_ROUNDS
         const uint32_t C = ((own + 63) / 64 + 3) & ~3u;            // bytes per lane (multiple of 4, <= 128)
         const uint32_t my_lo = un.lo + lane * C;
         const uint32_t my_hi = my_lo + C < un.hi ? my_lo + C : un.hi;
         const uint32_t nvalid = my_lo < un.hi ? my_hi - my_lo : 0;
+#endif
         Ctx5 o{fifo, P.s5_fifo_cap, 0, 0, false, false, 0, P.s5_term_bits, un.lo - P.s5_pos_bias};
 
+#if GFT_S5_ROUNDS
+        // ---- FILTER: coalesced rounds ------------------------------------------------------------------------------------
+        // Round r is the unit's bytes [1024 r, 1024 r + 1024): lane k filters the piece [1024 r + 16 k, + 16), so one load
+        // instruction of the wave reads 1 KiB of consecutive text -- eight 128-byte lines, each requested once.  (Until round 4
+        // a lane owned one contiguous stretch of the unit: every 16-byte load of the wave then touched 32 lines, every line was
+        // requested by four different instructions, and with sixteen waves' 4 KB each going through a 32 KB L1 most of those
+        // came from L2 again: 267 L1 -> L2 requests per 4 KB document, the L1's pending-request queue full half of the time.)
+        // The three bytes in front of a piece are the lane before's last ones: its last dword comes over by DPP (wave_shr:1),
+        // lane 0 takes the last dword of lane 63 of the round before (`carry`; the four bytes in front of the unit at first).
+        // The last, partial round of `tail` bytes gives every lane tnd = ceil(tail / 256) dwords: lane k owns
+        // [1024 n_full + 4 tnd k, + 4 tnd).  Flags: round r fills bits [16 (r & 1), + 16) of mask word r >> 1.
+        const uint32_t n_full = own >> 10, tail = own & 1023u;
+        const uint32_t tnd = (tail + 255u) >> 8;                   // dwords a lane owns in the partial round (0: there is none)
+        const uint32_t n_rounds = n_full + (tail ? 1u : 0u);        // <= 8
+        const uint32_t tstride = tnd * 4;
+        uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+        if (own) {
+            const uint8_t* ub = c.dbase + un.lo;                    // the unit's first byte
+            uint32_t carry = 0;
+            if (doc_abs + un.lo >= 4) carry = load_u32_unaligned(ub - 4);
+            else for (uint32_t i = 1; i <= 3 && i <= doc_abs + un.lo; i++) carry |= (uint32_t)ub[-(int)i] << (32 - 8 * i);
+            // (every lane loads in every round -- a lane without bytes in the partial round reads the round's first ones and
+            // ignores them: behind an exec-masked load the compiler cannot count the requests in flight)
+            auto round_src = [&](uint32_t r) -> const uint8_t* {
+                if (r < n_full) return ub + r * 1024u + lane * 16u;
+                const uint32_t at = lane * tstride;
+                return ub + n_full * 1024u + (at < tail ? at : 0u);
+            };
+            U128u nxt = *reinterpret_cast<const U128u*>(round_src(0));
+            mark(0);
+            uint32_t acc = 0, nbits = 0, njobs = 0, hib = 0;         // hib: OR of the lane's text (a byte >= 0x80 anywhere?)
+            const bool want_fold = P.fold && P.nonascii;
+            const uint32_t pad_g = P.s5_pad_g;
+            for (uint32_t r = 0; r < n_rounds; r++) {
+                const uint32_t w[4] = {nxt.x, nxt.y, nxt.z, nxt.w};
+                const bool whole = r < n_full || tnd == 4;          // wave-uniform: sixteen bytes per lane
+                const uint32_t here = r < n_full ? 16u : (lane * tstride < tail ? (tail - lane * tstride < tstride ? tail - lane * tstride : tstride) : 0u);
+                hib |= here ? (w[0] | w[1]) | (w[2] | w[3]) : 0u;   // (may take in a few bytes behind the unit: conservative)
+                if (r + 1 < n_rounds) nxt = *reinterpret_cast<const U128u*>(round_src(r + 1));
+                const uint32_t last = whole ? w[3] : tnd == 1 ? w[0] : tnd == 2 ? w[1] : w[2];
+                const uint32_t hist = (uint32_t)__builtin_amdgcn_update_dpp((int)carry, (int)last, 0x138, 0xF, 0xF, false);   // wave_shr:1
+                carry = __builtin_amdgcn_readlane(last, 63);
+                uint32_t h1 = lgrp[hist >> 24], h2 = lgrp[(hist >> 16) & 0xFF], h3 = lgrp[(hist >> 8) & 0xFF];   // g[j-1], g[j-2], g[j-3]
+                if (r == 0 && un.lo < 3 && lane == 0) {             // in front of the document: the pad group
+                    if (un.lo < 1) h1 = pad_g;
+                    if (un.lo < 2) h2 = pad_g;
+                    h3 = pad_g;
+                }
+                uint32_t pq = mad24s(h2, G, h1);
+                // probe at byte 0 of a dword: 3-gram (h2, h1, c0); the window that ends there has h3 in front, the window that
+                // ends at byte 1 has c1 behind.  Probe at byte 2: 3-gram (c0, c1, c2), h1 in front, c3 behind
+                auto dword = [&](uint32_t wd) {
+                    const uint32_t c0 = lgrp[wd & 0xFF], c1 = lgrp[(wd >> 8) & 0xFF], c2 = lgrp[(wd >> 16) & 0xFF], c3 = lgrp[wd >> 24];
+                    const uint32_t xa = mad24s(pq, G, c0);
+                    const uint32_t xb = mad24s(mad24s(c0, G, c1), G, c2);
+                    const u32x2 fa = ldual[xa], fb = ldual[xb];
+                    acc = __builtin_amdgcn_alignbit(fa.x >> h3, acc, 1);
+                    acc = __builtin_amdgcn_alignbit(fa.y >> c1, acc, 1);
+                    acc = __builtin_amdgcn_alignbit(fb.x >> h1, acc, 1);
+                    acc = __builtin_amdgcn_alignbit(fb.y >> c3, acc, 1);
+                    pq = mad24s(c2, G, c3);
+                    h3 = c1; h2 = c2; h1 = c3;
+                };
+                if (whole) {                                     // sixteen lookups, then eight probes in flight together
+                    uint32_t cc[19];                             // cc[3 + i] = group of byte i; cc[0..2] = h3, h2, h1
+                    cc[0] = h3; cc[1] = h2; cc[2] = h1;
+#pragma unroll
+                    for (int i = 0; i < 16; i++) cc[3 + i] = lgrp[(w[i >> 2] >> (8 * (i & 3))) & 0xFF];
+                    uint32_t xk[8];
+                    xk[0] = mad24s(pq, G, cc[3]);
+#pragma unroll
+                    for (int t = 1; t < 8; t++) xk[t] = mad24s(mad24s(cc[1 + 2 * t], G, cc[2 + 2 * t]), G, cc[3 + 2 * t]);
+                    u32x2 fk[8];
+#pragma unroll
+                    for (int t = 0; t < 8; t++) fk[t] = ldual[xk[t]];
+#pragma unroll
+                    for (int t = 0; t < 8; t++) {
+                        acc = __builtin_amdgcn_alignbit(fk[t].x >> cc[2 * t], acc, 1);         // window ends at byte 2t: cc[2t] stands in front
+                        acc = __builtin_amdgcn_alignbit(fk[t].y >> cc[4 + 2 * t], acc, 1);     // ... at byte 2t + 1: that byte's group behind
+                    }
+                    nbits += 16;
+                } else {
+                    dword(w[0]);
+                    if (tnd >= 2) dword(w[1]);
+                    if (tnd >= 3) dword(w[2]);
+                    nbits += tstride;
+                }
+                if (nbits == 32) {
+                    if ((r >> 1) == 0) m0 = acc; else if ((r >> 1) == 1) m1 = acc; else if ((r >> 1) == 2) m2 = acc; else m3 = acc;
+                    nbits = 0;
+                }
+            }
+            if (nbits) {                                         // the last, partial group of positions
+                const uint32_t v = acc >> (32 - nbits), k = (n_rounds - 1) >> 1;
+                if (k == 0) m0 = v; else if (k == 1) m1 = v; else if (k == 2) m2 = v; else m3 = v;
+            }
+            if (tail) {                                          // positions behind the unit carry garbage flags
+                const uint32_t at = lane * tstride, nv = at < tail ? (tail - at < 16u ? tail - at : 16u) : 0u;
+                const uint32_t sh = (n_full & 1u) * 16u, keep = ~(0xFFFFu << sh) | (((1u << nv) - 1u) << sh), k = n_full >> 1;
+                if (k == 0) m0 &= keep; else if (k == 1) m1 &= keep; else if (k == 2) m2 &= keep; else m3 &= keep;
+            }
+            // ASCII folding is not strings.ToLower once the text leaves ASCII (finder.go:140-142): the pieces of the lanes that
+            // met a byte >= 0x80 are judged now (gft_foldsafe_dev.hpp; which of a lane's pieces it was is not kept -- text that
+            // leaves ASCII is the exception for the dictionaries this kernel serves, the filter loop pays two ORs for it)
+            if (want_fold && !told_nonascii && __any((hib & 0x80808080u) != 0)) {
+                for (uint32_t r = 0; r < n_rounds; r++) {
+                    const uint32_t at = r < n_full ? r * 1024u + lane * 16u : n_full * 1024u + lane * tstride;
+                    fold_job_push((hib & 0x80808080u) != 0 && at < own, at, cand, P.cand_cap, njobs);
+                }
+            }
+            if (njobs && !told_nonascii) {
+                // bit 1: a piece breaks the rule; bit 0: more pieces than the list holds -- the host then checks the text itself
+                uint32_t bits = 1u;
+                if (njobs <= P.cand_cap) {
+                    FOLD_JOB_VARS(fj_);
+                    bits = fold_jobs_begin(P.text, end_v, doc_abs + un.lo, own, un.lo == 0, cand, njobs, FOLD_JOB_PASS(fj_)) || fold_jobs_finish(FOLD_JOB_PASS(fj_)) ? 2u : 0u;
+                }
+                if (bits) { told_nonascii = true; if (lane == 0) atomicOr(P.nonascii, bits); }
+            }
+        }
+#else
         // ---- FILTER -----------------------------------------------------------------------------------------------------
         uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
         if (own) {
@@ -354,15 +465,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
             (void)h2;
             const uint8_t* src = c.dbase + my_lo;
             U128u nxt{0, 0, 0, 0};
-            if (pf_have) {
-                nxt = pf_nxt;
-                if (nvalid) {
-                    const uint32_t hist = pf_hist;
-                    if (my_lo >= 1) h1 = lgrp[hist >> 24];
-                    if (my_lo >= 2) h2 = lgrp[(hist >> 16) & 0xFF];
-                    if (my_lo >= 3) h3 = lgrp[(hist >> 8) & 0xFF];
-                }
-            } else if (nvalid) {
+            if (nvalid) {
                 uint32_t hist = 0;
                 if (doc_abs + my_lo >= 4) hist = load_u32_unaligned(src - 4);
                 else for (uint32_t i = 1; i <= 3 && i <= doc_abs + my_lo; i++) hist |= (uint32_t)src[-(int)i] << (32 - 8 * i);
@@ -377,80 +480,6 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
             const bool want_fold = P.fold && P.nonascii;
             const uint32_t ndw = C >> 2;                         // dwords per lane (wave-uniform, <= 32)
             const uint32_t npieces = (ndw + 3) >> 2;
-#if GFT_S5_PIPE
-            // Whole pieces are software-pipelined: the sixteen group lookups of piece q + 1 are issued between the probes of
-            // piece q and the flag shifts that consume them, so a piece costs ONE LDS round trip instead of two (lookups ->
-            // keys -> probes -> flags in a row).  Two register sets for the groups (ga / gb), the loop body twice.
-            auto lookups = [&](const U128u& pw, uint32_t (&g)[16]) {
-                const uint32_t w[4] = {pw.x, pw.y, pw.z, pw.w};
-#pragma unroll
-                for (int i = 0; i < 16; i++) g[i] = lgrp[(w[i >> 2] >> (8 * (i & 3))) & 0xFF];
-            };
-            // (every load of the loop is UNCONDITIONAL -- a lane without such a piece reads the unit's first bytes instead and
-            // ignores them --: behind an exec-masked load the compiler cannot count, and waits for the youngest request too)
-            const uint8_t* safe = c.dbase + un.lo;
-            auto piece_load = [&](uint32_t at) {
-                const uint8_t* a = at < nvalid ? src + at : safe;
-                return *reinterpret_cast<const U128u*>(a);
-            };
-            U128u pw = nxt, pn = piece_load(16);                // words of piece q and of piece q + 1
-            uint32_t ga[16], gb[16];
-            if (ndw >= 4) lookups(pw, ga);
-            auto piece = [&](uint32_t q, uint32_t (&g)[16], uint32_t (&gn)[16]) {
-                const uint32_t w[4] = {pw.x, pw.y, pw.z, pw.w};
-                if (q * 16 < nvalid) hib |= (w[0] | w[1]) | (w[2] | w[3]);   // (may take in up to 15 bytes behind the lane's range: conservative)
-                const U128u pn2 = piece_load((q + 2) * 16);
-                const uint32_t nd = ndw - 4 * q;                 // dwords of this piece that belong to the lane (>= 1)
-                if (nd >= 4) {
-                    uint32_t xk[8];
-                    xk[0] = mad24s(pq, G, g[0]);
-                    // probe t >= 1 sits at byte 2t: the 3-gram of the bytes 2t - 2 .. 2t
-#pragma unroll
-                    for (int t = 1; t < 8; t++) xk[t] = mad24s(mad24s(g[2 * t - 2], G, g[2 * t - 1]), G, g[2 * t]);
-                    u32x2 fk[8];
-#pragma unroll
-                    for (int t = 0; t < 8; t++) fk[t] = ldual[xk[t]];
-                    const bool nfull = q + 1 < npieces && ndw - 4 * (q + 1) >= 4;      // wave-uniform
-                    if (nfull) lookups(pn, gn);
-                    // flags: window ends at byte 2t: cc[2t] stands in front; at byte 2t + 1: cc[4 + 2t] behind
-                    acc = __builtin_amdgcn_alignbit(fk[0].x >> h3, acc, 1);
-                    acc = __builtin_amdgcn_alignbit(fk[0].y >> g[1], acc, 1);
-                    acc = __builtin_amdgcn_alignbit(fk[1].x >> h1, acc, 1);
-                    acc = __builtin_amdgcn_alignbit(fk[1].y >> g[3], acc, 1);
-#pragma unroll
-                    for (int t = 2; t < 8; t++) {
-                        acc = __builtin_amdgcn_alignbit(fk[t].x >> g[2 * t - 3], acc, 1);
-                        acc = __builtin_amdgcn_alignbit(fk[t].y >> g[2 * t + 1], acc, 1);
-                    }
-                    pq = mad24s(g[14], G, g[15]);
-                    h3 = g[13]; h2 = g[14]; h1 = g[15];
-                } else {
-                    auto dword = [&](uint32_t wd) {
-                        const uint32_t c0 = lgrp[wd & 0xFF], c1 = lgrp[(wd >> 8) & 0xFF], c2 = lgrp[(wd >> 16) & 0xFF], c3 = lgrp[wd >> 24];
-                        const uint32_t xa = mad24s(pq, G, c0);
-                        const uint32_t xb = mad24s(mad24s(c0, G, c1), G, c2);
-                        const u32x2 fa = ldual[xa], fb = ldual[xb];
-                        acc = __builtin_amdgcn_alignbit(fa.x >> h3, acc, 1);
-                        acc = __builtin_amdgcn_alignbit(fa.y >> c1, acc, 1);
-                        acc = __builtin_amdgcn_alignbit(fb.x >> h1, acc, 1);
-                        acc = __builtin_amdgcn_alignbit(fb.y >> c3, acc, 1);
-                        pq = mad24s(c2, G, c3);
-                        h3 = c1; h2 = c2; h1 = c3;
-                    };
-                    dword(w[0]);
-                    if (nd >= 2) dword(w[1]);
-                    if (nd >= 3) dword(w[2]);
-                }
-                if ((q & 1) && nd >= 4) {                        // 32 positions complete
-                    if ((q >> 1) == 0) m0 = acc; else if ((q >> 1) == 1) m1 = acc; else if ((q >> 1) == 2) m2 = acc; else m3 = acc;
-                }
-                pw = pn; pn = pn2;
-            };
-            for (uint32_t q = 0; q < npieces; q += 2) {
-                piece(q, ga, gb);
-                if (q + 1 < npieces) piece(q + 1, gb, ga);
-            }
-#else
             for (uint32_t q = 0; q < npieces; q++) {
                 const uint32_t w[4] = {nxt.x, nxt.y, nxt.z, nxt.w};
                 if (q * 16 < nvalid) hib |= (w[0] | w[1]) | (w[2] | w[3]);   // (may take in up to 15 bytes behind the lane's range: conservative)
@@ -498,7 +527,6 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
                     if ((q >> 1) == 0) m0 = acc; else if ((q >> 1) == 1) m1 = acc; else if ((q >> 1) == 2) m2 = acc; else m3 = acc;
                 }
             }
-#endif
             if (ndw & 7) {                                       // the last, partial group of 32 positions
                 const uint32_t v = acc >> (32 - 4 * (ndw & 7));
                 const uint32_t k = ndw >> 3;
@@ -528,6 +556,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
             m2 = nvalid >= 96 ? m2 : (nvalid > 64 ? m2 & ((1u << (nvalid - 64)) - 1) : 0);
             m3 = nvalid >= 128 ? m3 : (nvalid > 96 ? m3 & ((1u << (nvalid - 96)) - 1) : 0);
         }
+#endif
         mark(1);
         if (more_units) { abs_n = P.doc_off[un_n.doc]; end_n = P.doc_off[un_n.doc + 1]; }
 
@@ -555,10 +584,26 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
                 const uint32_t ptotal = lane_value(fincl, l1 - 1) - before;
                 if (lane >= l0 && lane < l1) {
                     uint32_t wpos = fincl - f - before;
-                    const uint32_t rel = lane * C + kScan2MaxOff;
                     if (lane == 0)
                         for (uint32_t i = 0; i < nborder; i++) cand[wpos++] = (uint16_t)(kScan2MaxOff - nborder + i);
                     uint32_t mm[4] = {m0, m1, m2, m3};
+#if GFT_S5_ROUNDS
+                    // (bits [16 (r & 1), + 16) of word r >> 1 are round r's: positions 1024 r + 16 lane + bit, in the partial
+                    // round 1024 n_full + 4 tnd lane + bit)
+#pragma unroll
+                    for (int r = 0; r < 8; r++) {
+                        if ((uint32_t)r < n_rounds) {
+                            uint32_t mk = (r & 1) ? mm[r >> 1] >> 16 : mm[r >> 1] & 0xFFFFu;
+                            const uint32_t rel = kScan2MaxOff + ((uint32_t)r < n_full ? (uint32_t)r * 1024u + lane * 16u : n_full * 1024u + lane * tstride);
+                            while (mk) {
+                                const uint32_t i = __builtin_ctz(mk);
+                                mk &= mk - 1;
+                                cand[wpos++] = (uint16_t)(rel + i);
+                            }
+                        }
+                    }
+#else
+                    const uint32_t rel = lane * C + kScan2MaxOff;
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         uint32_t mk = mm[k];
@@ -568,6 +613,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
                             cand[wpos++] = (uint16_t)(rel + 32 * k + i);
                         }
                     }
+#endif
                 }
                 wave_lds_sync();
                 // stage A: every flagged position -> LDS-only decisions; short terms are emitted here, positions that may end a
@@ -657,21 +703,6 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
                     b_t8 = cand_load(c, b_k.p);
                     b_fr = front_load(c, b_k.p, 0);
                     b_tl = tail_load(c, b_k.p);
-                }
-                if (GFT_S5_PREFETCH && more_units && !pf_ok) {
-                    // (unconditional loads: a lane without bytes of its own reads the next unit's first ones -- the compiler counts
-                    // the requests in flight only behind loads that every lane issues)
-                    const uint32_t n_lo = __builtin_amdgcn_readfirstlane(un_n.lo), n_hi = __builtin_amdgcn_readfirstlane(un_n.hi);
-                    const uint64_t n_abs = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(abs_n >> 32)) << 32 |
-                                           (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)abs_n);
-                    if (n_hi > n_lo && n_abs + n_lo >= 4) {
-                        const uint32_t n_C = ((n_hi - n_lo + 63) / 64 + 3) & ~3u;
-                        const uint32_t n_my = n_lo + lane * n_C;
-                        const uint8_t* a = P.text + n_abs + (n_my < n_hi ? n_my : n_lo);
-                        pf_hist = load_u32_unaligned(a - 4);
-                        pf_nxt = *reinterpret_cast<const U128u*>(a);
-                        pf_ok = true;
-                    }
                 }
                 while (o.npend) { if (SG) short_trip_g(c, o, lsg, ubase, o.npend < 64 ? o.npend : 64); else short_trip(c, o, ubase, o.npend < 64 ? o.npend : 64); }
                 if (DBG && (P.dbg & 2)) { if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(KARG(dbg_counters) + 2), (unsigned long long)ns); }

@@ -1044,7 +1044,8 @@ int solve_pipeline(gft_engine* e, uint64_t n_docs, const gft_extra_matches* d_ex
         if (solve_lds_bytes(S.n_slots, S.tile_words, G, true, 0, 0, false) + 1024 <= e->lds_max) { group_docs = G; p_in_lds = true; break; }
     }
     // ... and the fused programs too, if there is room left (the interpreter fetches them word after word)
-    const bool prog_in_lds = solve_lds_bytes(S.n_slots, S.tile_words, group_docs, p_in_lds, S.fprog_words, S.n_exprs, true) + 1024 <= e->lds_max;
+    // (a set with a wide INORD group runs the kernel variant that reads its programs from L2: launch_g)
+    const bool prog_in_lds = !e->wide_pairs && solve_lds_bytes(S.n_slots, S.tile_words, group_docs, p_in_lds, S.fprog_words, S.n_exprs, true) + 1024 <= e->lds_max;
     const uint64_t n_groups = (n_docs + group_docs - 1) / group_docs;
     const size_t lds_need = solve_lds_bytes(S.n_slots, S.tile_words, group_docs, p_in_lds, S.fprog_words, S.n_exprs, prog_in_lds) + 512;
     const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, e->lds_max / lds_need));

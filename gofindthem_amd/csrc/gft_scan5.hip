@@ -34,8 +34,11 @@ namespace {
 #include "gft_scan2_dev.hpp"
 #include "gft_foldsafe_dev.hpp"
 
-#ifndef GFT_S5_ROUNDS
-#define GFT_S5_ROUNDS 1
+#ifndef GFT_S5_TEXT2
+#define GFT_S5_TEXT2 1
+#endif
+#ifndef GFT_S5_LIST2
+#define GFT_S5_LIST2 1
 #endif
 #ifndef GFT_S5_WAYS
 #define GFT_S5_WAYS 2
@@ -328,135 +331,12 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
         const uint32_t nborder = un.lo < kScan2MaxOff ? un.lo : kScan2MaxOff;
         const uint32_t ubase = un.lo - kScan2MaxOff;               // candidate lists hold p - ubase (may wrap; p never does)
         const uint32_t own = un.hi - un.lo;
-#if !GFT_S5_ROUNDS
         const uint32_t C = ((own + 63) / 64 + 3) & ~3u;            // bytes per lane (multiple of 4, <= 128)
         const uint32_t my_lo = un.lo + lane * C;
         const uint32_t my_hi = my_lo + C < un.hi ? my_lo + C : un.hi;
         const uint32_t nvalid = my_lo < un.hi ? my_hi - my_lo : 0;
-#endif
         Ctx5 o{fifo, P.s5_fifo_cap, 0, 0, false, false, 0, P.s5_term_bits, un.lo - P.s5_pos_bias};
 
-#if GFT_S5_ROUNDS
-        // ---- FILTER: coalesced rounds ------------------------------------------------------------------------------------
-        // Round r is the unit's bytes [1024 r, 1024 r + 1024): lane k filters the piece [1024 r + 16 k, + 16), so one load
-        // instruction of the wave reads 1 KiB of consecutive text -- eight 128-byte lines, each requested once.  (Until round 4
-        // a lane owned one contiguous stretch of the unit: every 16-byte load of the wave then touched 32 lines, every line was
-        // requested by four different instructions, and with sixteen waves' 4 KB each going through a 32 KB L1 most of those
-        // came from L2 again: 267 L1 -> L2 requests per 4 KB document, the L1's pending-request queue full half of the time.)
-        // The three bytes in front of a piece are the lane before's last ones: its last dword comes over by DPP (wave_shr:1),
-        // lane 0 takes the last dword of lane 63 of the round before (`carry`; the four bytes in front of the unit at first).
-        // The last, partial round of `tail` bytes gives every lane tnd = ceil(tail / 256) dwords: lane k owns
-        // [1024 n_full + 4 tnd k, + 4 tnd).  Flags: round r fills bits [16 (r & 1), + 16) of mask word r >> 1.
-        const uint32_t n_full = own >> 10, tail = own & 1023u;
-        const uint32_t tnd = (tail + 255u) >> 8;                   // dwords a lane owns in the partial round (0: there is none)
-        const uint32_t n_rounds = n_full + (tail ? 1u : 0u);        // <= 8
-        const uint32_t tstride = tnd * 4;
-        uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
-        if (own) {
-            const uint8_t* ub = c.dbase + un.lo;                    // the unit's first byte
-            uint32_t carry = 0;
-            if (doc_abs + un.lo >= 4) carry = load_u32_unaligned(ub - 4);
-            else for (uint32_t i = 1; i <= 3 && i <= doc_abs + un.lo; i++) carry |= (uint32_t)ub[-(int)i] << (32 - 8 * i);
-            // (every lane loads in every round -- a lane without bytes in the partial round reads the round's first ones and
-            // ignores them: behind an exec-masked load the compiler cannot count the requests in flight)
-            auto round_src = [&](uint32_t r) -> const uint8_t* {
-                if (r < n_full) return ub + r * 1024u + lane * 16u;
-                const uint32_t at = lane * tstride;
-                return ub + n_full * 1024u + (at < tail ? at : 0u);
-            };
-            U128u nxt = *reinterpret_cast<const U128u*>(round_src(0));
-            mark(0);
-            uint32_t acc = 0, nbits = 0, njobs = 0, hib = 0;         // hib: OR of the lane's text (a byte >= 0x80 anywhere?)
-            const bool want_fold = P.fold && P.nonascii;
-            const uint32_t pad_g = P.s5_pad_g;
-            for (uint32_t r = 0; r < n_rounds; r++) {
-                const uint32_t w[4] = {nxt.x, nxt.y, nxt.z, nxt.w};
-                const bool whole = r < n_full || tnd == 4;          // wave-uniform: sixteen bytes per lane
-                const uint32_t here = r < n_full ? 16u : (lane * tstride < tail ? (tail - lane * tstride < tstride ? tail - lane * tstride : tstride) : 0u);
-                hib |= here ? (w[0] | w[1]) | (w[2] | w[3]) : 0u;   // (may take in a few bytes behind the unit: conservative)
-                if (r + 1 < n_rounds) nxt = *reinterpret_cast<const U128u*>(round_src(r + 1));
-                const uint32_t last = whole ? w[3] : tnd == 1 ? w[0] : tnd == 2 ? w[1] : w[2];
-                const uint32_t hist = (uint32_t)__builtin_amdgcn_update_dpp((int)carry, (int)last, 0x138, 0xF, 0xF, false);   // wave_shr:1
-                carry = __builtin_amdgcn_readlane(last, 63);
-                uint32_t h1 = lgrp[hist >> 24], h2 = lgrp[(hist >> 16) & 0xFF], h3 = lgrp[(hist >> 8) & 0xFF];   // g[j-1], g[j-2], g[j-3]
-                if (r == 0 && un.lo < 3 && lane == 0) {             // in front of the document: the pad group
-                    if (un.lo < 1) h1 = pad_g;
-                    if (un.lo < 2) h2 = pad_g;
-                    h3 = pad_g;
-                }
-                uint32_t pq = mad24s(h2, G, h1);
-                // probe at byte 0 of a dword: 3-gram (h2, h1, c0); the window that ends there has h3 in front, the window that
-                // ends at byte 1 has c1 behind.  Probe at byte 2: 3-gram (c0, c1, c2), h1 in front, c3 behind
-                auto dword = [&](uint32_t wd) {
-                    const uint32_t c0 = lgrp[wd & 0xFF], c1 = lgrp[(wd >> 8) & 0xFF], c2 = lgrp[(wd >> 16) & 0xFF], c3 = lgrp[wd >> 24];
-                    const uint32_t xa = mad24s(pq, G, c0);
-                    const uint32_t xb = mad24s(mad24s(c0, G, c1), G, c2);
-                    const u32x2 fa = ldual[xa], fb = ldual[xb];
-                    acc = __builtin_amdgcn_alignbit(fa.x >> h3, acc, 1);
-                    acc = __builtin_amdgcn_alignbit(fa.y >> c1, acc, 1);
-                    acc = __builtin_amdgcn_alignbit(fb.x >> h1, acc, 1);
-                    acc = __builtin_amdgcn_alignbit(fb.y >> c3, acc, 1);
-                    pq = mad24s(c2, G, c3);
-                    h3 = c1; h2 = c2; h1 = c3;
-                };
-                if (whole) {                                     // sixteen lookups, then eight probes in flight together
-                    uint32_t cc[19];                             // cc[3 + i] = group of byte i; cc[0..2] = h3, h2, h1
-                    cc[0] = h3; cc[1] = h2; cc[2] = h1;
-#pragma unroll
-                    for (int i = 0; i < 16; i++) cc[3 + i] = lgrp[(w[i >> 2] >> (8 * (i & 3))) & 0xFF];
-                    uint32_t xk[8];
-                    xk[0] = mad24s(pq, G, cc[3]);
-#pragma unroll
-                    for (int t = 1; t < 8; t++) xk[t] = mad24s(mad24s(cc[1 + 2 * t], G, cc[2 + 2 * t]), G, cc[3 + 2 * t]);
-                    u32x2 fk[8];
-#pragma unroll
-                    for (int t = 0; t < 8; t++) fk[t] = ldual[xk[t]];
-#pragma unroll
-                    for (int t = 0; t < 8; t++) {
-                        acc = __builtin_amdgcn_alignbit(fk[t].x >> cc[2 * t], acc, 1);         // window ends at byte 2t: cc[2t] stands in front
-                        acc = __builtin_amdgcn_alignbit(fk[t].y >> cc[4 + 2 * t], acc, 1);     // ... at byte 2t + 1: that byte's group behind
-                    }
-                    nbits += 16;
-                } else {
-                    dword(w[0]);
-                    if (tnd >= 2) dword(w[1]);
-                    if (tnd >= 3) dword(w[2]);
-                    nbits += tstride;
-                }
-                if (nbits == 32) {
-                    if ((r >> 1) == 0) m0 = acc; else if ((r >> 1) == 1) m1 = acc; else if ((r >> 1) == 2) m2 = acc; else m3 = acc;
-                    nbits = 0;
-                }
-            }
-            if (nbits) {                                         // the last, partial group of positions
-                const uint32_t v = acc >> (32 - nbits), k = (n_rounds - 1) >> 1;
-                if (k == 0) m0 = v; else if (k == 1) m1 = v; else if (k == 2) m2 = v; else m3 = v;
-            }
-            if (tail) {                                          // positions behind the unit carry garbage flags
-                const uint32_t at = lane * tstride, nv = at < tail ? (tail - at < 16u ? tail - at : 16u) : 0u;
-                const uint32_t sh = (n_full & 1u) * 16u, keep = ~(0xFFFFu << sh) | (((1u << nv) - 1u) << sh), k = n_full >> 1;
-                if (k == 0) m0 &= keep; else if (k == 1) m1 &= keep; else if (k == 2) m2 &= keep; else m3 &= keep;
-            }
-            // ASCII folding is not strings.ToLower once the text leaves ASCII (finder.go:140-142): the pieces of the lanes that
-            // met a byte >= 0x80 are judged now (gft_foldsafe_dev.hpp; which of a lane's pieces it was is not kept -- text that
-            // leaves ASCII is the exception for the dictionaries this kernel serves, the filter loop pays two ORs for it)
-            if (want_fold && !told_nonascii && __any((hib & 0x80808080u) != 0)) {
-                for (uint32_t r = 0; r < n_rounds; r++) {
-                    const uint32_t at = r < n_full ? r * 1024u + lane * 16u : n_full * 1024u + lane * tstride;
-                    fold_job_push((hib & 0x80808080u) != 0 && at < own, at, cand, P.cand_cap, njobs);
-                }
-            }
-            if (njobs && !told_nonascii) {
-                // bit 1: a piece breaks the rule; bit 0: more pieces than the list holds -- the host then checks the text itself
-                uint32_t bits = 1u;
-                if (njobs <= P.cand_cap) {
-                    FOLD_JOB_VARS(fj_);
-                    bits = fold_jobs_begin(P.text, end_v, doc_abs + un.lo, own, un.lo == 0, cand, njobs, FOLD_JOB_PASS(fj_)) || fold_jobs_finish(FOLD_JOB_PASS(fj_)) ? 2u : 0u;
-                }
-                if (bits) { told_nonascii = true; if (lane == 0) atomicOr(P.nonascii, bits); }
-            }
-        }
-#else
         // ---- FILTER -----------------------------------------------------------------------------------------------------
         uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
         if (own) {
@@ -556,7 +436,6 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
             m2 = nvalid >= 96 ? m2 : (nvalid > 64 ? m2 & ((1u << (nvalid - 64)) - 1) : 0);
             m3 = nvalid >= 128 ? m3 : (nvalid > 96 ? m3 & ((1u << (nvalid - 96)) - 1) : 0);
         }
-#endif
         mark(1);
         if (more_units) { abs_n = P.doc_off[un_n.doc]; end_n = P.doc_off[un_n.doc + 1]; }
 
@@ -587,23 +466,21 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
                     if (lane == 0)
                         for (uint32_t i = 0; i < nborder; i++) cand[wpos++] = (uint16_t)(kScan2MaxOff - nborder + i);
                     uint32_t mm[4] = {m0, m1, m2, m3};
-#if GFT_S5_ROUNDS
-                    // (bits [16 (r & 1), + 16) of word r >> 1 are round r's: positions 1024 r + 16 lane + bit, in the partial
-                    // round 1024 n_full + 4 tnd lane + bit)
+                    const uint32_t rel = lane * C + kScan2MaxOff;
+#if GFT_S5_LIST2
+                    // two mask words side by side: their ctz chains are independent, the trip count is the larger of the two
+                    // popcounts over the lanes instead of their sum
 #pragma unroll
-                    for (int r = 0; r < 8; r++) {
-                        if ((uint32_t)r < n_rounds) {
-                            uint32_t mk = (r & 1) ? mm[r >> 1] >> 16 : mm[r >> 1] & 0xFFFFu;
-                            const uint32_t rel = kScan2MaxOff + ((uint32_t)r < n_full ? (uint32_t)r * 1024u + lane * 16u : n_full * 1024u + lane * tstride);
-                            while (mk) {
-                                const uint32_t i = __builtin_ctz(mk);
-                                mk &= mk - 1;
-                                cand[wpos++] = (uint16_t)(rel + i);
-                            }
+                    for (int k = 0; k < 4; k += 2) {
+                        uint32_t ma = mm[k], mb = mm[k + 1];
+                        uint32_t wa = wpos, wb = wpos + __popc(ma);
+                        wpos = wb + __popc(mb);
+                        while (ma | mb) {
+                            if (ma) { const uint32_t i = __builtin_ctz(ma); ma &= ma - 1; cand[wa++] = (uint16_t)(rel + 32 * k + i); }
+                            if (mb) { const uint32_t i = __builtin_ctz(mb); mb &= mb - 1; cand[wb++] = (uint16_t)(rel + 32 * (k + 1) + i); }
                         }
                     }
 #else
-                    const uint32_t rel = lane * C + kScan2MaxOff;
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         uint32_t mk = mm[k];
@@ -700,9 +577,20 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
                     b_k.x = survx[b_on ? lane : 0];
                     b_s0 = slot_load(&P.slots[scan2_slot_hash(b_k.x, 0, P.slot_shift, P.slot_seed)]);
                     b_s1 = slot_load(&P.slots[scan2_slot_hash(b_k.x, 1, P.slot_shift, P.slot_seed)]);
-                    b_t8 = cand_load(c, b_k.p);
-                    b_fr = front_load(c, b_k.p, 0);
-                    b_tl = tail_load(c, b_k.p);
+                    if (GFT_S5_TEXT2 && !c.near24 && !c.near_end) {
+                        // the 32 bytes around the position as two 16-byte loads -- text[p-23 .. p-8] and text[p-7 .. p+8] -- instead
+                        // of three (window + front 8, front 16, tail 4): one request less per survivor into an L1 whose
+                        // pending-request queue is full half of the time
+                        const U128u v1 = *reinterpret_cast<const U128u*>(c.dbase + (int64_t)b_k.p - 23);
+                        const U128u v2 = *reinterpret_cast<const U128u*>(c.dbase + (int64_t)b_k.p - 7);
+                        b_fr.f[4] = v1.x; b_fr.f[3] = v1.y; b_fr.f[2] = v1.z; b_fr.f[1] = v1.w;
+                        b_t8.tw = v2.x; b_t8.w = v2.y;
+                        b_tl = v2.z;
+                    } else {
+                        b_t8 = cand_load(c, b_k.p);
+                        b_fr = front_load(c, b_k.p, 0);
+                        b_tl = tail_load(c, b_k.p);
+                    }
                 }
                 while (o.npend) { if (SG) short_trip_g(c, o, lsg, ubase, o.npend < 64 ? o.npend : 64); else short_trip(c, o, ubase, o.npend < 64 ? o.npend : 64); }
                 if (DBG && (P.dbg & 2)) { if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(KARG(dbg_counters) + 2), (unsigned long long)ns); }

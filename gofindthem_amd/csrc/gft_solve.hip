@@ -269,7 +269,7 @@ __device__ __attribute__((noinline)) bool inord_group_wide(const uint32_t* __res
 // are the empty list (the dummy pair) are remembered (`empt`, by their first pair) and vanish in an OR, so the pairs alive
 // are the PRESENT leaves plus a dummy per empty operand.  Returns 0 / 1, or 2 when more than 64 pairs are alive after all
 // (a document that holds dozens of the group's terms): the caller then takes the scratch path above.
-__device__ __attribute__((noinline)) uint32_t inord_group_sparse(const uint32_t* __restrict__ prog, uint32_t len, const DocHits* Mp,
+__device__ __forceinline__ uint32_t inord_group_sparse(const uint32_t* __restrict__ prog, uint32_t len, const DocHits* Mp,
                                                                   const uint32_t* Pw, uint32_t G, uint32_t j) {
     const DocHits& M = *Mp;
     const uint32_t lane = lane_id();
@@ -398,6 +398,9 @@ __device__ __forceinline__ uint64_t wave_transpose64(uint64_t x) {
 // group's boolean value is true, rval of expression.go:137).  The (lane, document) pairs are taken one after the other
 // and each is evaluated by the whole wave, so a large document's matches are scanned 64 wide and a wave with few
 // candidates does not leave 63 lanes idle.  Returns the documents whose position list is non-empty.
+// WIDE: the kernel variant of program sets that hold a wide group (inord_group_sparse / inord_group_wide are real calls: a
+// kernel that contains them keeps registers free around the call sites, which the common variant cannot afford)
+template <bool WIDE>
 __device__ __forceinline__ uint64_t inord_wave(const SolveParams& S, bool is_inord, uint32_t grp, uint64_t cand, uint64_t d0,
                                                const uint32_t* Pw = nullptr, uint32_t G = 0) {
     const uint32_t lane = lane_id();
@@ -430,13 +433,13 @@ __device__ __forceinline__ uint64_t inord_wave(const SolveParams& S, bool is_ino
                 M.xslot = S.x_slot + x0; M.xpos = S.x_pos + x0; M.nx = (uint32_t)(S.x_off[d + 1] - x0);
             }
             bool r;
-            if (__builtin_expect((glen & kGroupWide) != 0, 0)) {
+            if (WIDE && (glen & kGroupWide) != 0) {
                 const uint64_t wv = (uint64_t)blockIdx.x * (kSolveBlockThreads / 64) + (threadIdx.x >> 6);
                 const uint32_t q = Pw ? inord_group_sparse(S.gprog + goff, glen & ~kGroupWide, &M, Pw, G, j) : 2u;
                 r = q == 1;
                 if (q == 2) r = S.wide_slot != nullptr && inord_group_wide(S.gprog + goff, glen & ~kGroupWide, &M, S.wide_slot + wv * S.wide_cap, S.wide_theta + wv * S.wide_cap);
             } else {
-                r = inord_group_wave(S.gprog + goff, glen, M);
+                r = inord_group_wave(S.gprog + goff, glen & ~kGroupWide, M);
             }
             if (r && lane == L) res |= 1ull << j;
         }
@@ -496,7 +499,7 @@ constexpr uint32_t bit_index(uint32_t m) { return m <= 1 ? 0 : 1 + bit_index(m >
 // to scratch beyond (a wave-uniform slow path, like the NOT / INORD words).
 // ALL 64 lanes of a wave call this together (lanes without a program pass chunks = 0): the trip count is the wave's
 // maximum, finished lanes run no-op words, so the INORD steps can use the whole wave.
-template <bool P_LDS, uint32_t R, bool RARE, class PT, class AT>
+template <bool P_LDS, uint32_t R, int RARE, class PT, class AT>
 __device__ __forceinline__ AT run_program(const SolveParams& S, const PT* P, const uint4* prog, uint32_t stride, uint32_t chunks,
                                           AT valid, uint64_t d0) {
     static_assert(R == 0 || R == kSolveRegStack || R == kSolveRegStackDeep, "three interpreters");
@@ -566,8 +569,8 @@ __device__ __forceinline__ AT run_program(const SolveParams& S, const PT* P, con
                 const bool rare = (int32_t)wq < 0, is_not = rare && (wq & kDwNeg), is_inord = rare && !(wq & kDwNeg);
                 if (is_not) acc = ~acc;
                 // candidates: documents where the group's boolean value is true (rval, expression.go:137)
-                const AT in = AT(inord_wave(S, is_inord, (wq & kDwFieldMask) >> kDwFieldShift, (uint64_t)(acc & valid), d0,
-                                            reinterpret_cast<const uint32_t*>(P), (uint32_t)sizeof(PT) * 8u));
+                const AT in = AT(inord_wave<RARE == 2>(S, is_inord, (wq & kDwFieldMask) >> kDwFieldShift, (uint64_t)(acc & valid), d0,
+                                                       reinterpret_cast<const uint32_t*>(P), (uint32_t)sizeof(PT) * 8u));
                 if (is_inord) acc = in;
             }
         };
@@ -599,7 +602,7 @@ __device__ __forceinline__ AT run_program(const SolveParams& S, const PT* P, con
 // is instruction issue: ~34 vector instructions per program word at 8 documents per group; leaving a block of INORD
 // conjunctions as soon as no document is left in any accumulator removes 45 % of that work and not a microsecond -- the
 // group waits for its longest program, 59 trips that one wave issues alone.)
-template <bool P_LDS, uint32_t R, bool RARE, class PT, class AT>
+template <bool P_LDS, uint32_t R, int RARE, class PT, class AT>
 __device__ __forceinline__ AT run_program_far(const SolveParams& S, const PT* P, const uint4* prog, uint32_t stride, uint32_t chunks,
                                               AT valid, uint64_t d0) {
     static_assert(R == 0 || R == kSolveRegStack || R == kSolveRegStackDeep, "three interpreters");
@@ -667,8 +670,8 @@ __device__ __forceinline__ AT run_program_far(const SolveParams& S, const PT* P,
                 const bool rare = (int32_t)wq < 0, is_not = rare && (wq & kDwNeg), is_inord = rare && !(wq & kDwNeg);
                 if (is_not) acc = ~acc;
                 // candidates: documents where the group's boolean value is true (rval, expression.go:137)
-                const AT in = AT(inord_wave(S, is_inord, (wq & kDwFieldMask) >> kDwFieldShift, (uint64_t)(acc & valid), d0,
-                                            reinterpret_cast<const uint32_t*>(P), (uint32_t)sizeof(PT) * 8u));
+                const AT in = AT(inord_wave<RARE == 2>(S, is_inord, (wq & kDwFieldMask) >> kDwFieldShift, (uint64_t)(acc & valid), d0,
+                                                       reinterpret_cast<const uint32_t*>(P), (uint32_t)sizeof(PT) * 8u));
                 if (is_inord) acc = in;
             }
         };
@@ -722,7 +725,7 @@ template <> struct AType<64> { using type = Mask64; };
 // G = documents per group = bits of a presence-matrix element: 64 when 8 bytes per slot fit LDS, else 32 / 16 / 8 so that
 // large dictionaries still keep P in LDS (the evaluation then covers fewer documents per operation, but P stops being an
 // L2 ping-pong of atomics and random reads)
-template <bool P_LDS, bool PROG_LDS, int G, bool RARE, bool DBG = false>
+template <bool P_LDS, bool PROG_LDS, int G, int RARE, bool DBG = false>   // RARE: 0 no NOT / INORD word, 1 some, 2 some and a wide INORD group
 __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const SolveParams S) {
     const uint32_t dbg = DBG ? S.dbg : 0u;      // timing-study knock-outs (GFT_SOLVE_DEBUG): compiled out of production launches
     using PT = typename PType<G>::type;
@@ -997,15 +1000,18 @@ template <int G>
 hipError_t launch_g(const SolveParams& S, bool p_in_lds, bool prog_in_lds, unsigned grid, size_t lds, hipStream_t st) {
     using Kern = void (*)(const SolveParams);
     const bool io = S.has_rare != 0;
-    const Kern fn = p_in_lds ? (prog_in_lds ? (io ? k_solve_groups<true, true, G, true> : k_solve_groups<true, true, G, false>)
-                                            : (io ? k_solve_groups<true, false, G, true> : k_solve_groups<true, false, G, false>))
-                             : (prog_in_lds ? (io ? k_solve_groups<false, true, 64, true> : k_solve_groups<false, true, 64, false>)
-                                            : (io ? k_solve_groups<false, false, 64, true> : k_solve_groups<false, false, 64, false>));
+    const Kern fn = p_in_lds ? (prog_in_lds ? (io ? k_solve_groups<true, true, G, 1> : k_solve_groups<true, true, G, 0>)
+                                            : (io ? k_solve_groups<true, false, G, 1> : k_solve_groups<true, false, G, 0>))
+                             : (prog_in_lds ? (io ? k_solve_groups<false, true, 64, 1> : k_solve_groups<false, true, 64, 0>)
+                                            : (io ? k_solve_groups<false, false, 64, 1> : k_solve_groups<false, false, 64, 0>));
     Kern run = fn;
+    // a program set with a wide INORD group (SolveParams::wide_cap): the variant that can call the wide paths; its programs
+    // are read from L2 (the caller plans LDS accordingly)
+    if (S.wide_cap) run = p_in_lds ? k_solve_groups<true, false, G, 2> : k_solve_groups<false, false, 64, 2>;
     // timing studies: the benchmark's shape only (presence matrix and programs in LDS, 64 documents per group)
-    if (S.dbg && G == 64 && p_in_lds && prog_in_lds) run = io ? k_solve_groups<true, true, 64, true, true> : k_solve_groups<true, true, 64, false, true>;
+    if (S.dbg && !S.wide_cap && G == 64 && p_in_lds && prog_in_lds) run = io ? k_solve_groups<true, true, 64, 1, true> : k_solve_groups<true, true, 64, 0, true>;
     // ... and the shape of a 100 000-term dictionary (8 documents per group, programs in L2)
-    if (S.dbg && G == 8 && p_in_lds && !prog_in_lds) run = io ? k_solve_groups<true, false, 8, true, true> : k_solve_groups<true, false, 8, false, true>;
+    if (S.dbg && !S.wide_cap && G == 8 && p_in_lds && !prog_in_lds) run = io ? k_solve_groups<true, false, 8, 1, true> : k_solve_groups<true, false, 8, 0, true>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(run), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     run<<<dim3(grid), dim3(kSolveBlockThreads), lds, st>>>(S);

@@ -465,13 +465,12 @@ def test_expressions_beyond_the_device_solver_limits_are_solved_on_the_host():
     exprs = exprs[:400] + [wide] + exprs[400:900] + [deep_right, deep] + exprs[900:] + [huge]
     f = Finder(GpuEngine(), EmptyRgxEngine(), False)
     f.AddExpressions(exprs)
-    f.ForceBuild()
-    assert _lib_load().gft_n_host_exprs(f.engine_handle()) == 1          # `huge` alone
     o = Oracle(sorted(f.GetKeywords()))
     o.set_expressions(exprs, False)
     text, off = w.docs_host(0, 300)
     want = o.process(text, off, fold=True)
     assert want[:, 400 >> 5].any() and np.array_equal(f.ProcessTexts(blob=text, doc_off=off), want)
+    assert _lib_load().gft_n_host_exprs(f.engine_handle()) == 1          # `huge` alone (the programs are uploaded by now)
     one = f.ProcessText(bytes(text[int(off[5]):int(off[6])]))
     assert [r.ExpresionIndex for r in one] == [i for i in range(len(exprs)) if want[5, i >> 5] >> (i & 31) & 1]
     # device-resident corpus: the host's bits are patched into the device bitmap

@@ -194,6 +194,8 @@ struct gft_engine {
     uint32_t fprog_words = 0;
     uint32_t n_inord_groups = 0;           // fused INORD ops: 0 = the solver never reads positions
     uint32_t wide_pairs = 0;               // the widest INORD group the device solves through its scratch path (0: none); d_wide_*
+    uint32_t n_wide = 0;                   // expressions with such a group: answered by the solver's second phase (d_wide_list)
+    DevBuf d_wide_list;
     uint32_t n_rare_words = 0;             // fused NOT + INORD ops: 0 = the solver variant without their slow path
     DevBuf d_pscratch;                    // HBM presence matrices when n_slots * 8 B does not fit LDS
 
@@ -287,7 +289,7 @@ int upload(gft_engine* e, DevBuf& buf, const std::vector<T>& v, const char* what
 // traits != nullptr: a program beyond the device solver's limits is not refused but marked (it is solved on the host),
 // and the slots of its multi-leaf INORD groups are listed
 int check_program(const gft_engine* e, const uint32_t* w, uint64_t len, uint32_t n_slots, uint32_t idx, ProgramTraits* traits = nullptr) {
-    uint32_t sp = 0, psp = 0, g_tot = 0, g_psp = 0;           // g_*: the most pairs / the deepest pair stack of the group being read
+    uint32_t sp = 0, psp = 0, g_tot = 0, g_psp = 0, max_sp = 0;   // g_*: the most pairs / the deepest pair stack of the group being read
     std::vector<uint32_t> group_slots;
     std::vector<uint32_t> pcnt;   // pair counts of the INORD operand stack
     bool in_group = false;
@@ -334,6 +336,7 @@ int check_program(const gft_engine* e, const uint32_t* w, uint64_t len, uint32_t
         }
         // (the depth of the PUBLIC postfix form binds only a caller without traits; gft_set_programs judges the depth of the
         // fused form, which is what the device interprets: operands are reordered there, a chain nested to one side is flat)
+        max_sp = std::max(max_sp, sp);
         if (sp > kMaxBoolDepth && !traits)
             return fail(e, GFT_E_UNSUPPORTED, "program " + std::to_string(idx) + ": operand stack deeper than " +
                                                    std::to_string(kMaxBoolDepth));
@@ -348,6 +351,7 @@ int check_program(const gft_engine* e, const uint32_t* w, uint64_t len, uint32_t
         }
     }
     if (sp != 1 || !pcnt.empty()) return bad("program does not reduce to one value");
+    if (traits && traits->wide_pairs && max_sp > kMaxPairDepthWide) traits->over_limit = true;   // (the wide evaluator's boolean stack: a bit per entry)
     if (traits) {
         std::sort(traits->inord_slots.begin(), traits->inord_slots.end());
         traits->inord_slots.erase(std::unique(traits->inord_slots.begin(), traits->inord_slots.end()), traits->inord_slots.end());
@@ -359,7 +363,7 @@ int check_program(const gft_engine* e, const uint32_t* w, uint64_t len, uint32_t
 // `gbase` = offset of this program inside the uploaded public word array.
 // public postfix words -> fused words (gft_kernels.hpp FusedOp); returns the deepest the accumulator stack gets
 uint32_t fuse_program(const uint32_t* w, uint64_t len, uint64_t gbase, std::vector<uint32_t>& out,
-                      std::vector<uint32_t>& groups, const std::vector<uint64_t>* wide_groups = nullptr) {
+                      std::vector<uint32_t>& groups) {
     // postfix -> tree (node = operator or leaf, with the range of public words it covers)
     struct Node { uint32_t op, slot; int64_t l, r; uint64_t s, e; };
     std::vector<Node> nodes;
@@ -435,9 +439,7 @@ uint32_t fuse_program(const uint32_t* w, uint64_t len, uint64_t gbase, std::vect
                 if (nodes[nd.l].op != GFT_OP_UNIT) {
                     out.push_back(kFopInord << 28 | (uint32_t)(groups.size() / 2));
                     groups.push_back((uint32_t)(gbase + nodes[nd.l].s));
-                    // (the group's closing INORD word follows its subtree: wide groups are named by that word's index)
-                    const bool wide = wide_groups && std::binary_search(wide_groups->begin(), wide_groups->end(), nodes[nd.l].e + 1);
-                    groups.push_back((uint32_t)(nodes[nd.l].e - nodes[nd.l].s + 1) | (wide ? kGroupWide : 0u));
+                    groups.push_back((uint32_t)(nodes[nd.l].e - nodes[nd.l].s + 1));
                 }
                 if (neg) out.push_back(kFopNot << 28);
             }
@@ -1054,7 +1056,7 @@ int solve_pipeline(gft_engine* e, uint64_t n_docs, const gft_extra_matches* d_ex
         HIP_TRY(e->d_pscratch.ensure((size_t)grid * S.n_slots * 8), "presence scratch alloc");
         S.p_scratch = e->d_pscratch.as<uint64_t>();
     }
-    S.wide_slot = nullptr; S.wide_theta = nullptr; S.wide_cap = 0;
+    S.wide_slot = nullptr; S.wide_theta = nullptr; S.wide_cap = 0; S.wide_list = nullptr; S.n_wide = 0;
     if (e->wide_pairs) {
         // (a region per wave of the grid; 12 bytes per pair: 8 192 pairs x 4 096 waves = 400 MB at the very most)
         const uint64_t n_waves = (uint64_t)grid * (kSolveBlockThreads / 64);
@@ -1063,6 +1065,7 @@ int solve_pipeline(gft_engine* e, uint64_t n_docs, const gft_extra_matches* d_ex
         HIP_TRY(e->d_wide_theta.ensure(n_waves * S.wide_cap * 8), "INORD scratch alloc");
         S.wide_slot = e->d_wide_slot.as<uint32_t>();
         S.wide_theta = e->d_wide_theta.as<long long>();
+        S.wide_list = e->d_wide_list.as<uint32_t>(); S.n_wide = e->n_wide;
     }
     e->last_solve_group_docs = p_in_lds ? group_docs : 0;
     ProfScope ps(e, "solve");
@@ -1349,7 +1352,7 @@ void gft_engine_destroy(gft_engine* e) {
         for (auto& kv : e->prof)
             for (auto& p : kv.second.ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
         DevBuf* all[] = {&e->d_byte_class, &e->d_delta, &e->d_out_term, &e->d_out_link, &e->d_term_len, &e->d_prog,
-                         &e->d_prog_off, &e->d_fprog, &e->d_fprog_off, &e->d_groups, &e->d_wide_slot, &e->d_wide_theta, &e->d_order, &e->d_blk_class, &e->d_wave_blk, &e->d_fprog_t, &e->d_fblk_off, &e->d_pscratch, &e->d_solve_dbg, &e->d_s2_filter,
+                         &e->d_prog_off, &e->d_fprog, &e->d_fprog_off, &e->d_groups, &e->d_wide_slot, &e->d_wide_theta, &e->d_wide_list, &e->d_order, &e->d_blk_class, &e->d_wave_blk, &e->d_fprog_t, &e->d_fblk_off, &e->d_pscratch, &e->d_solve_dbg, &e->d_s2_filter,
                          &e->d_s2_slots, &e->d_s2_more, &e->d_s2_cls, &e->d_s2_cls_fold, &e->d_s2_term_blob,
                          &e->d_s2_term_off, &e->d_ctl, &e->d_dbg, &e->d_s2_short3, &e->d_s2_shorts_packed, &e->d_s2_short3_big, &e->d_s2_fpt,
                          &e->d_s3_filter, &e->d_s3_short3, &e->d_s3_srec, &e->d_s3_short3_big, &e->d_s3_srec_big, &e->d_s3_bloom, &e->d_s3_slots,
@@ -1899,14 +1902,16 @@ int gft_set_programs(gft_engine* e, const uint32_t* prog_words, const uint64_t* 
     std::vector<uint32_t> fw, groups, fdepth;
     std::vector<uint64_t> fo(1, 0);
     for (uint32_t i = 0; i < n_exprs; i++) {
-        if (traits[i].over_limit) {
+        if (traits[i].over_limit || traits[i].wide_pairs) {
             // beyond a limit of the device solver: the device evaluates a stand-in (one leaf on the never-present slot), the
-            // expression itself is solved on the host from the scan's matches (host_solve.hpp) and its bit patched in
+            // expression itself is solved on the host from the scan's matches (host_solve.hpp) and its bit patched in.
+            // An expression with a WIDE INORD group gets the same stand-in in the fused form: the solver's second phase
+            // (gft_solve.hip wide_expr_doc) answers it from its public words, a document per wave
             const uint32_t stub = GFT_OP_UNIT << 28 | n_slots;
             fdepth.push_back(fuse_program(&stub, 1, 0, fw, groups));
         } else {
             const size_t fw0 = fw.size(), g0 = groups.size();
-            uint32_t depth = fuse_program(prog_words + prog_off[i], prog_off[i + 1] - prog_off[i], prog_off[i], fw, groups, &traits[i].wide_groups);
+            uint32_t depth = fuse_program(prog_words + prog_off[i], prog_off[i + 1] - prog_off[i], prog_off[i], fw, groups);
             if (depth > kMaxBoolDepth) {
                 // the fused form still nests deeper than the interpreter's stack (a balanced tree of 2^128 sub-trees would):
                 // the host's
@@ -2034,8 +2039,18 @@ int gft_set_programs(gft_engine* e, const uint32_t* prog_words, const uint64_t* 
         }
     }
     e->wide_pairs = 0;
+    std::vector<uint32_t> wide_list;                     // per wide expression: index, offset and length of its public words
     for (uint32_t i = 0; i < n_exprs; i++)
-        if (!traits[i].over_limit) e->wide_pairs = std::max(e->wide_pairs, traits[i].wide_pairs);
+        if (!traits[i].over_limit && traits[i].wide_pairs) {
+            e->wide_pairs = std::max(e->wide_pairs, traits[i].wide_pairs);
+            if (prog_off[i + 1] > 0xFFFFFFFFull) return fail(e, GFT_E_UNSUPPORTED, "program set too large");
+            wide_list.push_back(i); wide_list.push_back((uint32_t)prog_off[i]); wide_list.push_back((uint32_t)(prog_off[i + 1] - prog_off[i]));
+        }
+    e->n_wide = (uint32_t)(wide_list.size() / 3);
+    if (e->n_wide) {
+        if ((rc = upload(e, e->d_wide_list, wide_list, "program upload"))) return rc;
+        HIP_TRY(hipStreamSynchronize(e->stream), "program upload");        // (wide_list is a local)
+    }
     e->traits.swap(traits);
     e->fprog_words = (uint32_t)fw.size();
     e->n_inord_groups = e->n_rare_words = 0;
@@ -2043,6 +2058,7 @@ int gft_set_programs(gft_engine* e, const uint32_t* prog_words, const uint64_t* 
         e->n_inord_groups += (w >> 28) == kFopInord;
         e->n_rare_words += (w >> 28) == kFopInord || (w >> 28) == kFopNot;
     }
+    e->n_inord_groups += e->n_wide;                      // (their groups read positions too: the scan must write them)
     return GFT_OK;
 } GFT_CATCH((e ? &e->err : nullptr))
 

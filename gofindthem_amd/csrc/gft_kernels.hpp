@@ -11,11 +11,11 @@ constexpr uint32_t kSolveBlockThreads = 1024;    // 16 waves: 64 documents x 16-
 constexpr uint32_t kMaxPairs = 64;               // (slot, theta) pairs alive inside one INORD group
 constexpr uint32_t kMaxPairDepth = 32;           // operand-stack depth inside one INORD group
 constexpr uint32_t kMaxBoolDepth = 128;          // operand-stack depth of a whole program
-// wider INORD groups keep their pairs in a per-wave scratch region in HBM (gft_solve.hip inord_group_wide): chunks of 64 pairs
-// go through the lanes.  Beyond these the expression is solved on the host (host_solve.hpp)
+// An expression with a wider INORD group is answered by the solver kernel's second phase (gft_solve.hip wide_expr_doc: pairs
+// compacted by presence in the lanes, a per-wave scratch region in HBM behind that).  Beyond these limits the expression is
+// solved on the host (host_solve.hpp)
 constexpr uint32_t kMaxPairsWide = 8192;
 constexpr uint32_t kMaxPairDepthWide = 64;       // (a stack entry per lane)
-constexpr uint32_t kGroupWide = 0x80000000u;     // SolveParams::groups: top bit of a group's length word
 
 #define GFT_K_INORD_FLAG (1u << 27)
 #define GFT_K_SLOT_MASK ((1u << 27) - 1u)
@@ -135,6 +135,8 @@ struct SolveParams {
     uint32_t* wide_slot;         // pairs of wide INORD groups: [grid * waves][wide_cap] slots ...
     long long* wide_theta;       // ... and thresholds (null: no program has a wide group)
     uint32_t wide_cap;
+    const uint32_t* wide_list;   // [n_wide][3] = expression, offset and length of its public words in gprog: the expressions
+    uint32_t n_wide;             // with a wide INORD group, which the kernel's second phase answers (wide_expr_doc)
     uint32_t* bitmap;
 };
 

@@ -34,16 +34,7 @@ namespace {
 #include "gft_scan2_dev.hpp"
 #include "gft_foldsafe_dev.hpp"
 
-#ifndef GFT_S5_TEXT2
-#define GFT_S5_TEXT2 1
-#endif
-#ifndef GFT_S5_LIST2
-#define GFT_S5_LIST2 1
-#endif
-#ifndef GFT_S5_WAYS
-#define GFT_S5_WAYS 2
-#endif
-constexpr int kWays5 = GFT_S5_WAYS;  // stage A: candidates a lane works on at once
+constexpr int kWays5 = 2;           // stage A: candidates a lane works on at once (3 / 4 / 6 measured in round 4: + 1 / + 3 % / slower)
 
 struct Ctx5 {
     uint32_t* fifo;              // LDS
@@ -467,20 +458,6 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
                         for (uint32_t i = 0; i < nborder; i++) cand[wpos++] = (uint16_t)(kScan2MaxOff - nborder + i);
                     uint32_t mm[4] = {m0, m1, m2, m3};
                     const uint32_t rel = lane * C + kScan2MaxOff;
-#if GFT_S5_LIST2
-                    // two mask words side by side: their ctz chains are independent, the trip count is the larger of the two
-                    // popcounts over the lanes instead of their sum
-#pragma unroll
-                    for (int k = 0; k < 4; k += 2) {
-                        uint32_t ma = mm[k], mb = mm[k + 1];
-                        uint32_t wa = wpos, wb = wpos + __popc(ma);
-                        wpos = wb + __popc(mb);
-                        while (ma | mb) {
-                            if (ma) { const uint32_t i = __builtin_ctz(ma); ma &= ma - 1; cand[wa++] = (uint16_t)(rel + 32 * k + i); }
-                            if (mb) { const uint32_t i = __builtin_ctz(mb); mb &= mb - 1; cand[wb++] = (uint16_t)(rel + 32 * (k + 1) + i); }
-                        }
-                    }
-#else
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         uint32_t mk = mm[k];
@@ -490,7 +467,6 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
                             cand[wpos++] = (uint16_t)(rel + 32 * k + i);
                         }
                     }
-#endif
                 }
                 wave_lds_sync();
                 // stage A: every flagged position -> LDS-only decisions; short terms are emitted here, positions that may end a
@@ -577,7 +553,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
                     b_k.x = survx[b_on ? lane : 0];
                     b_s0 = slot_load(&P.slots[scan2_slot_hash(b_k.x, 0, P.slot_shift, P.slot_seed)]);
                     b_s1 = slot_load(&P.slots[scan2_slot_hash(b_k.x, 1, P.slot_shift, P.slot_seed)]);
-                    if (GFT_S5_TEXT2 && !c.near24 && !c.near_end) {
+                    if (!c.near24 && !c.near_end) {
                         // the 32 bytes around the position as two 16-byte loads -- text[p-23 .. p-8] and text[p-7 .. p+8] -- instead
                         // of three (window + front 8, front 16, tail 4): one request less per survivor into an L1 whose
                         // pending-request queue is full half of the time

@@ -262,21 +262,25 @@ __device__ __attribute__((noinline)) bool inord_group_wide(const uint32_t* __res
     return range_min(__builtin_amdgcn_readlane(st, sp - 1), top) != INT64_MAX;
 }
 
-// A wide group in the lanes after all: of an OR over hundreds of terms a document holds a handful, and the presence matrix
-// says which.  The group's words pass through the lanes 128 at a time; every UNIT lane looks its slot up in the presence
-// matrix (Pw: LDS or HBM, element slot * G + j for document j of the group), an absent UNIT that an OR follows is dropped
-// together with that OR (X or {} == X), and what is left is interpreted as in inord_group_wave with one addition: ranges that
-// are the empty list (the dummy pair) are remembered (`empt`, by their first pair) and vanish in an OR, so the pairs alive
-// are the PRESENT leaves plus a dummy per empty operand.  Returns 0 / 1, or 2 when more than 64 pairs are alive after all
-// (a document that holds dozens of the group's terms): the caller then takes the scratch path above.
-__device__ __forceinline__ uint32_t inord_group_sparse(const uint32_t* __restrict__ prog, uint32_t len, const DocHits* Mp,
-                                                                  const uint32_t* Pw, uint32_t G, uint32_t j) {
-    const DocHits& M = *Mp;
+// One expression with a WIDE INORD group for ONE document, by a whole wave, from the expression's public postfix words
+// (dsl/expression.go:66-142 in one pass: every word moves the boolean stack, the words inside an INORD group -- they carry
+// GFT_K_INORD_FLAG -- move the pair stack of inord_group_wave as well, and the group's INORD word joins the two:
+// rval && len(rpos) > 0, :137).  What makes a wide group fit a wave's 64 lanes after all: of an OR over hundreds of terms a
+// document holds a handful, and the presence matrix says which.  The words pass through the lanes 128 at a time; every
+// UNIT lane looks its slot up in the presence matrix (Pw: LDS or HBM, element slot * G + j for document j of the group); an
+// absent UNIT that an OR follows is dropped together with that OR (X or {} == X, for truth values and for position lists
+// alike), ranges that are the empty list (the dummy pair) are remembered (`empt`, by their first pair) and vanish in an OR:
+// the pairs alive are the PRESENT leaves plus a dummy per empty operand.  A group that still has more than 64 alive (a
+// document that holds dozens of its terms) is answered by inord_group_wide's scratch path when its INORD word comes.
+// The boolean stack is a bit per entry (gft_set_programs sends deeper expressions to the host).
+__device__ __forceinline__ bool wide_expr_doc(const uint32_t* __restrict__ prog, uint32_t len, const DocHits& M, const uint32_t* Pw,
+                                              uint32_t G, uint32_t j, uint32_t* ws, long long* wt) {
     const uint32_t lane = lane_id();
     uint32_t my_slot = kNoSlot;
     int64_t my_theta = -1;
-    uint64_t starts = 0, empt = 0;
-    uint32_t top = 0;
+    uint64_t starts = 0, empt = 0, bst = 0;                       // bst: the boolean stack, entry k = bit k
+    uint32_t top = 0, bsp = 0;
+    bool ovf = false;                                            // this group outgrew the lanes: pairs are not tracked any more
     auto fetch = [&](uint32_t at) { return at + lane < len ? prog[at + lane] : 0u; };
     uint32_t n0 = fetch(0), n1 = fetch(64);
     for (uint32_t c0 = 0; c0 < len; c0 += 128) {
@@ -291,62 +295,90 @@ __device__ __forceinline__ uint32_t inord_group_sparse(const uint32_t* __restric
         }
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            if (c0 + 64 * h >= len) break;
+            const uint32_t base = c0 + 64 * h;
+            if (base >= len) break;
             const uint32_t wl = w2[h];
             const uint64_t mU = __ballot((wl >> 28) == 1), mP = __ballot(pres[h]), mO = __ballot((wl >> 28) == 3);
             uint64_t skip = (mU & ~mP) & (mO >> 1);              // an absent UNIT and the OR behind it
             skip |= skip << 1;
-            uint64_t todo = ~skip & (len - (c0 + 64 * h) >= 64 ? ~0ull : (1ull << (len - (c0 + 64 * h))) - 1);
+            uint64_t todo = ~skip & (len - base >= 64 ? ~0ull : (1ull << (len - base)) - 1);
             while (todo) {
                 const uint32_t i = (uint32_t)__builtin_ctzll(todo);
                 todo &= todo - 1;
                 const uint32_t w = __builtin_amdgcn_readlane(wl, i);
                 const uint32_t op = w >> 28;
+                const bool fl = (w & GFT_K_INORD_FLAG) != 0;
                 if (op == 1) {                                   // UNIT
-                    if (top >= 64) return 2;
                     const bool here = (mP >> i) & 1;
-                    if (lane == top) { my_slot = here ? (w & GFT_K_SLOT_MASK) : kNoSlot; my_theta = -1; }
-                    starts |= 1ull << top;
-                    if (!here) empt |= 1ull << top;
-                    top++;
-                } else if (op == 2 || op == 3) {
-                    const uint32_t rb = 63u - (uint32_t)__builtin_clzll(starts);
-                    const uint64_t rest = starts & ~(1ull << rb);
-                    const uint32_t lb = 63u - (uint32_t)__builtin_clzll(rest);
-                    const uint32_t lc = rb - lb, rc = top - rb;
-                    const bool le = (empt >> lb) & 1, re = (empt >> rb) & 1;
-                    empt &= ~((1ull << lb) | (1ull << rb));
-                    if (op == 3) {                               // OR: union == concatenation, empty operands vanish
-                        if (re) { top = rb; if (le) empt |= 1ull << lb; }
-                        else if (le) {                           // (the dummy at lb goes: R moves down by one)
-                            const uint32_t r_slot = __shfl(my_slot, (int)((lane + 1) & 63u), 64);
-                            const int64_t r_theta = __shfl(my_theta, (int)((lane + 1) & 63u), 64);
-                            if (lane >= lb && lane < lb + rc) { my_slot = r_slot; my_theta = r_theta; }
-                            top = lb + rc;
-                        }
-                    } else {                                     // AND
-                        int64_t m = INT64_MAX;
-                        if (!le && !re) m = wave_succ_min(M, my_slot, my_theta, lb, lc);
-                        const uint32_t r_slot = __shfl(my_slot, (int)((lane + lc) & 63u), 64);
-                        const int64_t r_theta = __shfl(my_theta, (int)((lane + lc) & 63u), 64);
-                        if (m == INT64_MAX) {
-                            if (lane == lb) { my_slot = kNoSlot; my_theta = -1; }
-                            top = lb + 1;
-                            empt |= 1ull << lb;
-                        } else {
-                            if (lane >= lb && lane < lb + rc) { my_slot = r_slot; my_theta = r_theta < m ? m : r_theta; }
-                            top = lb + rc;
+                    bst = (bst & ~(1ull << bsp)) | ((uint64_t)here << bsp);
+                    bsp++;
+                    if (fl && !ovf) {
+                        if (top >= 64) ovf = true;
+                        else {
+                            if (lane == top) { my_slot = here ? (w & GFT_K_SLOT_MASK) : kNoSlot; my_theta = -1; }
+                            starts |= 1ull << top;
+                            if (!here) empt |= 1ull << top;
+                            top++;
                         }
                     }
-                    starts = rest;
+                } else if (op == 2 || op == 3) {
+                    const uint64_t b = (bst >> (bsp - 1)) & 1, a = (bst >> (bsp - 2)) & 1, r = op == 2 ? (a & b) : (a | b);
+                    bsp--;
+                    bst = (bst & ~(1ull << (bsp - 1))) | (r << (bsp - 1));
+                    if (fl && !ovf) {
+                        const uint32_t rb = 63u - (uint32_t)__builtin_clzll(starts);
+                        const uint64_t rest = starts & ~(1ull << rb);
+                        const uint32_t lb = 63u - (uint32_t)__builtin_clzll(rest);
+                        const uint32_t lc = rb - lb, rc = top - rb;
+                        const bool le = (empt >> lb) & 1, re = (empt >> rb) & 1;
+                        empt &= ~((1ull << lb) | (1ull << rb));
+                        if (op == 3) {                           // OR: union == concatenation, empty operands vanish
+                            if (re) { top = rb; if (le) empt |= 1ull << lb; }
+                            else if (le) {                       // (the dummy at lb goes: R moves down by one)
+                                const uint32_t r_slot = __shfl(my_slot, (int)((lane + 1) & 63u), 64);
+                                const int64_t r_theta = __shfl(my_theta, (int)((lane + 1) & 63u), 64);
+                                if (lane >= lb && lane < lb + rc) { my_slot = r_slot; my_theta = r_theta; }
+                                top = lb + rc;
+                            }
+                        } else {                                 // AND
+                            int64_t m = INT64_MAX;
+                            if (!le && !re) m = wave_succ_min(M, my_slot, my_theta, lb, lc);
+                            const uint32_t r_slot = __shfl(my_slot, (int)((lane + lc) & 63u), 64);
+                            const int64_t r_theta = __shfl(my_theta, (int)((lane + lc) & 63u), 64);
+                            if (m == INT64_MAX) {
+                                if (lane == lb) { my_slot = kNoSlot; my_theta = -1; }
+                                top = lb + 1;
+                                empt |= 1ull << lb;
+                            } else {
+                                if (lane >= lb && lane < lb + rc) { my_slot = r_slot; my_theta = r_theta < m ? m : r_theta; }
+                                top = lb + rc;
+                            }
+                        }
+                        starts = rest;
+                    }
+                } else if (op == 4) {                            // NOT (never inside a group: the parser rejects it)
+                    bst ^= 1ull << (bsp - 1);
+                } else if (op == 5) {                            // INORD: rval && len(rpos) > 0
+                    bool some = false;
+                    if ((bst >> (bsp - 1)) & 1) {                // (a false rval needs no positions)
+                        if (ovf) {
+                            // the group's words: the flagged run that ends in front of this word
+                            const uint32_t pc = base + i;
+                            uint32_t gs = pc;
+                            while (gs > 0 && (prog[gs - 1] & GFT_K_INORD_FLAG) != 0 && (prog[gs - 1] >> 28) != 5) gs--;
+                            some = ws != nullptr && inord_group_wide(prog + gs, pc - gs, &M, ws, wt);
+                        } else if (top) {
+                            const uint32_t gb = 63u - (uint32_t)__builtin_clzll(starts);
+                            some = !((empt >> gb) & 1) && wave_succ_min(M, my_slot, my_theta, gb, top - gb) != INT64_MAX;
+                        }
+                    }
+                    bst = (bst & ~(1ull << (bsp - 1))) | ((uint64_t)some << (bsp - 1));
+                    top = 0; starts = 0; empt = 0; ovf = false;
                 }
             }
         }
     }
-    if (!top) return 0;
-    const uint32_t b = 63u - (uint32_t)__builtin_clzll(starts);
-    if ((empt >> b) & 1) return 0;
-    return wave_succ_min(M, my_slot, my_theta, b, top - b) != INT64_MAX ? 1u : 0u;
+    return bsp == 1 && (bst & 1);
 }
 
 // 64 x 64 bit-matrix transpose across a wave: lane i holds row i; afterwards lane j holds column j (bit i = old row
@@ -398,11 +430,7 @@ __device__ __forceinline__ uint64_t wave_transpose64(uint64_t x) {
 // group's boolean value is true, rval of expression.go:137).  The (lane, document) pairs are taken one after the other
 // and each is evaluated by the whole wave, so a large document's matches are scanned 64 wide and a wave with few
 // candidates does not leave 63 lanes idle.  Returns the documents whose position list is non-empty.
-// WIDE: the kernel variant of program sets that hold a wide group (inord_group_sparse / inord_group_wide are real calls: a
-// kernel that contains them keeps registers free around the call sites, which the common variant cannot afford)
-template <bool WIDE>
-__device__ __forceinline__ uint64_t inord_wave(const SolveParams& S, bool is_inord, uint32_t grp, uint64_t cand, uint64_t d0,
-                                               const uint32_t* Pw = nullptr, uint32_t G = 0) {
+__device__ __forceinline__ uint64_t inord_wave(const SolveParams& S, bool is_inord, uint32_t grp, uint64_t cand, uint64_t d0) {
     const uint32_t lane = lane_id();
     uint64_t res = 0;
     uint64_t todo = __ballot(is_inord && cand != 0);
@@ -432,15 +460,7 @@ __device__ __forceinline__ uint64_t inord_wave(const SolveParams& S, bool is_ino
                 const uint64_t x0 = S.x_off[d];
                 M.xslot = S.x_slot + x0; M.xpos = S.x_pos + x0; M.nx = (uint32_t)(S.x_off[d + 1] - x0);
             }
-            bool r;
-            if (WIDE && (glen & kGroupWide) != 0) {
-                const uint64_t wv = (uint64_t)blockIdx.x * (kSolveBlockThreads / 64) + (threadIdx.x >> 6);
-                const uint32_t q = Pw ? inord_group_sparse(S.gprog + goff, glen & ~kGroupWide, &M, Pw, G, j) : 2u;
-                r = q == 1;
-                if (q == 2) r = S.wide_slot != nullptr && inord_group_wide(S.gprog + goff, glen & ~kGroupWide, &M, S.wide_slot + wv * S.wide_cap, S.wide_theta + wv * S.wide_cap);
-            } else {
-                r = inord_group_wave(S.gprog + goff, glen & ~kGroupWide, M);
-            }
+            const bool r = inord_group_wave(S.gprog + goff, glen, M);
             if (r && lane == L) res |= 1ull << j;
         }
     }
@@ -569,8 +589,7 @@ __device__ __forceinline__ AT run_program(const SolveParams& S, const PT* P, con
                 const bool rare = (int32_t)wq < 0, is_not = rare && (wq & kDwNeg), is_inord = rare && !(wq & kDwNeg);
                 if (is_not) acc = ~acc;
                 // candidates: documents where the group's boolean value is true (rval, expression.go:137)
-                const AT in = AT(inord_wave<RARE == 2>(S, is_inord, (wq & kDwFieldMask) >> kDwFieldShift, (uint64_t)(acc & valid), d0,
-                                                       reinterpret_cast<const uint32_t*>(P), (uint32_t)sizeof(PT) * 8u));
+                const AT in = AT(inord_wave(S, is_inord, (wq & kDwFieldMask) >> kDwFieldShift, (uint64_t)(acc & valid), d0));
                 if (is_inord) acc = in;
             }
         };
@@ -670,8 +689,7 @@ __device__ __forceinline__ AT run_program_far(const SolveParams& S, const PT* P,
                 const bool rare = (int32_t)wq < 0, is_not = rare && (wq & kDwNeg), is_inord = rare && !(wq & kDwNeg);
                 if (is_not) acc = ~acc;
                 // candidates: documents where the group's boolean value is true (rval, expression.go:137)
-                const AT in = AT(inord_wave<RARE == 2>(S, is_inord, (wq & kDwFieldMask) >> kDwFieldShift, (uint64_t)(acc & valid), d0,
-                                                       reinterpret_cast<const uint32_t*>(P), (uint32_t)sizeof(PT) * 8u));
+                const AT in = AT(inord_wave(S, is_inord, (wq & kDwFieldMask) >> kDwFieldShift, (uint64_t)(acc & valid), d0));
                 if (is_inord) acc = in;
             }
         };
@@ -928,6 +946,41 @@ __global__ void __launch_bounds__(kSolveBlockThreads) k_solve_groups(const Solve
                             : cls == 1 ? run_program_far<P_LDS, kSolveRegStack, RARE, PT, AT>(S, P, prog, stride, chunks, AT(valid), d0)
                                        : run_program_far<P_LDS, kSolveRegStackDeep, RARE, PT, AT>(S, P, prog, stride, chunks, AT(valid), d0);
                     if (has) R[e - e0] = (uint64_t)r;
+                }
+            }
+            if constexpr (RARE == 2) {
+                // 2a'. the expressions with a wide INORD group (stand-ins in the fused form: their R is 0 by now): a document per
+                // wave, all sixteen waves on one expression -- the candidates of ONE lane's program would otherwise queue on one
+                // wave while fifteen idle
+                lds_barrier();
+                const uint64_t wv = (uint64_t)blockIdx.x * kWaves + wave;
+                for (uint32_t k = 0; k < S.n_wide; k++) {
+                    const uint32_t e = uniform_word(S.wide_list, 3 * k);
+                    if (e < e0 || e >= e0 + ne) continue;
+                    const uint32_t goff = uniform_word(S.wide_list, 3 * k + 1), glen = uniform_word(S.wide_list, 3 * k + 2);
+                    for (uint32_t j = wave; j < nd; j += kWaves) {
+                        const uint64_t d = d0 + j;
+                        DocHits M;
+                        M.unit_start = S.unit_start; M.unit_count = S.unit_count;
+                        M.term = S.term; M.pos = S.pos;
+                        M.u0 = S.doc_unit_base[d]; M.u1 = S.doc_unit_base[d + 1];
+                        M.nx = 0; M.xslot = nullptr; M.xpos = nullptr;
+                        M.back = S.pos_back;
+                        M.per = 1;
+                        if (M.u1 - M.u0 >= kUnitsPerLaneMode) {
+                            const Unit first = S.units[M.u0];
+                            const uint32_t per32 = __builtin_amdgcn_readfirstlane(first.hi - first.lo);
+                            M.per = per32 ? per32 : 1u;
+                        }
+                        if (S.x_off) {
+                            const uint64_t x0 = S.x_off[d];
+                            M.xslot = S.x_slot + x0; M.xpos = S.x_pos + x0; M.nx = (uint32_t)(S.x_off[d + 1] - x0);
+                        }
+                        const bool r = wide_expr_doc(S.gprog + goff, glen, M, reinterpret_cast<const uint32_t*>(P), (uint32_t)G, j,
+                                                     S.wide_slot ? S.wide_slot + wv * S.wide_cap : nullptr, S.wide_theta ? S.wide_theta + wv * S.wide_cap : nullptr);
+                        if (r && lane == 0)
+                            __hip_atomic_fetch_or(reinterpret_cast<unsigned long long*>(&R[e - e0]), 1ull << j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
                 }
             }
             mark(2);

@@ -354,6 +354,14 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
             for (uint32_t q = 0; q < npieces; q++) {
                 const uint32_t w[4] = {nxt.x, nxt.y, nxt.z, nxt.w};
                 if (q * 16 < nvalid) hib |= (w[0] | w[1]) | (w[2] | w[3]);   // (may take in up to 15 bytes behind the lane's range: conservative)
+                // A dictionary over a large alphabet (SG) usually meets text that leaves ASCII: there the pieces that hold a
+                // high byte are noted one by one as they pass (a ballot per piece; a sixth of the fold jobs of "every piece of a
+                // lane that saw one").  The all-ASCII instantiation keeps the two ORs: the extra loop-carried state cost the
+                // headline 1.2 % when both shared the code (round 3)
+                if constexpr (SG) {
+                    if (want_fold && !told_nonascii)
+                        fold_job_push(q * 16 < nvalid && (((w[0] | w[1]) | (w[2] | w[3])) & 0x80808080u) != 0, lane * C + q * 16, cand, P.cand_cap, njobs);
+                }
                 if (q + 1 < npieces && (q + 1) * 16 < nvalid) nxt = *reinterpret_cast<const U128u*>(src + (q + 1) * 16);
                 const uint32_t nd = ndw - 4 * q;                 // dwords of this piece that belong to the lane (>= 1)
                 // probe at byte 0 of a dword: 3-gram (h2, h1, c0); the window that ends there has h3 in front, the window that
@@ -406,7 +414,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
             // ASCII folding is not strings.ToLower once the text leaves ASCII (finder.go:140-142): the pieces of the lanes that
             // met a byte >= 0x80 are judged now (gft_foldsafe_dev.hpp; which of a lane's pieces it was is not kept -- text that
             // leaves ASCII is the exception for the dictionaries this kernel serves, the filter loop pays two ORs for it)
-            if (want_fold && !told_nonascii && __any((hib & 0x80808080u) != 0)) {
+            if (!SG && want_fold && !told_nonascii && __any((hib & 0x80808080u) != 0)) {
                 for (uint32_t q = 0; q < npieces; q++)
                     fold_job_push((hib & 0x80808080u) != 0 && q * 16 < nvalid, lane * C + q * 16, cand, P.cand_cap, njobs);
             }

@@ -52,6 +52,7 @@ tail -1 $O/bench_inord.log > $O/r4_inord_bench.json
 python3 bench.py --steps 10 --warmup 2 --alphabet mixed > $O/bench_mixed.log 2>&1
 tail -1 $O/bench_mixed.log > $O/r4_mixed_bench.json
 python3 tools/bench_c1.py > $O/r4_c1_bench.json 2> $O/c1.log
+GFT_SOLVE_DEBUG=8 python3 tools/bench_c1.py 2>&1 | grep "solve debug" | tail -18 > $O/r4_c1_solver_phase_clocks.txt || true
 timeout -k 10 300 python3 tools/bench_overlimit.py --json $O/r4_overlimit.json > $O/overlimit.log 2>&1
 python3 tools/bench_latency.py --batch-docs 250000 --reps 50 > $O/r4_host_path.json 2> $O/lat.log
 echo part b collected

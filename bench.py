@@ -159,6 +159,7 @@ def main():
     # ---- timed region -------------------------------------------------------------------------------------
     for _ in range(args.warmup):
         step()
+    fence()                                # (the warm-up batches are complete -- a rerun of the last one included -- before anything is counted)
     L.gft_profile_enable(eh, 1)
     L.gft_profile_reset(eh)
     fence()

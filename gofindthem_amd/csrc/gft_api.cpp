@@ -1196,7 +1196,7 @@ int host_eval(gft_engine* e, const gft_extra_matches* extra, uint64_t n_docs, co
 // ---- compiled tables as one blob (BuildEngine for a large dictionary is paid once) -----------------
 namespace {
 constexpr uint32_t kTablesMagic = 0x54544647u;   // "GFTT"
-constexpr uint32_t kTablesVersion = 8;           // bump when a table layout or a hash function changes
+constexpr uint32_t kTablesVersion = 9;           // bump when a table layout or a hash function changes
 
 struct Writer {
     std::vector<uint8_t> b;
@@ -1255,6 +1255,10 @@ const char* validate_tables(const AcTables& a, const Scan2Tables& t, const Scan3
         // every bucket key into four classes: the two class maps must be one, and a key must be four classes
         if (t.kp != a.n_classes) return "scan2 class count differs from the automaton's";
         for (int b = 0; b < 256; b++) if (t.cls[b] != a.byte_class[b]) return "scan2 byte class differs from the automaton's";
+        // (a key lives in ITS pair of the bucket table and nowhere else: the kernels look nowhere else)
+        if (t.slot_shift < 1 || t.slot_shift > 31) return "bucket table size";
+        for (size_t i = 0; i < t.slots.size(); i++)
+            if (t.slots[i].key != kScan2EmptyKey && (scan2_pair_slot(t.slots[i].key, 0, t.slot_shift, t.slot_seed) | 1u) != ((uint32_t)i | 1u)) return "bucket placement";
         {
             const uint64_t kp4 = (uint64_t)t.kp * t.kp * t.kp * t.kp;
             for (const Scan2Slot& s : t.slots) if (s.key != kScan2EmptyKey && s.key >= kp4) return "bucket key";

@@ -221,6 +221,14 @@ GFT_HD inline uint32_t scan2_slot_hash(uint32_t x, int which, uint32_t shift, ui
     const uint32_t xf = (x ^ (x >> 20)) + seed;    // keys beyond 24 bits (hashed alphabets) keep their top bits in play
     return (which ? scan2_mul24c<0x85EBCBu>(xf) : scan2_mul24c<0x9E3779u>(xf)) >> shift;
 }
+// Scan2Tables (round 4): a key's two candidate slots are the two slots of ONE 64-byte pair -- one request of the L1 instead of
+// two at random places of the table.  A pair holds two keys; the table builder gives a term another anchor window when its
+// pair is full (scan2_tables.cpp), so no key ever lives anywhere else and a lookup is still one round trip.  (Scan3Tables
+// keeps the two independent choices of scan2_slot_hash: two anchors per term leave it no window to trade.)
+GFT_HD inline uint32_t scan2_pair_slot(uint32_t x, int which, uint32_t shift, uint32_t seed) {
+    const uint32_t xf = (x ^ (x >> 20)) + seed;
+    return ((scan2_mul24c<0x9E3779u>(xf) >> shift) & ~1u) | (uint32_t)which;
+}
 // fpt_lg == 0: the LDS table of kScan2FptSize cells; else a global table of 2^fpt_lg cells
 GFT_HD inline uint32_t scan2_fpt_index(uint32_t h, uint32_t fpt_lg) {
     return fpt_lg ? h >> (32 - fpt_lg) : scan2_mul24c<kScan2FptSize>(h >> 16) >> 16;

@@ -347,8 +347,8 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan2(const Scan2Params P) {
                         const uint32_t tl = tail_load(c, p);
                         Cand k;
                         cand_keys<false>(c, p, t8, k);
-                        const Slot s0 = slot_load(&P.slots[scan2_slot_hash(k.x, 0, P.slot_shift, P.slot_seed)]);
-                        const Slot s1 = slot_load(&P.slots[scan2_slot_hash(k.x, 1, P.slot_shift, P.slot_seed)]);
+                        const Slot s0 = slot_load(&P.slots[scan2_pair_slot(k.x, 0, P.slot_shift, P.slot_seed)]);
+                        const Slot s1 = slot_load(&P.slots[scan2_pair_slot(k.x, 1, P.slot_shift, P.slot_seed)]);
                         finish_long(c, on, rel, k, s0, s1, fr, tl, fifo, nf, dfr);
                     }
                     if (dfr.n) drain_deferred(c, ubase, fifo, nf, dfr);

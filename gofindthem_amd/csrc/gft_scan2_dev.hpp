@@ -283,8 +283,8 @@ __device__ __forceinline__ void cand_finish(const Ctx& c, const Cand& k, uint32_
     };
     // ---- terms of length >= 4, longest first ---------------------------------------------------------------------
     if (k.go_long) {
-        const Slot s0 = slot_load(&P.slots[scan2_slot_hash(k.x, 0, P.slot_shift, P.slot_seed)]);
-        const Slot s1 = slot_load(&P.slots[scan2_slot_hash(k.x, 1, P.slot_shift, P.slot_seed)]);
+        const Slot s0 = slot_load(&P.slots[scan2_pair_slot(k.x, 0, P.slot_shift, P.slot_seed)]);
+        const Slot s1 = slot_load(&P.slots[scan2_pair_slot(k.x, 1, P.slot_shift, P.slot_seed)]);
         Front t = front_load(c, p, k.tw);
         const uint32_t tl = tail_load(c, p);
         if (P.fold) front_fold(t);

@@ -354,8 +354,8 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan4(const Scan2Params P) {
                 for (int h = 0; h < 2; h++) { const uint32_t i = 64 * h + lane; if (i < left) { qbp[i] = (uint16_t)mp[h]; qbk[i] = mk[h]; } }
                 qb_n = left;
                 // both candidate slots of the key and the text around the window, all at once (the key is known)
-                const Slot s0 = slot_load(&P.slots[scan2_slot_hash(x, 0, P.slot_shift, P.slot_seed)]);
-                const Slot s1 = slot_load(&P.slots[scan2_slot_hash(x, 1, P.slot_shift, P.slot_seed)]);
+                const Slot s0 = slot_load(&P.slots[scan2_pair_slot(x, 0, P.slot_shift, P.slot_seed)]);
+                const Slot s1 = slot_load(&P.slots[scan2_pair_slot(x, 1, P.slot_shift, P.slot_seed)]);
                 const Text8 t8 = cand_load(c, p);
                 Front t = front_load(c, p, t8.tw);
                 const uint32_t tl = tail_load(c, p);

@@ -559,8 +559,8 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
                 uint32_t b_tl = 0;
                 if (ns) {
                     b_k.x = survx[b_on ? lane : 0];
-                    b_s0 = slot_load(&P.slots[scan2_slot_hash(b_k.x, 0, P.slot_shift, P.slot_seed)]);
-                    b_s1 = slot_load(&P.slots[scan2_slot_hash(b_k.x, 1, P.slot_shift, P.slot_seed)]);
+                    b_s0 = slot_load(&P.slots[scan2_pair_slot(b_k.x, 0, P.slot_shift, P.slot_seed)]);
+                    b_s1 = slot_load(&P.slots[scan2_pair_slot(b_k.x, 1, P.slot_shift, P.slot_seed)]);
                     if (!c.near24 && !c.near_end) {
                         // the 32 bytes around the position as two 16-byte loads -- text[p-23 .. p-8] and text[p-7 .. p+8] -- instead
                         // of three (window + front 8, front 16, tail 4): one request less per survivor into an L1 whose
@@ -597,8 +597,8 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
                     if (i0 + 64 <= kScan5SurvX) {
                         // the survivors' window keys came along from stage A: slots and text leave together, one round trip
                         k.x = survx[on ? i0 + lane : 0];
-                        const Slot s0 = slot_load(&P.slots[scan2_slot_hash(k.x, 0, P.slot_shift, P.slot_seed)]);
-                        const Slot s1 = slot_load(&P.slots[scan2_slot_hash(k.x, 1, P.slot_shift, P.slot_seed)]);
+                        const Slot s0 = slot_load(&P.slots[scan2_pair_slot(k.x, 0, P.slot_shift, P.slot_seed)]);
+                        const Slot s1 = slot_load(&P.slots[scan2_pair_slot(k.x, 1, P.slot_shift, P.slot_seed)]);
                         const Text8 t8 = cand_load(c, p);
                         const Front fr = front_load(c, p, t8.tw);
                         const uint32_t tl5 = tail_load(c, p);
@@ -609,8 +609,8 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
                         const Front fr = front_load(c, p, t8.tw);
                         const uint32_t tl5 = tail_load(c, p);
                         cand_keys<false>(c, p, t8, k);
-                        const Slot s0 = slot_load(&P.slots[scan2_slot_hash(k.x, 0, P.slot_shift, P.slot_seed)]);
-                        const Slot s1 = slot_load(&P.slots[scan2_slot_hash(k.x, 1, P.slot_shift, P.slot_seed)]);
+                        const Slot s0 = slot_load(&P.slots[scan2_pair_slot(k.x, 0, P.slot_shift, P.slot_seed)]);
+                        const Slot s1 = slot_load(&P.slots[scan2_pair_slot(k.x, 1, P.slot_shift, P.slot_seed)]);
                         finish_long5(c, o, on, rel, k, s0, s1, fr, tl5, dfr);
                     }
                 }

@@ -15,6 +15,8 @@
 // No MFMA: boolean algebra on bit masks; LDS- and latency-bound.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "gft_kernels.hpp"
 
 namespace gft {
@@ -49,14 +51,23 @@ constexpr uint32_t kNoSlot = 0xFFFFFFFFu;      // pair that never matches: the e
 constexpr uint32_t kUnitsPerLaneMode = 8;      // documents with at least this many units: one unit per lane
 
 __device__ __forceinline__ int64_t wave_min_i64(int64_t v) {
-#pragma unroll
-    for (int s = 32; s; s >>= 1) {
-        const int64_t o = __shfl_xor(v, s, 64);
-        v = o < v ? o : v;
-    }
-    // the same value in every lane: tell the compiler, so that what is derived from it stays in scalar registers
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
-    return (int64_t)(((uint64_t)hi << 32) | lo);
+    // Every caller's values are match positions (32 bits, below 2^32 - 1: a document is at most 4 GiB - 1 bytes) or INT64_MAX
+    // ("none"): the reduction runs on 32 bits with DPP moves -- running minimum along the four rows of 16 lanes, row results
+    // broadcast into the rows behind them, lane 63 ends up with the minimum of all -- instead of twelve xor shuffles through
+    // the LDS permute network (round 3), which cost as much as the loads they follow
+    uint32_t x = v == INT64_MAX ? 0xFFFFFFFFu : (uint32_t)v;
+    auto step = [](uint32_t y, auto ctrl, auto rows) {
+        const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)y, decltype(ctrl)::value, decltype(rows)::value, 0xF, false);
+        return o < y ? o : y;
+    };
+    x = step(x, std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xF>{});      // row_shr:1
+    x = step(x, std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xF>{});      // row_shr:2
+    x = step(x, std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xF>{});      // row_shr:4
+    x = step(x, std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xF>{});      // row_shr:8
+    x = step(x, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xA>{});      // row_bcast:15 -> rows 1 and 3
+    x = step(x, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xC>{});      // row_bcast:31 -> rows 2 and 3
+    const uint32_t m = __builtin_amdgcn_readlane(x, 63);
+    return m == 0xFFFFFFFFu ? INT64_MAX : (int64_t)m;
 }
 __device__ __forceinline__ int64_t readlane_i64(int64_t v, uint32_t l) {
     const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, l), hi = __builtin_amdgcn_readlane((uint32_t)((uint64_t)v >> 32), l);
@@ -109,32 +120,27 @@ __device__ int64_t wave_succ_min(const DocHits& M, uint32_t my_slot, int64_t my_
             ub++;
         }
         int64_t sofar = wave_min_i64(best);
-        // ... then the units behind it, one per lane, 64 at a time
+        // ... then the units behind it, EIGHT at a time, eight lanes per unit, eight of a unit's matches in flight per lane: a
+        // term of a rule set recurs every few units, so the answer is in the first step or two -- and a step is a unit's
+        // matches / 64 round trips, not a unit's matches / 8 as with one unit per lane (round 3: 13 000 cycles per query of the
+        // reference benchmark's 45-term chain, `profiles/r4_c1_solver_phase_clocks.txt`; the chain IS the call's time)
         while (ub < M.u1) {
             const int64_t next_lo = (int64_t)((ub - M.u0) * per);                      // positions of the next unit's slice begin here
             if (sofar != INT64_MAX && next_lo - (int64_t)M.back > sofar) break;
-            const uint64_t u = ub + lane;
+            const uint64_t u = ub + (lane >> 3);
+            const uint32_t member = lane & 7u;
             if (u < M.u1) {
                 const uint64_t s = M.unit_start[u];
                 const uint32_t n = M.unit_count[u];
-                uint32_t i = 0;
-                for (; i + 8 <= n; i += 8) {                     // eight matches in flight per lane (the walk is latency-bound)
+                for (uint32_t i0 = 0; i0 < n; i0 += 64) {
                     uint32_t t[8], p[8];
 #pragma unroll
-                    for (int q = 0; q < 8; q++) { t[q] = M.term[s + i + q]; p[q] = M.pos[s + i + q]; }
+                    for (int q = 0; q < 8; q++) { const uint32_t i = i0 + 8 * q + member; t[q] = i < n ? M.term[s + i] : kNoSlot - 1; p[q] = i < n ? M.pos[s + i] : 0u; }
 #pragma unroll
                     for (int q = 0; q < 8; q++) test(t[q], p[q]);
                 }
-                for (; i + 4 <= n; i += 4) {
-                    uint32_t t[4], p[4];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) { t[q] = M.term[s + i + q]; p[q] = M.pos[s + i + q]; }
-#pragma unroll
-                    for (int q = 0; q < 4; q++) test(t[q], p[q]);
-                }
-                for (; i < n; i++) test(M.term[s + i], M.pos[s + i]);
             }
-            ub += 64;
+            ub += 8;
             sofar = wave_min_i64(best);
         }
     } else {

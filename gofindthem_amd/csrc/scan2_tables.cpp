@@ -49,30 +49,64 @@ void build_scan2_tables(const AcTables& ac, Scan2Tables& t) {
     };
     // ... and, among windows of similar cost, one that no other term has taken: a bucket with a single term is verified
     // in the same trip that finds it, the entries of a shared bucket need another round of loads
+    // ... and one whose PAIR of the bucket table still has room: a key's two candidate slots are the two slots of one 64-byte
+    // pair (gft_kernels.hpp scan2_pair_slot), a pair holds two keys, and no key lives anywhere else -- so a window whose pair
+    // is full is not a choice.  Terms of exactly four bytes have one window; they are placed first.  Returns false when some
+    // term is left without a window (the caller tries another seed, then a larger table).
     std::unordered_map<uint32_t, uint32_t> taken;                // window key -> terms anchored there so far
-    auto pick_off = [&](const std::string& s) -> uint32_t {
-        const uint32_t L = (uint32_t)s.size();
-        double cost[kScan2MaxOff + 1], best_cost = 0;
-        uint32_t n = 0;
-        for (uint32_t off = 0; off <= kScan2MaxOff && off + kWin <= L; off++, n++) {
-            const uint32_t L1 = L - off;
-            double w = 0, f = 0;
-            for (uint32_t i = L1 - kWin; i < L1; i++) w += logp[ac.byte_class[(uint8_t)s[i]]];
-            for (uint32_t i = 0; i < 3 && i + kWin < L1; i++) f += logp[ac.byte_class[(uint8_t)s[L1 - kWin - 1 - i]]];
-            cost[off] = std::exp(w) * (1.0 + 3.0 * std::max(std::exp(f), 1.0 / 32));
-            if (off == 0 || cost[off] < best_cost) best_cost = cost[off];
-        }
-        uint32_t best = 0;
-        double best_eff = 0;
-        for (uint32_t off = 0; off < n; off++) {
-            auto it = taken.find(window_key(s, L - off));
-            // sharing a bucket is worth avoiding unless the free window is several times more frequent in text
-            const double eff = cost[off] * (it == taken.end() ? 1.0 : 4.0) * (off == 0 ? 0.999 : 1.0);
-            if (off == 0 || eff < best_eff) { best = off; best_eff = eff; }
-        }
-        taken[window_key(s, L - best)]++;
-        return best;
+    std::vector<uint8_t> pair_keys;                              // keys per pair of the table being planned
+    std::vector<uint32_t> off_of(ac.terms.size(), 0);
+    auto plan_offsets = [&](uint32_t lg, uint32_t seed) -> bool {
+        taken.clear();
+        pair_keys.assign((size_t)1 << (lg - 1), 0);
+        const uint32_t shift = 32 - lg;
+        auto pick_off = [&](const std::string& s, uint32_t* out) -> bool {
+            const uint32_t L = (uint32_t)s.size();
+            double cost[kScan2MaxOff + 1];
+            uint32_t n = 0;
+            for (uint32_t off = 0; off <= kScan2MaxOff && off + kWin <= L; off++, n++) {
+                const uint32_t L1 = L - off;
+                double w = 0, f = 0;
+                for (uint32_t i = L1 - kWin; i < L1; i++) w += logp[ac.byte_class[(uint8_t)s[i]]];
+                for (uint32_t i = 0; i < 3 && i + kWin < L1; i++) f += logp[ac.byte_class[(uint8_t)s[L1 - kWin - 1 - i]]];
+                cost[off] = std::exp(w) * (1.0 + 3.0 * std::max(std::exp(f), 1.0 / 32));
+            }
+            bool any = false;
+            uint32_t best = 0;
+            double best_eff = 0;
+            for (uint32_t off = 0; off < n; off++) {
+                const uint32_t key = window_key(s, L - off);
+                auto it = taken.find(key);
+                if (it == taken.end() && pair_keys[scan2_pair_slot(key, 0, shift, seed) >> 1] >= 2) continue;   // (its pair is full)
+                // sharing a bucket is worth avoiding unless the free window is several times more frequent in text
+                const double eff = cost[off] * (it == taken.end() ? 1.0 : 4.0) * (off == 0 ? 0.999 : 1.0);
+                if (!any || eff < best_eff) { best = off; best_eff = eff; any = true; }
+            }
+            if (!any) return false;
+            const uint32_t key = window_key(s, L - best);
+            if (taken[key]++ == 0) pair_keys[scan2_pair_slot(key, 0, shift, seed) >> 1]++;
+            *out = best;
+            return true;
+        };
+        for (int pass = 0; pass < 2; pass++)                     // the terms without a choice first
+            for (size_t id = 0; id < ac.terms.size(); id++) {
+                const std::string& s = ac.terms[id];
+                if (s.size() < kWin || (s.size() == kWin) != (pass == 0)) continue;
+                if (!pick_off(s, &off_of[id])) return false;
+            }
+        return true;
     };
+    uint32_t n_long = 0;
+    for (const auto& s : ac.terms) n_long += s.size() >= kWin;
+    uint32_t plan_lg = 10;
+    while ((1ull << plan_lg) < 2ull * n_long) plan_lg++;         // load <= 0.5 (as the two-choice placement before it)
+    uint32_t plan_seed = 0;
+    for (uint32_t attempt = 0;; attempt++) {
+        if (attempt && attempt % 8 == 0) plan_lg++;              // eight seeds per size, then the next size
+        if (plan_lg > 28) { t.why_not = "bucket table too large"; return; }
+        plan_seed = (attempt % 8) * 0x9E37u;
+        if (plan_offsets(plan_lg, plan_seed)) break;
+    }
     struct Ent { uint32_t term_id, len, off; };   // len = len1: the term up to the end of its window
     std::unordered_map<uint32_t, std::vector<Ent>> buckets;
     buckets.reserve(ac.terms.size() * 2);
@@ -89,7 +123,7 @@ void build_scan2_tables(const AcTables& ac, Scan2Tables& t) {
         const uint32_t L = (uint32_t)s.size();
         if (L == 0) continue;   // the empty keyword never matches
         if (L > kScan2LenMask) { t.why_not = "term longer than 16 MiB"; return; }
-        const uint32_t off = L >= kWin ? pick_off(s) : 0, L1 = L - off;
+        const uint32_t off = L >= kWin ? off_of[id] : 0, L1 = L - off;
         uint32_t tail = 0;      // radix value of the window's classes (the whole term when it is shorter)
         const uint32_t m = std::min(L1, kWin);
         for (uint32_t i = L1 - m; i < L1; i++) tail = tail * kp + ac.byte_class[(uint8_t)s[i]];
@@ -177,31 +211,15 @@ void build_scan2_tables(const AcTables& ac, Scan2Tables& t) {
         }
     }
     {
-        uint32_t lg = 10;
-        while ((1ull << lg) < 2 * items.size()) lg++;        // load <= 0.5 (two choices place that easily)
-        for (uint32_t attempt = 0;; attempt++) {
-            // eight seeds per size, then the next size
-            if (attempt && attempt % 8 == 0) lg++;
-            if (lg > 28) { t.why_not = "bucket table too large"; return; }
-            t.slot_shift = 32 - lg;
-            t.slot_seed = (attempt % 8) * 0x9E37u;
-            t.slots.assign((size_t)1 << lg, Scan2Slot{kScan2EmptyKey, 0, 0, {0, 0, 0, 0, 0}});
-            uint32_t rng = 0x2545F491u;
-            bool ok = true;
-            for (const Scan2Slot& it : items) {
-                Scan2Slot cur = it;
-                bool placed = false;
-                for (int kick = 0; kick < 1000 && !placed; kick++) {
-                    const uint32_t h0 = scan2_slot_hash(cur.key, 0, t.slot_shift, t.slot_seed),
-                                   h1 = scan2_slot_hash(cur.key, 1, t.slot_shift, t.slot_seed);
-                    if (t.slots[h0].key == kScan2EmptyKey) { t.slots[h0] = cur; placed = true; break; }
-                    if (t.slots[h1].key == kScan2EmptyKey) { t.slots[h1] = cur; placed = true; break; }
-                    rng = rng * 1664525u + 1013904223u;
-                    std::swap(cur, t.slots[(rng >> 16) & 1 ? h1 : h0]);
-                }
-                if (!placed) { ok = false; break; }
-            }
-            if (ok) break;
+        // every key into its pair (plan_offsets made sure that no pair gets a third)
+        t.slot_shift = 32 - plan_lg;
+        t.slot_seed = plan_seed;
+        t.slots.assign((size_t)1 << plan_lg, Scan2Slot{kScan2EmptyKey, 0, 0, {0, 0, 0, 0, 0}});
+        for (const Scan2Slot& it : items) {
+            const uint32_t p0 = scan2_pair_slot(it.key, 0, t.slot_shift, t.slot_seed);
+            if (t.slots[p0].key == kScan2EmptyKey) t.slots[p0] = it;
+            else if (t.slots[p0 + 1].key == kScan2EmptyKey) t.slots[p0 + 1] = it;
+            else { t.why_not = "bucket pair overflow (internal)"; return; }
         }
     }
     // ---- fingerprint table: one cell per term (gft_kernels.hpp) ---------------------------------------------------------

@@ -49,7 +49,7 @@ struct Scan2Tables {
     std::vector<uint32_t> shorts_packed;   // 3 words per record: term_id | len << 28, longest first, 0 = none
     std::vector<uint8_t> fpt;        // [kScan2FptSize] (fpt_lg == 0, LDS) or [2^fpt_lg] (global)
     uint32_t fpt_lg = 0;
-    uint32_t slot_shift = 0;         // slot index = scan2_slot_hash(key, 0 or 1, slot_shift, slot_seed)
+    uint32_t slot_shift = 0;         // slot index = scan2_pair_slot(key, 0 or 1, slot_shift, slot_seed): the two slots of one 64-byte pair
     uint32_t slot_seed = 0;
     std::vector<Scan2Slot> slots;    // power-of-two table, terms of length >= 4 only
     std::vector<Scan2Slot> more;     // entry lists of multi-term buckets

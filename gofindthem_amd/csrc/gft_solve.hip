@@ -107,40 +107,28 @@ __device__ int64_t wave_succ_min(const DocHits& M, uint32_t my_slot, int64_t my_
         const uint64_t per = M.per;                                                   // (all but the last slice have this size)
         const uint64_t k0 = thmin < 0 ? 0 : (uint64_t)thmin / per;                    // the slice that holds position thmin
         uint64_t ub = M.u0 + (k0 < M.u1 - M.u0 ? k0 : M.u1 - M.u0 - 1);
-        {   // the first unit, strided over all lanes: one round trip for a unit of a few hundred matches
-            const uint64_t s = M.unit_start[ub];
-            const uint32_t n = M.unit_count[ub];
-            for (uint32_t i0 = 0; i0 < n; i0 += 64 * 4) {
-                uint32_t t[4], p[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) { const uint32_t i = i0 + 64 * q + lane; t[q] = i < n ? M.term[s + i] : kNoSlot - 1; p[q] = i < n ? M.pos[s + i] : 0u; }
-#pragma unroll
-                for (int q = 0; q < 4; q++) test(t[q], p[q]);
-            }
-            ub++;
-        }
-        int64_t sofar = wave_min_i64(best);
-        // ... then the units behind it, EIGHT at a time, eight lanes per unit, eight of a unit's matches in flight per lane: a
-        // term of a rule set recurs every few units, so the answer is in the first step or two -- and a step is a unit's
+        int64_t sofar = INT64_MAX;
+        // From that unit on FOUR units at a time, sixteen lanes per unit, four of a unit's matches in flight per lane: a term
+        // of a rule set recurs every few units, so the answer is in the first step or the second -- and a step is a unit's
         // matches / 64 round trips, not a unit's matches / 8 as with one unit per lane (round 3: 13 000 cycles per query of the
         // reference benchmark's 45-term chain, `profiles/r4_c1_solver_phase_clocks.txt`; the chain IS the call's time)
         while (ub < M.u1) {
             const int64_t next_lo = (int64_t)((ub - M.u0) * per);                      // positions of the next unit's slice begin here
             if (sofar != INT64_MAX && next_lo - (int64_t)M.back > sofar) break;
-            const uint64_t u = ub + (lane >> 3);
-            const uint32_t member = lane & 7u;
+            const uint64_t u = ub + (lane >> 4);
+            const uint32_t member = lane & 15u;
             if (u < M.u1) {
                 const uint64_t s = M.unit_start[u];
                 const uint32_t n = M.unit_count[u];
                 for (uint32_t i0 = 0; i0 < n; i0 += 64) {
-                    uint32_t t[8], p[8];
+                    uint32_t t[4], p[4];
 #pragma unroll
-                    for (int q = 0; q < 8; q++) { const uint32_t i = i0 + 8 * q + member; t[q] = i < n ? M.term[s + i] : kNoSlot - 1; p[q] = i < n ? M.pos[s + i] : 0u; }
+                    for (int q = 0; q < 4; q++) { const uint32_t i = i0 + 16 * q + member; t[q] = i < n ? M.term[s + i] : kNoSlot - 1; p[q] = i < n ? M.pos[s + i] : 0u; }
 #pragma unroll
-                    for (int q = 0; q < 8; q++) test(t[q], p[q]);
+                    for (int q = 0; q < 4; q++) test(t[q], p[q]);
                 }
             }
-            ub += 8;
+            ub += 4;
             sofar = wave_min_i64(best);
         }
     } else {

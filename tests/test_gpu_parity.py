@@ -332,6 +332,24 @@ def test_table_export_import_roundtrip(eng, scan_kernel):
             # accepted: then the word was not an index (text bytes, filter bits ...) and the scan must still be in bounds
             e2.scan(text, off, fold=True)
         assert n_bad >= 2
+        # relations BETWEEN the tables: the suffix-window set's class count and class map must be the automaton's
+        # (build_scan5_tables indexes its counters by the automaton's classes), a bucket key must be four classes, and a key
+        # must sit in its own pair of the bucket table
+        def kp_offset(b):
+            at = 20
+            n_terms = struct.unpack_from("<Q", b, at)[0]; at += 8
+            for _ in range(n_terms):
+                at += 8 + struct.unpack_from("<Q", b, at)[0]
+            at += 4 + 256 + 4 + 4                          # n_classes, byte_class, n_states, max_term_len
+            for width in (4, 4, 4, 4, 4, 4, 4, 1):         # delta, out_term, out_link, term_len, depth, fail, child_begin, in_class
+                at += 8 + width * struct.unpack_from("<Q", b, at)[0]
+            return at + 4                                  # behind Scan2Tables::supported
+        at = kp_offset(blob)
+        kp = struct.unpack_from("<I", blob, at)[0]
+        assert 2 <= kp <= 64 and struct.unpack_from("<I", blob, at - 4)[0] == 1, "blob layout changed: adapt kp_offset"
+        for forged_kp in (kp - 1, kp + 1, 2):
+            with pytest.raises(GftError, match="inconsistent"):
+                e2.import_tables(resealed(blob[:at] + struct.pack("<I", forged_kp) + blob[at + 4:]))
         e2.import_tables(blob)
         # a refused blob leaves the engine as it was
         with pytest.raises(GftError):

@@ -187,7 +187,6 @@ struct gft_engine {
         uint64_t* rb = nullptr; hipEvent_t ev = nullptr;
     };
     Pending pend[2];
-    bool ctl_zeroed = false;               // the control block's counters are zero already (k_publish_ctl of the batch before)
     unsigned pend_head = 0, pend_count = 0;
     DevBuf d_order, d_blk_class, d_wave_blk;            // evaluation order of the programs (gft_set_programs)
     uint32_t last_solve_group_docs = 64;   // documents per solver group of the last launch (0 = presence matrix in HBM)
@@ -556,9 +555,7 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
 
     // 1. work units
     HIP_TRY(e->d_ctl.ensure(64), "control alloc");
-    // flag, cursor, match count, non-ASCII flag (a pipelined batch before this one has cleared them already: k_publish_ctl)
-    if (!e->ctl_zeroed) HIP_TRY(hipMemsetAsync(e->d_ctl.p, 0, 32, st), "memset");
-    e->ctl_zeroed = false;
+    HIP_TRY(hipMemsetAsync(e->d_ctl.p, 0, 32, st), "memset");     // flag, cursor, match count, non-ASCII flag
     HIP_TRY(e->d_unit_cnt.ensure(n_docs * 4), "unit alloc");
     HIP_TRY(e->d_unit_base.ensure((n_docs + 1) * 8), "unit alloc");
     HIP_TRY(e->d_partial.ensure(scan_partials_needed(n_docs) * 8), "unit alloc");
@@ -946,7 +943,6 @@ int refine_nonascii(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_
     uint32_t flag = 0;
     {
         ProfScope ps(e, "aux");
-        e->ctl_zeroed = false;                                   // (the check writes its verdict into the control block)
         HIP_TRY(launch_fold_safe(d_text, e->last_text_lo, e->last_text_hi, d_doc_off, n_docs, e->d_ctl.as<uint32_t>() + 6, e->stream), "fold check");
     }
     HIP_TRY(hipMemcpyAsync(&flag, e->d_ctl.as<uint32_t>() + 6, 4, hipMemcpyDeviceToHost, e->stream), "readback");
@@ -2184,9 +2180,7 @@ int gft_process_device_begin(gft_engine* e, const uint8_t* d_text_blob, const ui
     if (!pb.rb) HIP_TRY(hipHostMalloc((void**)&pb.rb, 64, hipHostMallocDefault), "pinned alloc");
     if (!pb.ev) HIP_TRY(hipEventCreateWithFlags(&pb.ev, hipEventDisableTiming), "event");
     pb.single = e->deferred_single; pb.n_docs_cap = e->deferred_n_docs; pb.unit_cap = e->deferred_unit_cap; pb.static_slabs = e->last_static_slabs;
-    // (the device writes the block into the pinned slot itself and clears it for the next batch: no copy command, no memset)
-    HIP_TRY(launch_publish_ctl(e->d_ctl.as<uint64_t>(), pb.rb, true, e->stream), "readback");
-    e->ctl_zeroed = true;
+    HIP_TRY(hipMemcpyAsync(pb.rb, e->d_ctl.p, 7 * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream), "readback");
     HIP_TRY(hipEventRecord(pb.ev, e->stream), "event");
     e->pend_count++;
     return GFT_OK;

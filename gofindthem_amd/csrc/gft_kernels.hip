@@ -636,23 +636,6 @@ hipError_t launch_pack_ctl(const uint64_t* d_unit_base, const uint64_t* d_doc_of
     return hipGetLastError();
 }
 
-// The control block of a batch -> pinned host memory, by the device itself (seven 8-byte stores over the host link behind the
-// batch's last kernel) instead of an asynchronous copy: a copy command on the stream costs more than this launch and the next
-// batch's kernels queue behind it.  zero: the block's first 32 bytes are cleared for the next batch (its memset, saved).
-__global__ void __launch_bounds__(64) k_publish_ctl(uint64_t* __restrict__ ctl, uint64_t* __restrict__ host_dst, int zero) {
-    const uint32_t i = threadIdx.x;
-    if (i < 7) {
-        const uint64_t v = ctl[i];
-        __hip_atomic_store(&host_dst[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (zero && i < 4) ctl[i] = 0;
-    }
-    __threadfence_system();
-}
-hipError_t launch_publish_ctl(uint64_t* d_ctl, uint64_t* host_dst, bool zero, hipStream_t st) {
-    k_publish_ctl<<<dim3(1), dim3(64), 0, st>>>(d_ctl, host_dst, zero ? 1 : 0);
-    return hipGetLastError();
-}
-
 hipError_t launch_patch_words(uint32_t* d_words, const uint64_t* d_idx, const uint32_t* d_clr, const uint32_t* d_set, uint64_t n, hipStream_t st) {
     if (!n) return hipSuccess;
     k_patch_words<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(d_words, d_idx, d_clr, d_set, n);

@@ -51,6 +51,23 @@ def test_no_device_fails_loudly():
     assert ei.value.code == _lib.GFT_E_HIP
 
 
+def test_loader_brings_torch_in_first_so_that_one_hip_runtime_is_mapped():
+    """libgft.so links /opt/rocm's libamdhip64, PyTorch ships its own copy of the same soname; a process that
+    mapped libgft.so BEFORE torch has carried two HIP runtimes.  The product loader imports torch
+    first when it is importable -- checked in a fresh process that never names torch itself."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from gofindthem_amd import _lib\n"
+            "assert 'torch' not in sys.modules\n"
+            "_lib.load()\n"
+            "libs = _lib._mapped_hip_runtimes()\n"
+            "print('torch' in sys.modules, len(libs))\n") % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split() == ["True", "1"], (out.stdout, out.stderr[-500:])
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     """... and without libgft.so the package does not fall back to anything either"""
     monkeypatch.setattr(_lib, "_LIB", None)

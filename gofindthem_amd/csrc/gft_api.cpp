@@ -807,9 +807,9 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
                         (double)t[4] / n_units, (double)t[5] / n_units, (double)t[6] / n_units, (double)t[7] / n_units, (double)t[8] / n_units,
                         (double)t[9] / n_units, (double)t[10] / n_units, (double)t[11] / n_units);
             else
-            fprintf(stderr, "[gft scan debug] wave cycles per unit: first bytes %.0f, filter %.0f, list %.0f, stage A %.0f, stage B %.0f, flush %.0f, unit record %.0f\n",
-                    (double)t[4] / n_units, (double)t[5] / n_units, (double)t[6] / n_units, (double)t[7] / n_units, (double)t[8] / n_units,
-                    (double)t[9] / n_units, (double)t[11] / n_units);
+            fprintf(stderr, "[gft scan debug] wave cycles per unit: first bytes %.0f, filter %.0f, list %.0f, stage A %.0f (scan5: trips %.0f + stage-B issue and short-term trips %.0f), stage B %.0f, flush %.0f, unit record %.0f\n",
+                    (double)t[4] / n_units, (double)t[5] / n_units, (double)t[6] / n_units, (double)(t[7] + t[10]) / n_units, (double)t[10] / n_units, (double)t[7] / n_units,
+                    (double)t[8] / n_units, (double)t[9] / n_units, (double)t[11] / n_units);
             double sum = 0;
             for (int k = 4; k < 12; k++) sum += (double)t[k];
             if (t[13]) fprintf(stderr, "[gft scan debug] %llu waves: mean %.0f cycles in all, the slowest %.0f (+%.1f %%)\n", (unsigned long long)t[13],

@@ -34,9 +34,6 @@ namespace {
 #include "gft_scan2_dev.hpp"
 #include "gft_foldsafe_dev.hpp"
 
-#ifndef GFT_S5_R32
-#define GFT_S5_R32 1
-#endif
 constexpr int kWays5 = 2;           // stage A: candidates a lane works on at once (3 / 4 / 6 measured in round 4: + 1 / + 3 % / slower)
 
 struct Ctx5 {
@@ -325,145 +322,12 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
         const uint32_t nborder = un.lo < kScan2MaxOff ? un.lo : kScan2MaxOff;
         const uint32_t ubase = un.lo - kScan2MaxOff;               // candidate lists hold p - ubase (may wrap; p never does)
         const uint32_t own = un.hi - un.lo;
-#if !GFT_S5_R32
         const uint32_t C = ((own + 63) / 64 + 3) & ~3u;            // bytes per lane (multiple of 4, <= 128)
         const uint32_t my_lo = un.lo + lane * C;
         const uint32_t my_hi = my_lo + C < un.hi ? my_lo + C : un.hi;
         const uint32_t nvalid = my_lo < un.hi ? my_hi - my_lo : 0;
-#endif
         Ctx5 o{fifo, P.s5_fifo_cap, 0, 0, false, false, 0, P.s5_term_bits, un.lo - P.s5_pos_bias};
 
-#if GFT_S5_R32
-        // ---- FILTER: rounds of 2 KiB, 32 bytes per lane -------------------------------------------------------------------
-        // Round r is the unit's bytes [2048 r, + 2048); lane k filters [2048 r + 32 k, + 32) as two pieces of sixteen: the wave's
-        // two loads of a round read 2 KiB of consecutive text -- sixteen 128-byte lines, each requested once, the second load
-        // hitting what the first brought -- where a lane that owns one contiguous stretch of the unit spreads every load over
-        // 32 lines (72 L1 -> L2 requests per 4 KB document for 32 lines of text).  A round is one mask word, so the candidate
-        // list is built as before (a flag loop per word); the three bytes in front of a lane's first piece are the lane before's
-        // last ones: its last dword comes over by DPP (wave_shr:1), lane 0 takes the last dword of lane 63 of the round before
-        // (`carry`; the four bytes in front of the unit at first).  The partial round of `tail` bytes gives every lane
-        // tnd = ceil(tail / 256) dwords: lane k owns [2048 n_full + 4 tnd k, + 4 tnd).
-        const uint32_t n_full = own >> 11, tail = own & 2047u;
-        const uint32_t tnd = (tail + 255u) >> 8;                   // dwords a lane owns in the partial round (0: there is none)
-        const uint32_t n_rounds = n_full + (tail ? 1u : 0u);        // <= 4
-        const uint32_t tstride = tnd * 4;
-        uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
-        if (own) {
-            const uint8_t* ub = c.dbase + un.lo;                    // the unit's first byte
-            uint32_t carry = 0;
-            if (doc_abs + un.lo >= 4) carry = load_u32_unaligned(ub - 4);
-            else for (uint32_t i = 1; i <= 3 && i <= doc_abs + un.lo; i++) carry |= (uint32_t)ub[-(int)i] << (32 - 8 * i);
-            // (every lane loads in every round -- a lane without bytes in the partial round reads the round's first ones and
-            // ignores them: behind an exec-masked load the compiler cannot count the requests in flight)
-            auto round_src = [&](uint32_t r) -> const uint8_t* {
-                if (r < n_full) return ub + r * 2048u + lane * 32u;
-                const uint32_t at = lane * tstride;
-                return ub + n_full * 2048u + (at < tail ? at : 0u);
-            };
-            const uint8_t* rs = round_src(0);
-            U128u na = *reinterpret_cast<const U128u*>(rs), nb = *reinterpret_cast<const U128u*>(rs + 16);
-            mark(0);
-            uint32_t acc = 0, njobs = 0, hib = 0;                   // hib: OR of the lane's text (a byte >= 0x80 anywhere?)
-            const bool want_fold = P.fold && P.nonascii;
-            const uint32_t pad_g = P.s5_pad_g;
-            for (uint32_t r = 0; r < n_rounds; r++) {
-                const uint32_t wa[4] = {na.x, na.y, na.z, na.w}, wb[4] = {nb.x, nb.y, nb.z, nb.w};
-                const bool full = r < n_full;                       // wave-uniform
-                const uint32_t nda = full ? 4u : (tnd < 4u ? tnd : 4u), ndb = full ? 4u : (tnd > 4u ? tnd - 4u : 0u);   // dwords of the two pieces
-                const uint32_t at = full ? r * 2048u + lane * 32u : n_full * 2048u + lane * tstride;   // the lane's first byte (unit relative)
-                const uint32_t here = at < own ? (own - at < 4u * (nda + ndb) ? own - at : 4u * (nda + ndb)) : 0u;
-                if (r + 1 < n_rounds) {
-                    rs = round_src(r + 1);
-                    na = *reinterpret_cast<const U128u*>(rs); nb = *reinterpret_cast<const U128u*>(rs + 16);
-                }
-                // the dword in front of the lane's bytes: the lane before's last one
-                const uint32_t nlast = nda + ndb - 1u;              // (wave-uniform index of the lane's last dword)
-                const uint32_t last = nlast < 4u ? (nlast == 0 ? wa[0] : nlast == 1 ? wa[1] : nlast == 2 ? wa[2] : wa[3])
-                                                 : (nlast == 4 ? wb[0] : nlast == 5 ? wb[1] : nlast == 6 ? wb[2] : wb[3]);
-                const uint32_t hist = (uint32_t)__builtin_amdgcn_update_dpp((int)carry, (int)last, 0x138, 0xF, 0xF, false);   // wave_shr:1
-                carry = __builtin_amdgcn_readlane(last, 63);
-                uint32_t h1 = lgrp[hist >> 24], h2 = lgrp[(hist >> 16) & 0xFF], h3 = lgrp[(hist >> 8) & 0xFF];   // g[j-1], g[j-2], g[j-3]
-                if (r == 0 && un.lo < 3 && lane == 0) {             // in front of the document: the pad group
-                    if (un.lo < 1) h1 = pad_g;
-                    if (un.lo < 2) h2 = pad_g;
-                    h3 = pad_g;
-                }
-                uint32_t pq = mad24s(h2, G, h1);
-                // one piece of up to four dwords.  Probe at byte 0 of a dword: 3-gram (h2, h1, c0); the window that ends there
-                // has h3 in front, the window that ends at byte 1 has c1 behind.  Probe at byte 2: 3-gram (c0, c1, c2), h1 in
-                // front, c3 behind
-                auto piece = [&](const uint32_t (&w)[4], uint32_t nd, uint32_t pat, uint32_t pvalid) {
-                    hib |= pvalid ? (w[0] | w[1]) | (w[2] | w[3]) : 0u;   // (may take in a few bytes behind the unit: conservative)
-                    if constexpr (SG) {
-                        if (want_fold && !told_nonascii)
-                            fold_job_push(pvalid && (((w[0] | w[1]) | (w[2] | w[3])) & 0x80808080u) != 0, pat, cand, P.cand_cap, njobs);
-                    }
-                    if (nd >= 4) {                               // a whole piece: sixteen lookups, then eight probes in flight together
-                        uint32_t cc[19];                         // cc[3 + i] = group of byte i; cc[0..2] = h3, h2, h1
-                        cc[0] = h3; cc[1] = h2; cc[2] = h1;
-#pragma unroll
-                        for (int i = 0; i < 16; i++) cc[3 + i] = lgrp[(w[i >> 2] >> (8 * (i & 3))) & 0xFF];
-                        uint32_t xk[8];
-                        xk[0] = mad24s(pq, G, cc[3]);
-#pragma unroll
-                        for (int t = 1; t < 8; t++) xk[t] = mad24s(mad24s(cc[1 + 2 * t], G, cc[2 + 2 * t]), G, cc[3 + 2 * t]);
-                        u32x2 fk[8];
-#pragma unroll
-                        for (int t = 0; t < 8; t++) fk[t] = ldual[xk[t]];
-#pragma unroll
-                        for (int t = 0; t < 8; t++) {
-                            acc = __builtin_amdgcn_alignbit(fk[t].x >> cc[2 * t], acc, 1);         // window ends at byte 2t: cc[2t] stands in front
-                            acc = __builtin_amdgcn_alignbit(fk[t].y >> cc[4 + 2 * t], acc, 1);     // ... at byte 2t + 1: that byte's group behind
-                        }
-                        pq = mad24s(cc[17], G, cc[18]);
-                        h3 = cc[16]; h2 = cc[17]; h1 = cc[18];
-                    } else {
-                        auto dword = [&](uint32_t wd) {
-                            const uint32_t c0 = lgrp[wd & 0xFF], c1 = lgrp[(wd >> 8) & 0xFF], c2 = lgrp[(wd >> 16) & 0xFF], c3 = lgrp[wd >> 24];
-                            const uint32_t xa = mad24s(pq, G, c0);
-                            const uint32_t xb = mad24s(mad24s(c0, G, c1), G, c2);
-                            const u32x2 fa = ldual[xa], fb = ldual[xb];
-                            acc = __builtin_amdgcn_alignbit(fa.x >> h3, acc, 1);
-                            acc = __builtin_amdgcn_alignbit(fa.y >> c1, acc, 1);
-                            acc = __builtin_amdgcn_alignbit(fb.x >> h1, acc, 1);
-                            acc = __builtin_amdgcn_alignbit(fb.y >> c3, acc, 1);
-                            pq = mad24s(c2, G, c3);
-                            h3 = c1; h2 = c2; h1 = c3;
-                        };
-                        dword(w[0]);
-                        if (nd >= 2) dword(w[1]);
-                        if (nd >= 3) dword(w[2]);
-                    }
-                };
-                piece(wa, nda, at, here != 0);
-                if (ndb) piece(wb, ndb, at + 16, here > 16);
-                const uint32_t nbits = 4u * (nda + ndb);
-                uint32_t v = nbits == 32 ? acc : acc >> (32 - nbits);
-                if (!full) v &= here >= 32 ? ~0u : (1u << here) - 1u;    // positions behind the unit carry garbage flags
-                if (r == 0) m0 = v; else if (r == 1) m1 = v; else if (r == 2) m2 = v; else m3 = v;
-            }
-            // ASCII folding is not strings.ToLower once the text leaves ASCII (finder.go:140-142): the pieces of the lanes that
-            // met a byte >= 0x80 are judged now (gft_foldsafe_dev.hpp; the all-ASCII instantiation does not keep which of a
-            // lane's pieces it was: text that leaves ASCII is the exception for the dictionaries it serves)
-            if (!SG && want_fold && !told_nonascii && __any((hib & 0x80808080u) != 0)) {
-                for (uint32_t r = 0; r < n_rounds; r++)
-                    for (uint32_t h = 0; h < 2; h++) {
-                        const uint32_t at = (r < n_full ? r * 2048u + lane * 32u : n_full * 2048u + lane * tstride) + 16 * h;
-                        const uint32_t span = r < n_full ? 32u : tstride;
-                        fold_job_push((hib & 0x80808080u) != 0 && at < own && 16 * h < span, at, cand, P.cand_cap, njobs);
-                    }
-            }
-            if (njobs && !told_nonascii) {
-                // bit 1: a piece breaks the rule; bit 0: more pieces than the list holds -- the host then checks the text itself
-                uint32_t bits = 1u;
-                if (njobs <= P.cand_cap) {
-                    FOLD_JOB_VARS(fj_);
-                    bits = fold_jobs_begin(P.text, end_v, doc_abs + un.lo, own, un.lo == 0, cand, njobs, FOLD_JOB_PASS(fj_)) || fold_jobs_finish(FOLD_JOB_PASS(fj_)) ? 2u : 0u;
-                }
-                if (bits) { told_nonascii = true; if (lane == 0) atomicOr(P.nonascii, bits); }
-            }
-        }
-#else
         // ---- FILTER -----------------------------------------------------------------------------------------------------
         uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
         if (own) {
@@ -571,7 +435,6 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
             m2 = nvalid >= 96 ? m2 : (nvalid > 64 ? m2 & ((1u << (nvalid - 64)) - 1) : 0);
             m3 = nvalid >= 128 ? m3 : (nvalid > 96 ? m3 & ((1u << (nvalid - 96)) - 1) : 0);
         }
-#endif
         mark(1);
         if (more_units) { abs_n = P.doc_off[un_n.doc]; end_n = P.doc_off[un_n.doc + 1]; }
 
@@ -602,18 +465,6 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
                     if (lane == 0)
                         for (uint32_t i = 0; i < nborder; i++) cand[wpos++] = (uint16_t)(kScan2MaxOff - nborder + i);
                     uint32_t mm[4] = {m0, m1, m2, m3};
-#if GFT_S5_R32
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {                  // mask word k = round k
-                        uint32_t mk = mm[k];
-                        const uint32_t rel = kScan2MaxOff + ((uint32_t)k < n_full ? (uint32_t)k * 2048u + lane * 32u : n_full * 2048u + lane * tstride);
-                        while (mk) {
-                            const uint32_t i = __builtin_ctz(mk);
-                            mk &= mk - 1;
-                            cand[wpos++] = (uint16_t)(rel + i);
-                        }
-                    }
-#else
                     const uint32_t rel = lane * C + kScan2MaxOff;
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
@@ -624,7 +475,6 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
                             cand[wpos++] = (uint16_t)(rel + 32 * k + i);
                         }
                     }
-#endif
                 }
                 wave_lds_sync();
                 // stage A: every flagged position -> LDS-only decisions; short terms are emitted here, positions that may end a
@@ -695,6 +545,7 @@ __global__ void __launch_bounds__(kScan2Threads) k_scan5(const Scan2Params P) {
                     }
                 }
                 wave_lds_sync();
+                mark(6);                                         // (stage A's trips end here; what follows until mark(3) is the short-term trips)
                 // stage B: the survivors, densely packed over the lanes, go to the L2 bucket table.  The first trip's loads -- the
                 // slots its keys name (they came along from stage A) and the text around the positions, the longest single wait
                 // of a unit -- are issued in FRONT of the short-term trips, which touch LDS only, and consumed behind them

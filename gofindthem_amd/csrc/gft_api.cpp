@@ -176,6 +176,7 @@ struct gft_engine {
     int single_streak = 0;
     uint64_t last_static_slabs = 0;        // pool entries the waves of the last scan launch owned from the start (gft_scan2 / 3)
     bool deferred_single = false;          // ... and this one took that path
+    uint32_t ctl_epoch = 1, deferred_epoch = 0;   // k_units_single batches are numbered from 2 (their control-block flags)
     uint64_t deferred_n_docs = 0;
     // gft_process_device_begin / _end: up to two batches enqueued, their read-backs landing in pinned slots of their own
     struct Pending {
@@ -183,7 +184,7 @@ struct gft_engine {
         int rc = 0;
         const uint8_t* d_text = nullptr; const uint64_t* d_doc_off = nullptr; uint64_t n_docs = 0; uint32_t flags = 0;
         uint32_t* d_bitmap = nullptr;
-        bool single = false; uint64_t n_docs_cap = 0, unit_cap = 0, static_slabs = 0;     // deferred_check's view of the launch
+        bool single = false; uint32_t epoch = 0; uint64_t n_docs_cap = 0, unit_cap = 0, static_slabs = 0;     // deferred_check's view of the launch
         uint64_t* rb = nullptr; hipEvent_t ev = nullptr;
     };
     Pending pend[2];
@@ -555,7 +556,6 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
 
     // 1. work units
     HIP_TRY(e->d_ctl.ensure(64), "control alloc");
-    HIP_TRY(hipMemsetAsync(e->d_ctl.p, 0, 32, st), "memset");     // flag, cursor, match count, non-ASCII flag
     HIP_TRY(e->d_unit_cnt.ensure(n_docs * 4), "unit alloc");
     HIP_TRY(e->d_unit_base.ensure((n_docs + 1) * 8), "unit alloc");
     HIP_TRY(e->d_partial.ensure(scan_partials_needed(n_docs) * 8), "unit alloc");
@@ -563,6 +563,14 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
     // small batches from host memory (a single ProcessText / FindSubstrings call is the reference's own shape): the unit
     // table is a few entries, computed here and uploaded instead of five kernel launches and a synchronising read-back
     const bool host_units = h_doc_off != nullptr && n_docs <= kHostUnitDocs;
+    // The batch before was one unit per document: this one gets its unit table from ONE launch on that assumption
+    // (k_units_single) instead of count + prefix sum + fill + clamp; deferred_check learns whether it held.  That launch
+    // also clears the control block (its two flags are raised to the batch's EPOCH, a number no earlier batch wrote there,
+    // so they need no clearing): one node less on the stream of every batch
+    bool units_single = !host_units && defer_ok && !need_csr && e->single_streak >= 2 && e->pool_cap > 0 &&
+                        std::min(std::min(e->d_units.cap / sizeof(Unit), e->d_unit_start.cap / 8), e->d_unit_count.cap / 4) >= n_docs;
+    if (units_single && ++e->ctl_epoch < 2) { e->ctl_epoch = 1; units_single = false; }      // (wrapped: this batch the general way)
+    if (!units_single) HIP_TRY(hipMemsetAsync(e->d_ctl.p, 0, 32, st), "memset");     // flag, cursor, match count, non-ASCII flag
     std::vector<uint64_t> hub;
     std::vector<Unit> hun;
     struct DrainIf { gft_engine* e; bool on; ~DrainIf() { if (on && e->stream) (void)hipStreamSynchronize(e->stream); } } drain_units{e, host_units};
@@ -583,15 +591,12 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
         }
         n_units = hub[n_docs]; text_lo = h_doc_off[0]; text_hi = h_doc_off[n_docs];
         HIP_TRY(hipMemcpyAsync(e->d_unit_base.p, hub.data(), (n_docs + 1) * 8, hipMemcpyHostToDevice, st), "unit upload");
-    } else if (defer_ok && !need_csr && e->single_streak >= 2 && e->pool_cap > 0 &&
-               std::min(std::min(e->d_units.cap / sizeof(Unit), e->d_unit_start.cap / 8), e->d_unit_count.cap / 4) >= n_docs) {
-        // The batch before was one unit per document: this one gets its unit table from ONE launch on that assumption
-        // (k_units_single) instead of count + prefix sum + fill + clamp; deferred_check learns whether it held.
+    } else if (units_single) {
         ProfScope ps(e, "aux");
         HIP_TRY(launch_units_single(d_doc_off, n_docs, unit_max, e->d_units.as<Unit>(), e->d_unit_base.as<uint64_t>(),
-                                    e->d_ctl.as<uint32_t>(), st), "unit table");
+                                    e->d_ctl.as<uint32_t>(), e->ctl_epoch, st), "unit table");
         n_units = n_docs; text_lo = 0; text_hi = ~0ull;
-        e->deferred = true; e->deferred_single = true;
+        e->deferred = true; e->deferred_single = true; e->deferred_epoch = e->ctl_epoch;
         e->deferred_unit_cap = n_docs; e->deferred_n_docs = n_docs;
     } else {
         {
@@ -886,7 +891,7 @@ int scan_pipeline(gft_engine* e, const uint8_t* d_text, const uint64_t* d_doc_of
 // block -- the batch's only host synchronisation.  *again = the unit table or the match pool was too small (they have
 // been grown): the caller runs the batch once more, this time with the sizes known.
 // (what the launch of a deferred batch knew: the engine's fields at that time, or a pipelined batch's snapshot of them)
-struct DeferredLaunch { bool single; uint64_t n_docs, unit_cap, static_slabs; };
+struct DeferredLaunch { bool single; uint64_t n_docs, unit_cap, static_slabs; uint32_t epoch; };   // epoch: of a k_units_single batch (its flags)
 int deferred_interpret(gft_engine* e, const uint64_t* rb, const DeferredLaunch& dl, bool* again);
 
 int deferred_check(gft_engine* e, bool* again) {
@@ -898,14 +903,16 @@ int deferred_check(gft_engine* e, bool* again) {
     uint64_t* rb = e->pin_rb;
     HIP_TRY(hipMemcpyAsync(rb, e->d_ctl.p, 7 * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream), "readback");
     HIP_TRY(hipStreamSynchronize(e->stream), "process pipeline");
-    return deferred_interpret(e, rb, DeferredLaunch{e->deferred_single, e->deferred_n_docs, e->deferred_unit_cap, e->last_static_slabs}, again);
+    return deferred_interpret(e, rb, DeferredLaunch{e->deferred_single, e->deferred_n_docs, e->deferred_unit_cap, e->last_static_slabs, e->deferred_single ? e->deferred_epoch : 0u}, again);
 }
 
 int deferred_interpret(gft_engine* e, const uint64_t* rb, const DeferredLaunch& dl, bool* again) {
     *again = false;
     const uint64_t cursor = rb[1] + dl.static_slabs, total = rb[2], n_units = rb[4], text_lo = rb[5], text_hi = rb[6];
     e->last_nonascii_bits = (uint32_t)rb[3]; e->last_nonascii = e->last_nonascii_bits != 0;
-    if (dl.single && (uint32_t)(rb[3] >> 32)) {                  // a document of more than one unit: the general path
+    // (a k_units_single batch raises its flags to its epoch; what an earlier batch left there is smaller)
+    const bool flag_bad = dl.single ? (uint32_t)rb[0] == dl.epoch : (uint32_t)rb[0] != 0;
+    if (dl.single && (uint32_t)(rb[3] >> 32) == dl.epoch) {      // a document of more than one unit: the general path
         e->single_streak = -8;
         *again = true;
         return GFT_OK;
@@ -914,7 +921,7 @@ int deferred_interpret(gft_engine* e, const uint64_t* rb, const DeferredLaunch& 
     e->last_text_lo = text_lo; e->last_text_hi = text_hi;
     e->last_n_units = n_units; e->last_total = total;
     if (text_hi < text_lo) return fail(e, GFT_E_INVALID, "doc_off is not ascending");
-    if ((uint32_t)rb[0]) return fail(e, GFT_E_INVALID, "doc_off is not ascending, or a document is longer than 4 GiB - 1 bytes (positions are 32-bit)");
+    if (flag_bad) return fail(e, GFT_E_INVALID, "doc_off is not ascending, or a document is longer than 4 GiB - 1 bytes (positions are 32-bit)");
     // (the DFA kernel's cursor counts matches, the suffix-window kernels' slabs: both must fit the pool)
     if (n_units > dl.unit_cap || cursor > e->pool_cap) {
         if (cursor > e->pool_cap) { int rc = ensure_pool(e, cursor + cursor / 16); if (rc) return rc; }
@@ -2147,7 +2154,7 @@ int gft_process_device_begin(gft_engine* e, const uint8_t* d_text_blob, const ui
             if (!o.done) {
                 if (hipEventSynchronize(o.ev) != hipSuccess) { o.rc = fail(e, GFT_E_HIP, "event wait"); o.done = true; break; }
                 bool again = false;
-                o.rc = deferred_interpret(e, o.rb, DeferredLaunch{o.single, o.n_docs_cap, o.unit_cap, o.static_slabs}, &again);
+                o.rc = deferred_interpret(e, o.rb, DeferredLaunch{o.single, o.n_docs_cap, o.unit_cap, o.static_slabs, o.single ? o.epoch : 0u}, &again);
                 if (!o.rc && again) { e->pend_count = 0; o.rc = gft_process_device(e, o.d_text, o.d_doc_off, o.n_docs, o.flags, nullptr, o.d_bitmap); e->pend_count = 1; }
                 else if (!o.rc) { DeviceGuard g2(e->device); o.rc = refine_nonascii(e, o.d_text, o.d_doc_off, o.n_docs, o.flags); }
                 o.done = true;
@@ -2179,7 +2186,7 @@ int gft_process_device_begin(gft_engine* e, const uint8_t* d_text_blob, const ui
     e->deferred = false;
     if (!pb.rb) HIP_TRY(hipHostMalloc((void**)&pb.rb, 64, hipHostMallocDefault), "pinned alloc");
     if (!pb.ev) HIP_TRY(hipEventCreateWithFlags(&pb.ev, hipEventDisableTiming), "event");
-    pb.single = e->deferred_single; pb.n_docs_cap = e->deferred_n_docs; pb.unit_cap = e->deferred_unit_cap; pb.static_slabs = e->last_static_slabs;
+    pb.single = e->deferred_single; pb.epoch = e->deferred_epoch; pb.n_docs_cap = e->deferred_n_docs; pb.unit_cap = e->deferred_unit_cap; pb.static_slabs = e->last_static_slabs;
     HIP_TRY(hipMemcpyAsync(pb.rb, e->d_ctl.p, 7 * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream), "readback");
     HIP_TRY(hipEventRecord(pb.ev, e->stream), "event");
     e->pend_count++;
@@ -2196,7 +2203,7 @@ int gft_process_device_end(gft_engine* e) try {
     DeviceGuard g(e->device);
     if (hipEventSynchronize(pb.ev) != hipSuccess) { pop(); return fail(e, GFT_E_HIP, "event wait"); }
     bool again = false;
-    int rc = deferred_interpret(e, pb.rb, DeferredLaunch{pb.single, pb.n_docs_cap, pb.unit_cap, pb.static_slabs}, &again);
+    int rc = deferred_interpret(e, pb.rb, DeferredLaunch{pb.single, pb.n_docs_cap, pb.unit_cap, pb.static_slabs, pb.single ? pb.epoch : 0u}, &again);
     if (!rc && again) {
         // this batch outgrew the unit table or the match pool (both have been grown): once more, with its own synchronisations.
         // A younger batch in flight is behind it on the stream; it keeps its own bitmap and its own verdict.

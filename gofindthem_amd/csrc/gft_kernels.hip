@@ -82,17 +82,20 @@ __global__ void __launch_bounds__(256) k_unit_fill(const uint64_t* __restrict__ 
 // general path (count, prefix sum, fill).
 __global__ void __launch_bounds__(256) k_units_single(const uint64_t* __restrict__ doc_off, uint64_t n_docs, uint32_t unit_max,
                                                       Unit* __restrict__ units, uint64_t* __restrict__ unit_base,
-                                                      uint32_t* __restrict__ ctl32) {
+                                                      uint32_t* __restrict__ ctl32, uint32_t epoch) {
     const uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (d == 0) {
+        // the control block of the batch: cursor, match count and the non-ASCII word start at zero (nobody else in this
+        // launch touches them); the two flags are not cleared but RAISED TO THE BATCH'S EPOCH by whoever has cause to
         uint64_t* ctl64 = reinterpret_cast<uint64_t*>(ctl32);
         unit_base[n_docs] = n_docs;
+        ctl32[1] = 0; ctl64[1] = 0; ctl64[2] = 0; ctl32[6] = 0;
         ctl64[4] = n_docs; ctl64[5] = doc_off[0]; ctl64[6] = doc_off[n_docs];
     }
     if (d >= n_docs) return;
     uint64_t n = doc_off[d + 1] - doc_off[d];
-    if (n > 0xFFFFFFFFull) { atomicOr(ctl32, 1u); n = 0; }       // (as k_unit_count)
-    if (n > unit_max) { atomicOr(ctl32 + 7, 1u); n = unit_max; }  // (no kernel ever sees a unit longer than unit_max)
+    if (n > 0xFFFFFFFFull) { atomicMax(ctl32, epoch); n = 0; }       // (as k_unit_count)
+    if (n > unit_max) { atomicMax(ctl32 + 7, epoch); n = unit_max; }  // (no kernel ever sees a unit longer than unit_max)
     units[d] = Unit{(uint32_t)d, 0u, (uint32_t)n};
     unit_base[d] = d;
 }
@@ -650,9 +653,9 @@ hipError_t launch_unit_fill(const uint64_t* d_doc_off, uint64_t n_docs, const ui
 }
 
 hipError_t launch_units_single(const uint64_t* d_doc_off, uint64_t n_docs, uint32_t unit_max, Unit* d_units, uint64_t* d_unit_base,
-                               uint32_t* d_ctl32, hipStream_t st) {
+                               uint32_t* d_ctl32, uint32_t epoch, hipStream_t st) {
     if (!n_docs) return hipSuccess;
-    k_units_single<<<dim3((unsigned)((n_docs + 255) / 256)), dim3(256), 0, st>>>(d_doc_off, n_docs, unit_max, d_units, d_unit_base, d_ctl32);
+    k_units_single<<<dim3((unsigned)((n_docs + 255) / 256)), dim3(256), 0, st>>>(d_doc_off, n_docs, unit_max, d_units, d_unit_base, d_ctl32, epoch);
     return hipGetLastError();
 }
 

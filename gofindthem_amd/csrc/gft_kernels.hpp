@@ -408,7 +408,7 @@ hipError_t launch_pack_ctl(const uint64_t* d_unit_base, const uint64_t* d_doc_of
 hipError_t launch_unit_fill(const uint64_t* d_doc_off, uint64_t n_docs, const uint64_t* d_unit_base, Unit* d_units,
                             uint32_t unit_max, hipStream_t st, uint64_t max_units = ~0ull);
 hipError_t launch_units_single(const uint64_t* d_doc_off, uint64_t n_docs, uint32_t unit_max, Unit* d_units, uint64_t* d_unit_base,
-                               uint32_t* d_ctl32, hipStream_t st);
+                               uint32_t* d_ctl32, uint32_t epoch, hipStream_t st);
 hipError_t launch_patch_words(uint32_t* d_words, const uint64_t* d_idx, const uint32_t* d_clr, const uint32_t* d_set, uint64_t n, hipStream_t st);
 hipError_t launch_clamp_u64(uint64_t* d_v, uint64_t n, uint64_t cap, hipStream_t st);
 uint64_t scan_partials_needed(uint64_t n);

@@ -608,3 +608,50 @@ def test_process_device_begin_end_pipelines_two_batches():
     assert np.array_equal(b[3].cpu().numpy().astype(np.uint32), b[4])
     assert L.gft_last_nonascii(f.engine_handle()) == 0
     f.close()
+
+
+def test_steady_state_batches_are_scanned_once():
+    """A sequence of equal batches settles on ONE scan launch and ONE solver launch per batch: the
+    deferred verdict (gft_api.cpp deferred_interpret) must not send a batch of single-unit documents around again, on the
+    synchronous entry point and with two batches in flight alike -- a rerun is invisible in the results, so the profile
+    counters (gft_profile_read) are what this test reads."""
+    import ctypes as C
+    import torch
+    from gofindthem_amd.workload import Workload, make_expressions
+    L = _lib_load()
+    w = Workload(1000)
+    exprs = make_expressions(w.terms(), 100, inord_fraction=0.2, cover=True)
+    f = Finder(GpuEngine(), EmptyRgxEngine(), False)
+    f.AddExpressions(exprs)
+    o = Oracle(sorted(f.GetKeywords()))
+    o.set_expressions(exprs, False)
+    words = (len(exprs) + 31) // 32
+    text, off = w.docs_host(0, 400)
+    want = o.process(text, off, fold=True)
+    docs = [bytes(text[int(off[d]):int(off[d + 1])]).decode() for d in range(400)]
+    t, od = _device_batch(docs)
+    bms = [torch.zeros((400, words), dtype=torch.int32, device="cuda") for _ in range(2)]
+    for _ in range(6):                                 # sizes learnt, deferred, then the one-launch unit table
+        f.ProcessDevice(t.data_ptr(), od.data_ptr(), 400, bms[0].data_ptr())
+    eh = f.engine_handle()
+
+    def launches(name):
+        ms, n = C.c_double(), C.c_uint64()
+        assert L.gft_profile_read(eh, name.encode(), C.byref(ms), C.byref(n)) == 0
+        return n.value
+
+    L.gft_profile_enable(eh, 1)
+    L.gft_profile_reset(eh)
+    for _ in range(12):
+        f.ProcessDevice(t.data_ptr(), od.data_ptr(), 400, bms[0].data_ptr())
+    assert launches("scan") == 12 and launches("solve") == 12
+    L.gft_profile_reset(eh)
+    for i in range(12):
+        f.ProcessDeviceBegin(t.data_ptr(), od.data_ptr(), 400, bms[i % 2].data_ptr())
+        if i:
+            f.ProcessDeviceEnd()
+    f.ProcessDeviceEnd()
+    assert launches("scan") == 12 and launches("solve") == 12
+    L.gft_profile_enable(eh, 0)
+    for bm in bms:
+        assert np.array_equal(bm.cpu().numpy().astype(np.uint32), want)

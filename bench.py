@@ -160,7 +160,10 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()                                # (the warm-up batches are complete -- a rerun of the last one included -- before anything is counted)
-    L.gft_profile_enable(eh, 1)
+    # (mode 2: HIP events around the scan kernel's launches only -- the kernel the roofline prices.  Every bracket is two
+    # event nodes on the stream, a few microseconds between two kernels each; the solver's and the auxiliary kernels'
+    # times are read from the same step run again behind the timed region, below)
+    L.gft_profile_enable(eh, 2)
     L.gft_profile_reset(eh)
     fence()
     t0 = time.perf_counter()
@@ -176,19 +179,21 @@ def main():
         L.gft_profile_read(eh, name.encode(), C.byref(ms), C.byref(n))
         return ms.value, int(n.value)
     scan_ms, scan_n = prof("scan")
-    solve_ms, solve_n = prof("solve")
-    aux_ms, aux_n = prof("aux")
     # the spread of the dominant kernel from launch to launch: the same step again, every launch read on its own (behind the
     # timed region -- reading the events synchronises)
     scan_each = []
+    solve_ms = aux_ms = 0.0
+    again_steps = min(args.steps, 20)
     L.gft_profile_enable(eh, 1)
-    for _ in range(min(args.steps, 20)):
+    for _ in range(again_steps):
         L.gft_profile_reset(eh)
         step()
         fence()
         ms1, n1 = prof("scan")
         if n1:
             scan_each.append(ms1 / n1)
+        solve_ms += prof("solve")[0]
+        aux_ms += prof("aux")[0]
     L.gft_profile_enable(eh, 0)
 
     # ---- same-run consistency that needs no oracle: the corpus generator's host and device forms agree on a sample,
@@ -313,8 +318,10 @@ def main():
                          "scan_ms_median": float(np.median(scan_each)) if scan_each else None,
                          "scan_ms_stddev": float(np.std(scan_each)) if scan_each else None,
                          "scan_ms_spread_launches": len(scan_each)},
-            "kernels_ms_per_step": {"scan": scan_ms / args.steps, "solve": solve_ms / args.steps,
-                                    "aux(units+prefix sums+gather)": aux_ms / args.steps},
+            "kernels_ms_per_step": {"scan": scan_ms / args.steps, "solve": solve_ms / max(again_steps, 1),
+                                    "aux(units+prefix sums+gather)": aux_ms / max(again_steps, 1),
+                                    "how": "scan: HIP events inside the timed region; solve, aux: the same step run %d more "
+                                           "times behind it with every launch bracketed" % again_steps},
             "cpu_baseline": cpu,
             "go_reference": go_ref,
             "parity": parity if parity_ok else "PARITY FAILED",

@@ -212,7 +212,8 @@ struct gft_engine {
     std::vector<uint32_t> h_term, h_pos;
 
     // profiling
-    bool profiling = false;
+    int profiling = 0;                     // gft_profile_enable: 0 off, 1 every category, 2 the scan kernel only
+    std::vector<hipEvent_t> prof_pool;     // events given back by gft_profile_reset
     std::map<std::string, ProfCat> prof;
 };
 
@@ -271,8 +272,12 @@ struct ProfScope {
     gft_engine* e;
     hipEvent_t a = nullptr, b = nullptr;
     ProfScope(gft_engine* e_, const char* cat) : e(e_) {
-        if (!e->profiling) return;
-        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+        if (!e->profiling || (e->profiling == 2 && std::strcmp(cat, "scan") != 0)) return;
+        auto get = [&](hipEvent_t* ev) {
+            if (!e->prof_pool.empty()) { *ev = e->prof_pool.back(); e->prof_pool.pop_back(); return true; }
+            return hipEventCreate(ev) == hipSuccess;
+        };
+        if (!get(&a) || !get(&b)) { a = b = nullptr; return; }
         (void)hipEventRecord(a, e->stream);
         e->prof[cat].ev.emplace_back(a, b);
     }
@@ -1361,7 +1366,8 @@ void gft_engine_destroy(gft_engine* e) {
         DeviceGuard g(e->device);
         if (e->stream) (void)hipStreamSynchronize(e->stream);
         for (auto& kv : e->prof)
-            for (auto& p : kv.second.ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+            for (auto& p : kv.second.ev) { e->prof_pool.push_back(p.first); e->prof_pool.push_back(p.second); }
+        for (hipEvent_t ev : e->prof_pool) (void)hipEventDestroy(ev);
         DevBuf* all[] = {&e->d_byte_class, &e->d_delta, &e->d_out_term, &e->d_out_link, &e->d_term_len, &e->d_prog,
                          &e->d_prog_off, &e->d_fprog, &e->d_fprog_off, &e->d_groups, &e->d_wide_slot, &e->d_wide_theta, &e->d_wide_list, &e->d_order, &e->d_blk_class, &e->d_wave_blk, &e->d_fprog_t, &e->d_fblk_off, &e->d_pscratch, &e->d_solve_dbg, &e->d_s2_filter,
                          &e->d_s2_slots, &e->d_s2_more, &e->d_s2_cls, &e->d_s2_cls_fold, &e->d_s2_term_blob,
@@ -2457,7 +2463,7 @@ int gft_debug_host_solve(const uint32_t* words, uint64_t len, const uint32_t* sl
 int gft_profile_enable(gft_engine* e, int on) try {
     if (!e) return GFT_E_INVALID;
     GFT_LOCK(e);
-    e->profiling = on != 0;
+    e->profiling = on == 2 ? 2 : on != 0;
     return GFT_OK;
 } GFT_CATCH((e ? &e->err : nullptr))
 
@@ -2468,7 +2474,7 @@ int gft_profile_reset(gft_engine* e) try {
     DeviceGuard g(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (auto& kv : e->prof) {
-        for (auto& p : kv.second.ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+        for (auto& p : kv.second.ev) { e->prof_pool.push_back(p.first); e->prof_pool.push_back(p.second); }
         kv.second.ev.clear();
     }
     return GFT_OK;

@@ -298,7 +298,9 @@ int gft_regex_required_literals(const uint8_t* pattern, uint64_t len, char* out,
 int gft_to_lower(const uint8_t* in, uint64_t len, uint8_t* out, uint64_t cap, uint64_t* needed);
 
 /* ---- measurement hooks (bench.py) ---------------------------------------------------------------------- */
-/* When enabled, every kernel launch is bracketed by HIP events on the engine's stream. */
+/* on = 1: every kernel launch is bracketed by HIP events on the engine's stream (categories "scan", "solve", "aux");
+ * on = 2: the scan kernel's launches only -- an event record is a node of its own on the stream, a few microseconds
+ * between two kernels: a run that is being timed as a whole brackets the one kernel it prices; 0: off. */
 int gft_profile_enable(gft_engine* e, int on);
 /* Sums since the last reset.  names: "scan", "solve", "aux".  Synchronises the stream. */
 int gft_profile_read(gft_engine* e, const char* name, double* total_ms, uint64_t* launches);

@@ -724,7 +724,11 @@ hipError_t launch_scan5(const Scan2Params& P, unsigned n_cus, hipStream_t st) {
                        (size_t)kScan5Waves * scan5_wave_lds(P.s5_fifo_cap, P.cand_cap);
     using Kern = void (*)(const Scan2Params);
     // (the timing-study instantiations exist for the direct short-term table only)
+#ifdef GFT_S5_SG_CLOCKS       // (study builds, tools/build_variant.sh: the phase clocks of the large-alphabet instantiation)
+    const Kern fn = P.s5_sG ? (P.dbg && fl ? k_scan5<true, true, true> : fl ? k_scan5<true, false, true> : k_scan5<false, false, true>)
+#else
     const Kern fn = P.s5_sG ? (fl ? k_scan5<true, false, true> : k_scan5<false, false, true>)
+#endif
                     : P.dbg ? (fl ? k_scan5<true, true, false> : k_scan5<false, true, false>) : (fl ? k_scan5<true, false, false> : k_scan5<false, false, false>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;

@@ -18,6 +18,6 @@ def _fuzz():
 
 @pytest.mark.parametrize("seed", [7, 8])
 def test_scan_fuzz_slice(seed):
-    done, err = _fuzz().run(iters=40, seed=seed, budget_s=60.0)
+    done, err = _fuzz().run(iters=30, seed=seed, budget_s=60.0)
     assert err is None, err
     assert done >= 10

@@ -40,6 +40,9 @@ def main():
     ap.add_argument("--cpu-docs", type=int, default=-1, help="documents in the CPU baseline sample (-1 auto, 0 off)")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--parity-docs", type=int, default=2048)
+    ap.add_argument("--cu-margin", type=int, default=-1,
+                    help="compute units left free of the engine's persistent kernels (gft_set_cu_margin); default: 0 on one GPU, "
+                         "2 x N (at most 16) on N > 1, where RCCL's send / receive kernels of batch i's gather run beside batch i + 1")
     ap.add_argument("--alphabet", choices=["lower", "mixed"], default="lower",
                     help="lower: SURVEY.md 8(d) corpus over a-z (the configuration the metric is quoted on); mixed: the same "
                          "words with capitals, digits, punctuation and two-byte UTF-8 letters (> 48 byte classes, a real "
@@ -89,6 +92,10 @@ def main():
     eh = finder.engine_handle()
     stream = torch.cuda.current_stream().cuda_stream
     assert L.gft_set_stream(eh, stream) == 0
+    # N > 1: the scan and solver kernels hold every CU they run on (one workgroup with the CU's whole LDS), so RCCL's kernels
+    # would wait for a launch to end and then keep the next launch's workgroups waiting; a few CUs are left to them
+    cu_margin = args.cu_margin if args.cu_margin >= 0 else (min(16, 2 * world) if world > 1 else 0)
+    assert L.gft_set_cu_margin(eh, cu_margin) == 0
     from gofindthem_amd.sharding import BitmapGather, all_ranks_ok, max_over_ranks, shard_range, split_docs
     total_docs = args.docs if args.scaling == "strong" else args.docs * world
     if args.scaling == "strong":
@@ -308,7 +315,7 @@ def main():
                        "alphabet": args.alphabet, "keywords": n_keywords,
                        "docs_total": total_docs, "docs_per_gpu": args.docs, "text_bytes_per_gpu": text_bytes, "matches_per_gpu": n_matches,
                        "matches_per_doc": n_matches / args.docs, "matches_per_doc_max": hits_max,
-                       "parallelism": "docs sharded x%d" % world},
+                       "parallelism": "docs sharded x%d" % world, "cu_margin": cu_margin},
             "roofline": {"bound": "hbm", "kernel": kernel_names.get(scan_kernel, scan_kernel), "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,
                          "measured_read_ceiling": ceiling_gbps, "frac_of_measured_ceiling": achieved / ceiling_gbps,

@@ -39,6 +39,7 @@ SYMBOLS = {
     "gft_process_device_multi": (_i, [_vp, _vp, _vp, _vp, _u32, _vp]),
     "gft_last_error": (C.c_char_p, [_vp]),
     "gft_set_stream": (_i, [_vp, _vp]),
+    "gft_set_cu_margin": (_i, [_vp, C.c_uint32]),
     "gft_build": (_i, [_vp, _vp, _vp, _u32, _u32]),
     "gft_export_tables": (_i, [_vp, _vp, _u64, C.POINTER(_u64)]),
     "gft_import_tables": (_i, [_vp, C.c_char_p, _u64]),

@@ -76,7 +76,8 @@ struct gft_engine {
     hipEvent_t pin_ev[2] = {nullptr, nullptr};
     std::unique_ptr<gft::CopyPool> copy_pool;   // the threads that fill / empty the bounce buffers (created with the first large copy)
     bool own_stream = false;
-    unsigned n_cus = 256;
+    unsigned n_cus = 256;                  // CUs the persistent kernels fill: the device's minus cu_margin
+    unsigned n_cus_hw = 256, cu_margin = 0;
     size_t lds_max = 65536;
     mutable std::string err;
 
@@ -1344,7 +1345,9 @@ int gft_engine_create(gft_engine** out, int device) try {
     DeviceGuard g(device);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
-        e->n_cus = prop.multiProcessorCount > 0 ? (unsigned)prop.multiProcessorCount : 256;
+        e->n_cus_hw = prop.multiProcessorCount > 0 ? (unsigned)prop.multiProcessorCount : 256;
+        if (const char* m = getenv("GFT_CU_MARGIN")) { const int v = atoi(m); if (v > 0) e->cu_margin = (unsigned)v; }
+        e->n_cus = e->n_cus_hw > e->cu_margin ? e->n_cus_hw - e->cu_margin : 1;
         int optin = 0;
         if (hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, device) != hipSuccess) optin = 0;
         e->lds_max = std::max<size_t>(prop.sharedMemPerBlock, (size_t)std::max(optin, 0));
@@ -1409,6 +1412,16 @@ int gft_set_stream(gft_engine* e, void* hip_stream) try {
     return GFT_OK;
 } GFT_CATCH((e ? &e->err : nullptr))
 
+
+int gft_set_cu_margin(gft_engine* e, uint32_t margin) try {
+    if (!e) return GFT_E_INVALID;
+    GFT_LOCK(e);
+    if (e->device < 0) return fail(e, GFT_E_HIP, "no HIP device available");
+    if (e->pend_count) return fail(e, GFT_E_INVALID, "batches are in flight (gft_process_device_end first)");
+    e->cu_margin = margin;
+    e->n_cus = e->n_cus_hw > margin ? e->n_cus_hw - margin : 1;
+    return GFT_OK;
+} GFT_CATCH((e ? &e->err : nullptr))
 
 // e->tab / e->s2 hold compiled tables (from gft_build or gft_import_tables): check them against the device, upload
 static int install_tables(gft_engine* e, uint32_t flags) {

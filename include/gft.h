@@ -76,6 +76,12 @@ const char* gft_last_error(const gft_engine* e);
  * default stream, plain hipMemcpy) can be handed to the *_device entry points without an explicit synchronisation.
  * Every entry point returns after its work has completed. */
 int gft_set_stream(gft_engine* e, void* hip_stream);
+/* Leave `margin` compute units free of this engine's kernels (default 0; environment: GFT_CU_MARGIN).  The scan and solver
+ * kernels are persistent -- one workgroup per CU that holds the CU's whole LDS for the length of the launch --, so a kernel
+ * of somebody else's (RCCL's send / receive kernels when the bitmap gather of batch i travels beside batch i + 1, bench.py
+ * N > 1) finds no CU until they exit and then keeps the next launch's workgroups waiting.  With a margin those kernels
+ * always find room; the batch's kernels run on n_cus - margin CUs.  Not while batches are in flight. */
+int gft_set_cu_margin(gft_engine* e, uint32_t margin);
 
 /* ---- SubstringEngine.BuildEngine (finder/substringEngine.go:98-106) ----------------------------------- */
 /* Receives the full keyword set (already lower-cased by the DSL parser when case-insensitive,

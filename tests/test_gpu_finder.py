@@ -655,3 +655,36 @@ def test_steady_state_batches_are_scanned_once():
     L.gft_profile_enable(eh, 0)
     for bm in bms:
         assert np.array_equal(bm.cpu().numpy().astype(np.uint32), want)
+
+
+def test_cu_margin_leaves_results_alone():
+    """gft_set_cu_margin (what bench.py sets for N > 1 so that RCCL's kernels find a CU beside the persistent scan and solver
+    workgroups): the same bitmaps on 240 CUs, on ONE CU (a margin larger than the device) and on all of them again; refused
+    while a batch is in flight."""
+    import torch
+    from gofindthem_amd.workload import Workload, make_expressions
+    L = _lib_load()
+    w = Workload(1000)
+    exprs = make_expressions(w.terms(), 100, inord_fraction=0.3, cover=True)
+    f = Finder(GpuEngine(), EmptyRgxEngine(), False)
+    f.AddExpressions(exprs)
+    o = Oracle(sorted(f.GetKeywords()))
+    o.set_expressions(exprs, False)
+    words = (len(exprs) + 31) // 32
+    text, off = w.docs_host(0, 600)
+    want = o.process(text, off, fold=True)
+    docs = [bytes(text[int(off[d]):int(off[d + 1])]).decode() for d in range(600)]
+    t, od = _device_batch(docs)
+    bm = torch.zeros((600, words), dtype=torch.int32, device="cuda")
+    f.ProcessDevice(t.data_ptr(), od.data_ptr(), 600, bm.data_ptr())       # (the engine exists from here on)
+    eh = f.engine_handle()
+    for margin in (16, 100000, 0):
+        assert L.gft_set_cu_margin(eh, margin) == 0
+        for _ in range(4):                                                 # first, deferred and one-launch-unit-table batches
+            bm.zero_()
+            f.ProcessDevice(t.data_ptr(), od.data_ptr(), 600, bm.data_ptr())
+            assert np.array_equal(bm.cpu().numpy().astype(np.uint32), want)
+    f.ProcessDeviceBegin(t.data_ptr(), od.data_ptr(), 600, bm.data_ptr())
+    assert L.gft_set_cu_margin(eh, 8) != 0
+    f.ProcessDeviceEnd()
+    assert L.gft_set_cu_margin(eh, 8) == 0
